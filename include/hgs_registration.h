@@ -1,0 +1,161 @@
+/* hgs_registration.h — C-ABI of the MI355X-native scan-matching backend for hdl_graph_slam.
+ *
+ * This is the drop-in boundary behind
+ *     pcl::Registration<PointXYZI,PointXYZI>::Ptr hdl_graph_slam::select_registration_method(ros::NodeHandle&)
+ *     (reference: include/hdl_graph_slam/registrations.hpp:17, src/hdl_graph_slam/registrations.cpp:22-124).
+ * The pcl::Registration adapter that forwards to these entry points is adapters/registration_hip.hpp; the
+ * reference-side patch is shown in INTEGRATION.md.  Every function is extern "C", takes plain pointers and
+ * sizes, returns an int status (HGS_OK == 0) and never throws.  There is no global mutable state: each
+ * hgs_handle owns one HIP stream and its device buffers, so the two engine instances that live in one
+ * nodelet manager (odometry: apps/scan_matching_odometry_nodelet.cpp:106, loop closure:
+ * include/hdl_graph_slam/loop_detector.hpp:47) can run concurrently from different threads.
+ *
+ * Conventions
+ *  - points: array of records with three consecutive floats x,y,z at the start of each record and a byte stride
+ *    (32 for pcl::PointXYZI, 16 for float4, 12 for packed xyz).  Non-finite points are ignored.
+ *  - 4x4 transforms: float[16], COLUMN-major (Eigen::Matrix4f::data()), mapping source -> target frame.
+ *  - indices returned to the caller always refer to the caller's original point order.
+ */
+#ifndef HGS_REGISTRATION_H
+#define HGS_REGISTRATION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGS_ABI_VERSION 1
+
+enum hgs_status {
+  HGS_OK = 0,
+  HGS_ERR_INVALID_ARGUMENT = 1,
+  HGS_ERR_NO_TARGET = 2,
+  HGS_ERR_NO_SOURCE = 3,
+  HGS_ERR_HIP = 4,      /* a HIP runtime call failed; hgs_last_error() has the text */
+  HGS_ERR_NO_DEVICE = 5,
+  HGS_ERR_UNSUPPORTED = 6
+};
+
+/* registration_method strings of registrations.cpp:26-121 that this backend implements. */
+enum hgs_method {
+  HGS_FAST_GICP = 0,  /* fast_gicp::FastGICP      — registrations.cpp:27-36   */
+  HGS_FAST_VGICP = 1, /* fast_gicp::FastVGICP     — registrations.cpp:48-56   */
+  HGS_NDT_OMP = 2     /* pclomp::NormalDistributionsTransform — registrations.cpp:101-120 */
+};
+
+/* reg_nn_search_method (registrations.cpp:103,112-118) / FastVGICP neighbour search. */
+enum hgs_neighbor_search {
+  HGS_KDTREE = 0,
+  HGS_DIRECT1 = 1,
+  HGS_DIRECT7 = 2,
+  HGS_DIRECT27 = 3
+};
+
+typedef struct hgs_params {
+  int32_t method;                     /* hgs_method                                                        */
+  int32_t max_iterations;             /* reg_maximum_iterations           (64)                             */
+  double transformation_epsilon;      /* reg_transformation_epsilon       (0.01)                           */
+  double rotation_epsilon;            /* fast_gicp LsqRegistration        (2e-3), not exposed by hdl       */
+  double max_correspondence_distance; /* reg_max_correspondence_distance  (2.5), FAST_GICP only            */
+  int32_t correspondence_randomness;  /* reg_correspondence_randomness    (20) = k of the covariance kNN   */
+  int32_t neighbor_search;            /* hgs_neighbor_search: NDT (DIRECT7), VGICP (DIRECT1)               */
+  double resolution;                  /* reg_resolution                   (NDT 0.5 / VGICP 1.0)            */
+  double ndt_step_size;               /* pclomp NDT step_size_            (0.1)                            */
+  double ndt_outlier_ratio;           /* pclomp NDT outlier_ratio_        (0.55)                           */
+  int32_t ndt_min_points_per_voxel;   /* VoxelGridCovariance              (6)                              */
+  int32_t ndt_upstream_hd1_sign;      /* 1: reproduce upstream h_ang_d1 = (.., .., +sy); 0: exact 2nd derivative */
+  int32_t lm_max_iterations;          /* fast_gicp LM inner tries         (10)                             */
+  double lm_init_lambda_factor;       /* fast_gicp                        (1e-9)                           */
+  int32_t device_id;                  /* HIP device ordinal                                                */
+  int32_t reserved;
+} hgs_params;
+
+typedef struct hgs_result {
+  float final_transformation[16]; /* getFinalTransformation(), column-major                                    */
+  int32_t converged;              /* hasConverged()                                                            */
+  int32_t iterations;             /* outer iterations executed                                                 */
+  double error;                   /* GICP/VGICP: last accepted sum e^T M e; NDT: trans_probability (score/N)  */
+  double fitness_score;           /* getFitnessScore(max_range) — filled by the batch entry point, else NaN    */
+  uint32_t num_inliers;           /* #source points with d2 <= max_range in that score                         */
+  int32_t candidate_id;           /* index into the caller's candidate list (batch), else 0                    */
+  int32_t lm_tries;               /* GICP: total LM tries; NDT: derivative passes                              */
+  int32_t reserved;
+} hgs_result;
+
+typedef struct hgs_handle hgs_handle; /* one registration engine instance (one pcl::Registration object)   */
+typedef struct hgs_cloud hgs_cloud;   /* a point cloud resident in HBM (a KeyFrame::cloud, keyframe.hpp:42) */
+
+/* ---- engine life cycle -------------------------------------------------------------------------------- */
+/* Fill *p with the factory defaults of registrations.cpp for `method`. */
+int hgs_params_default(int32_t method, hgs_params* p);
+/* Replaces `new fast_gicp::FastGICP / pclomp::NormalDistributionsTransform` + setters, registrations.cpp:27-36,101-120. */
+int hgs_create(const hgs_params* p, hgs_handle** out);
+int hgs_destroy(hgs_handle* h);
+const char* hgs_last_error(const hgs_handle* h); /* h may be NULL: error of the last failed hgs_create on this thread */
+int hgs_abi_version(void);
+
+/* ---- clouds resident on the device -------------------------------------------------------------------- */
+/* Upload + pack a host cloud (H2D on the handle's stream).  The cloud caches its search structure and
+ * covariances once an engine has computed them, like fast_gicp keeps them per input pointer. */
+int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, hgs_cloud** out);
+int hgs_cloud_destroy(hgs_cloud* c);
+size_t hgs_cloud_size(const hgs_cloud* c);
+/* Drop cached search structure / covariances (forces the cold path again; used by benchmarks). */
+int hgs_cloud_invalidate(hgs_cloud* c);
+
+/* ---- pcl::Registration surface (methods the callers use: SURVEY §8b) ---------------------------------- */
+/* setInputTarget — scan_matching_odometry_nodelet.cpp:172,246 ; loop_detector.hpp:122 */
+int hgs_set_target(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes);
+int hgs_set_target_cloud(hgs_handle* h, hgs_cloud* c); /* borrowed, must outlive its use */
+/* setInputSource — scan_matching_odometry_nodelet.cpp:177 ; loop_detector.hpp:136 */
+int hgs_set_source(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes);
+int hgs_set_source_cloud(hgs_handle* h, hgs_cloud* c);
+/* align(output, guess) + hasConverged() + getFinalTransformation() — odometry_nodelet.cpp:210-220 ; loop_detector.hpp:143-153 */
+int hgs_align(hgs_handle* h, const float guess[16], hgs_result* out);
+/* The `output` cloud of align(): out_pts[i].xyz = T * source[i].xyz (records of stride_bytes; other bytes untouched). */
+int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t stride_bytes);
+/* getFitnessScore(max_range) with PCL's semantics (information_matrix_calculator.cpp:49-80): mean of the
+ * squared 1-NN distances d2 over source points with d2 <= max_range (sic), DBL_MAX if none. */
+int hgs_fitness(hgs_handle* h, const float T[16], double max_range, double* score, uint32_t* num_inliers);
+/* getSearchMethodTarget()->nearestKSearch(pt, 1, ...) for a batch of query points (odometry_nodelet.cpp:314-321). */
+int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_bytes, int32_t* idx, float* d2);
+
+/* ---- loop-closure batch: LoopDetector::matching, loop_detector.hpp:117-171 ----------------------------- */
+/* Registers every candidate (source) against the handle's current target with its own guess, then evaluates
+ * getFitnessScore(max_range) for each.  out[i] is filled for all candidates.  *best receives the index the
+ * sequential rule of loop_detector.hpp:147-153 selects (skip non-converged, skip score > best, ties replace ->
+ * the LAST minimal candidate wins), or -1 if none. */
+int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_candidates, const float* guesses /* 16*n */,
+                         double max_range, hgs_result* out, int32_t* best);
+/* Pure host helper: the sequential selection rule above applied to an arbitrary record list (used after the
+ * multi-GPU all-gather of per-candidate records). */
+int hgs_select_best(const hgs_result* records, size_t n, int32_t* best);
+
+/* ---- "next" row f1: InformationMatrixCalculator::calc_fitness_score (information_matrix_calculator.cpp:49-80) */
+int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, const float relpose[16], double max_range, double* score);
+
+/* ---- measurement ---------------------------------------------------------------------------------------- */
+enum hgs_stage {
+  HGS_STAGE_UPLOAD = 0,     /* H2D + pack                                            */
+  HGS_STAGE_INDEX = 1,      /* spatial sort + bounding-interval tree build           */
+  HGS_STAGE_COVARIANCE = 2, /* kNN covariance pre-pass (GICP/VGICP)                  */
+  HGS_STAGE_VOXELIZE = 3,   /* Gaussian voxel table build (NDT / VGICP)              */
+  HGS_STAGE_LINEARIZE = 4,  /* correspondence search + J^T M J accumulation (GICP) / NDT derivatives */
+  HGS_STAGE_ERROR = 5,      /* LM trial error evaluation                             */
+  HGS_STAGE_SOLVE = 6,      /* 6x6 reductions + solve + LM/Newton update             */
+  HGS_STAGE_FITNESS = 7,    /* fitness score NN pass                                 */
+  HGS_STAGE_COUNT = 8
+};
+/* Enable/disable hipEvent bracketing of every kernel stage on the handle's stream (adds sync cost when read). */
+int hgs_profile_enable(hgs_handle* h, int enabled);
+/* Accumulated GPU milliseconds and launch counts per stage since the last reset; arrays of HGS_STAGE_COUNT. */
+int hgs_profile_read(hgs_handle* h, double* ms, uint64_t* launches, int reset);
+/* Block until everything enqueued on the handle's stream has finished. */
+int hgs_synchronize(hgs_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGS_REGISTRATION_H */

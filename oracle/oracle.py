@@ -1,0 +1,277 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes front-end of oracle/libhgs_oracle.so (CPU restatement of the
+fast_gicp / ndt_omp engines that src/hdl_graph_slam/registrations.cpp:22-124 selects).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  Parity is UNPINNED by
+the reference (no tests / golden vectors upstream; engines live in un-vendored dependencies) — see DESIGN.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libhgs_oracle.so")
+
+HGS_FAST_GICP, HGS_FAST_VGICP, HGS_NDT_OMP = 0, 1, 2
+HGS_KDTREE, HGS_DIRECT1, HGS_DIRECT7, HGS_DIRECT27 = 0, 1, 2, 3
+
+
+class HgsParams(C.Structure):
+    _fields_ = [
+        ("method", C.c_int32), ("max_iterations", C.c_int32),
+        ("transformation_epsilon", C.c_double), ("rotation_epsilon", C.c_double),
+        ("max_correspondence_distance", C.c_double),
+        ("correspondence_randomness", C.c_int32), ("neighbor_search", C.c_int32),
+        ("resolution", C.c_double), ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double),
+        ("ndt_min_points_per_voxel", C.c_int32), ("ndt_upstream_hd1_sign", C.c_int32),
+        ("lm_max_iterations", C.c_int32), ("lm_init_lambda_factor", C.c_double),
+        ("device_id", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class HgsResult(C.Structure):
+    _fields_ = [
+        ("final_transformation", C.c_float * 16), ("converged", C.c_int32), ("iterations", C.c_int32),
+        ("error", C.c_double), ("fitness_score", C.c_double), ("num_inliers", C.c_uint32),
+        ("candidate_id", C.c_int32), ("lm_tries", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+    def matrix(self) -> np.ndarray:
+        return np.array(self.final_transformation, dtype=np.float32).reshape(4, 4).T.copy()  # column-major -> numpy
+
+
+def default_params(method: int) -> HgsParams:
+    """Factory defaults of src/hdl_graph_slam/registrations.cpp (same values as hgs_params_default)."""
+    p = HgsParams()
+    p.method = method
+    p.max_iterations = 64
+    p.transformation_epsilon = 0.01
+    p.rotation_epsilon = 2e-3
+    p.max_correspondence_distance = 2.5 if method == HGS_FAST_GICP else 3.4028234663852886e38
+    p.correspondence_randomness = 20
+    p.neighbor_search = HGS_DIRECT7 if method == HGS_NDT_OMP else HGS_DIRECT1
+    p.resolution = 0.5 if method == HGS_NDT_OMP else 1.0
+    p.ndt_step_size = 0.1
+    p.ndt_outlier_ratio = 0.55
+    p.ndt_min_points_per_voxel = 6
+    p.ndt_upstream_hd1_sign = 1
+    p.lm_max_iterations = 10
+    p.lm_init_lambda_factor = 1e-9
+    p.device_id = 0
+    return p
+
+
+def build(force: bool = False) -> str:
+    src_newer = False
+    if os.path.exists(_LIB_PATH):
+        t = os.path.getmtime(_LIB_PATH)
+        for f in os.listdir(_HERE):
+            if f.endswith((".cpp", ".hpp")) and os.path.getmtime(os.path.join(_HERE, f)) > t:
+                src_newer = True
+    if force or src_newer or not os.path.exists(_LIB_PATH):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "all"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.hgso_create.restype = C.c_void_p
+        L.hgso_create.argtypes = [C.POINTER(HgsParams)]
+        L.hgso_destroy.argtypes = [C.c_void_p]
+        for name in ("hgso_set_target", "hgso_set_source"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        L.hgso_align.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(HgsResult)]
+        L.hgso_fitness.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        L.hgso_nn_target.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.hgso_trace_len.argtypes = [C.c_void_p]
+        L.hgso_trace_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.hgso_knn.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.hgso_covariances.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        L.hgso_gicp_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hgso_gicp_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hgso_ndt_cells.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hgso_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hgso_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
+        L.hgso_solve6.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.hgso_eig_sym3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hgso_euler_xyz.argtypes = [C.c_void_p, C.c_void_p]
+        L.hgso_ndt_pose.argtypes = [C.c_void_p, C.c_void_p]
+        L.hgso_set_num_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _cloud_args(cloud: np.ndarray):
+    cloud = np.ascontiguousarray(cloud)
+    if cloud.dtype.fields is not None:
+        return cloud, len(cloud), cloud.dtype.itemsize
+    cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+    return cloud, cloud.shape[0], cloud.strides[0]
+
+
+def colmajor16(T: np.ndarray):
+    a = np.ascontiguousarray(np.asarray(T, dtype=np.float32).T.reshape(16))  # numpy row-major -> column-major
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def set_num_threads(n: int) -> int:
+    return lib().hgso_set_num_threads(n)
+
+
+class OracleRegistration:
+    """pcl::Registration-shaped front-end over the CPU oracle."""
+
+    def __init__(self, params: HgsParams):
+        self.params = params
+        self._h = lib().hgso_create(C.byref(params))
+        self._keep = {}
+        self.result = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().hgso_destroy(self._h)
+            self._h = None
+
+    def setInputTarget(self, cloud):
+        c, n, s = _cloud_args(cloud)
+        self._keep["t"] = c
+        lib().hgso_set_target(self._h, _ptr(c), n, s)
+
+    def setInputSource(self, cloud):
+        c, n, s = _cloud_args(cloud)
+        self._keep["s"] = c
+        self.n_source = n
+        lib().hgso_set_source(self._h, _ptr(c), n, s)
+
+    def align(self, guess=None) -> HgsResult:
+        g, gp = colmajor16(np.eye(4) if guess is None else guess)
+        r = HgsResult()
+        rc = lib().hgso_align(self._h, gp, C.byref(r))
+        assert rc == 0
+        self.result = r
+        return r
+
+    def hasConverged(self):
+        return bool(self.result.converged)
+
+    def getFinalTransformation(self):
+        return self.result.matrix()
+
+    def getFitnessScore(self, max_range=np.finfo(np.float64).max, T=None):
+        T = self.getFinalTransformation() if T is None else T
+        g, gp = colmajor16(T)
+        score, ninl = C.c_double(), C.c_uint32()
+        lib().hgso_fitness(self._h, gp, max_range, C.byref(score), C.byref(ninl))
+        self.last_num_inliers = ninl.value
+        return score.value
+
+    def nn_target(self, q_xyz: np.ndarray):
+        q = np.ascontiguousarray(q_xyz, dtype=np.float32)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float32)
+        lib().hgso_nn_target(self._h, _ptr(q), len(q), q.strides[0], _ptr(idx), _ptr(d2))
+        return idx, d2
+
+    def trace(self) -> np.ndarray:
+        n = lib().hgso_trace_len(self._h)
+        w = 8 if self.params.method == HGS_NDT_OMP else 14
+        out = np.zeros((n, w))
+        for i in range(n):
+            lib().hgso_trace_get(self._h, i, _ptr(out[i]))
+        return out
+
+    # ---- stage level
+    def gicp_linearize(self, T: np.ndarray):
+        T12 = np.ascontiguousarray(np.asarray(T, dtype=np.float64)[:3, :4])
+        H, b, err = np.zeros((6, 6)), np.zeros(6), np.zeros(1)
+        corr = np.empty(self.n_source, np.int32)
+        rc = lib().hgso_gicp_linearize(self._h, _ptr(T12), _ptr(H), _ptr(b), _ptr(err), _ptr(corr))
+        assert rc == 0
+        return H, b, float(err[0]), corr
+
+    def gicp_error(self, T: np.ndarray) -> float:
+        T12 = np.ascontiguousarray(np.asarray(T, dtype=np.float64)[:3, :4])
+        err = np.zeros(1)
+        assert lib().hgso_gicp_error(self._h, _ptr(T12), _ptr(err)) == 0
+        return float(err[0])
+
+    def ndt_cells(self):
+        cap = 1 << 20
+        ijk = np.zeros((cap, 3), np.int32)
+        mean = np.zeros((cap, 3))
+        icov = np.zeros((cap, 6))
+        npts = np.zeros(cap, np.int32)
+        n = lib().hgso_ndt_cells(self._h, cap, _ptr(ijk), _ptr(mean), _ptr(icov), _ptr(npts))
+        n = min(n, cap)
+        return ijk[:n].copy(), mean[:n].copy(), icov[:n].copy(), npts[:n].copy()
+
+    def ndt_derivatives(self, p6):
+        p = np.ascontiguousarray(p6, dtype=np.float64)
+        score, g, H = np.zeros(1), np.zeros(6), np.zeros((6, 6))
+        assert lib().hgso_ndt_derivatives(self._h, _ptr(p), _ptr(score), _ptr(g), _ptr(H)) == 0
+        return float(score[0]), g, H
+
+
+def knn(points: np.ndarray, queries: np.ndarray, k: int, brute: bool = False):
+    p, n, s = _cloud_args(points)
+    q, nq, qs = _cloud_args(queries)
+    idx = np.empty((nq, k), np.int32)
+    d2 = np.empty((nq, k), np.float32)
+    lib().hgso_knn(_ptr(p), n, s, _ptr(q), nq, qs, k, int(brute), _ptr(idx), _ptr(d2))
+    return idx, d2
+
+
+def covariances(points: np.ndarray, k: int = 20) -> np.ndarray:
+    p, n, s = _cloud_args(points)
+    out = np.zeros((n, 6))
+    lib().hgso_covariances(_ptr(p), n, s, k, _ptr(out))
+    return out
+
+
+def se3_exp(d6) -> np.ndarray:
+    d = np.ascontiguousarray(d6, dtype=np.float64)
+    T = np.zeros((3, 4))
+    lib().hgso_se3_exp(_ptr(d), _ptr(T))
+    return np.vstack([T, [0, 0, 0, 1]])
+
+
+def solve6(A, b, svd=False) -> np.ndarray:
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(6)
+    lib().hgso_solve6(_ptr(A), _ptr(b), int(svd), _ptr(x))
+    return x
+
+
+def eig_sym3(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    w, V = np.zeros(3), np.zeros((3, 3))
+    lib().hgso_eig_sym3(_ptr(A), _ptr(w), _ptr(V))
+    return w, V
+
+
+def euler_xyz(R) -> np.ndarray:
+    R = np.ascontiguousarray(R, dtype=np.float32)
+    out = np.zeros(3, np.float32)
+    lib().hgso_euler_xyz(_ptr(R), _ptr(out))
+    return out
+
+
+def ndt_pose(p6) -> np.ndarray:
+    p = np.ascontiguousarray(p6, dtype=np.float64)
+    T = np.zeros((3, 4))
+    lib().hgso_ndt_pose(_ptr(p), _ptr(T))
+    return np.vstack([T, [0, 0, 0, 1]])

@@ -1,0 +1,143 @@
+"""Second, independent restatement (numpy / scipy, float64) of the per-stage arithmetic of SURVEY.md Appendix A,
+used to cross-check the C++ oracle (SURVEY §4 test plan item 3).  Small inputs only."""
+from __future__ import annotations
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def se3_exp(d):
+    """Rodrigues + V matrix; d = [omega, v] (fast_gicp so3.hpp)."""
+    w, v = np.asarray(d[:3], float), np.asarray(d[3:], float)
+    th = np.linalg.norm(w)
+    W = skew(w)
+    if th < 1e-10:
+        R = np.eye(3) + W
+        V = R
+    else:
+        R = np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th**2 * W @ W
+        V = np.eye(3) + (1 - np.cos(th)) / th**2 * W + (th - np.sin(th)) / th**3 * W @ W
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = V @ v
+    return T
+
+
+def gicp_covariances(xyz, k=20):
+    xyz = np.asarray(xyz, np.float64)
+    tree = cKDTree(xyz)
+    _, idx = tree.query(xyz, k=k)
+    nb = xyz[idx]                                  # [n,k,3]
+    c = nb - nb.mean(axis=1, keepdims=True)
+    C = np.einsum("nki,nkj->nij", c, c) / k
+    C = C + 1e-3 * np.eye(3)
+    Ci = np.linalg.inv(C)
+    Ci = Ci / np.linalg.norm(Ci, axis=(1, 2), keepdims=True)
+    return np.linalg.inv(Ci)
+
+
+def gicp_linearize(src, tgt, cov_s, cov_t, T, max_corr):
+    src, tgt = np.asarray(src, np.float64), np.asarray(tgt, np.float64)
+    R, t = T[:3, :3], T[:3, 3]
+    q = src @ R.T + t
+    d, j = cKDTree(tgt).query(q)
+    valid = d * d < max_corr**2
+    H, b, err = np.zeros((6, 6)), np.zeros(6), 0.0
+    for i in np.flatnonzero(valid):
+        M = np.linalg.inv(cov_t[j[i]] + R @ cov_s[i] @ R.T)
+        e = tgt[j[i]] - q[i]
+        J = np.hstack([skew(q[i]), -np.eye(3)])
+        H += J.T @ M @ J
+        b += J.T @ M @ e
+        err += e @ M @ e
+    return H, b, err, np.where(valid, j, -1)
+
+
+def fitness(src, tgt, T, max_range):
+    q = np.asarray(src, np.float64) @ T[:3, :3].T + T[:3, 3]
+    d, _ = cKDTree(np.asarray(tgt, np.float64)).query(q)
+    d2 = d * d
+    m = d2 <= max_range
+    return (d2[m].mean() if m.any() else np.finfo(np.float64).max), int(m.sum())
+
+
+def ndt_cells(xyz, res, min_points=6):
+    """dict (i,j,k) -> (n, mean, icov) following VoxelGridCovariance::applyFilter."""
+    xyz32 = np.asarray(xyz, np.float32)
+    inv = np.float32(1.0) / np.float32(res)
+    ijk = np.floor(xyz32 * inv).astype(np.int64)
+    cells = {}
+    x64 = xyz32.astype(np.float64)
+    order = np.lexsort((ijk[:, 0], ijk[:, 1], ijk[:, 2]))
+    ijk_s = ijk[order]
+    brk = np.flatnonzero(np.concatenate([[True], np.any(ijk_s[1:] != ijk_s[:-1], axis=1)]))
+    ends = np.concatenate([brk[1:], [len(order)]])
+    for s, e in zip(brk, ends):
+        n = e - s
+        if n < min_points:
+            continue
+        p = x64[order[s:e]]
+        mean = p.sum(0) / n
+        cov = (p.T @ p - 2 * np.outer(p.sum(0), mean)) / n + np.outer(mean, mean)
+        cov *= (n - 1.0) / n
+        w, V = np.linalg.eigh((cov + cov.T) / 2)
+        if w[0] < 0 or w[1] < 0 or w[2] <= 0:
+            continue
+        mn = 0.01 * w[2]
+        if w[0] < mn:
+            w = w.copy()
+            w[0] = mn
+            w[1] = max(w[1], mn)
+            cov = V @ np.diag(w) @ np.linalg.inv(V)
+        cells[tuple(ijk_s[s])] = (n, mean, np.linalg.inv(cov))
+    return cells
+
+
+def ndt_pose(p):
+    cx, sx, cy, sy, cz, sz = np.cos(p[3]), np.sin(p[3]), np.cos(p[4]), np.sin(p[4]), np.cos(p[5]), np.sin(p[5])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rx @ Ry @ Rz
+    T[:3, 3] = p[:3]
+    return T
+
+
+def ndt_gauss(res, outlier_ratio=0.55):
+    c1 = 10 * (1 - outlier_ratio)
+    c2 = outlier_ratio / res**3
+    d3 = -np.log(c2)
+    d1 = -np.log(c1 + c2) - d3
+    d2 = -2 * np.log((-np.log(c1 * np.exp(-0.5) + c2) - d3) / d1)
+    return d1, d2
+
+
+def ndt_score(src, cells, p, res, direct7=True, freeze_p=None):
+    """Score only (float64), for finite-difference checks of the oracle's analytic gradient/Hessian."""
+    d1, d2 = ndt_gauss(res)
+    # cell assignment optionally frozen at pose freeze_p (the score is discontinuous where points change cells)
+    T = ndt_pose(p if freeze_p is None else freeze_p).astype(np.float32)
+    src32 = np.asarray(src, np.float32)
+    q = (src32 @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    inv = np.float32(1.0) / np.float32(res)
+    ijk = np.floor(q * inv).astype(np.int64)
+    offs = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)] if direct7 else [(0, 0, 0)]
+    # exact (float64) transform for the smooth part so FD is not dominated by float32 rounding
+    q64 = np.asarray(src, np.float64) @ ndt_pose(p)[:3, :3].T + np.asarray(p[:3], np.float64)
+    score = 0.0
+    for i in range(len(q)):
+        for o in offs:
+            c = cells.get((ijk[i, 0] + o[0], ijk[i, 1] + o[1], ijk[i, 2] + o[2]))
+            if c is None:
+                continue
+            x = q64[i] - c[1]
+            e = np.exp(-d2 / 2 * x @ c[2] @ x)
+            if not (0 <= d2 * e <= 1):
+                continue
+            score += -d1 * e
+    return score
