@@ -1,0 +1,101 @@
+// hgs_device.h — structures shared between the host engine (hgs_engine.hip) and the kernels (hgs_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hgs_gicp.h"
+#include "hgs_ndt.h"
+
+namespace hgs {
+
+// Per-cloud mutable header living in HBM next to the cloud's arrays.
+struct CloudMeta {
+  int nvalid;            // number of finite points (written by k_bbox_count)
+  int ndt_ncells;        // number of valid Gaussian cells (NDT target)
+  unsigned bbmin[3];     // order-preserving uint encoding of the float bounding box
+  unsigned bbmax[3];
+  int ndt_min_b[3], ndt_max_b[3], ndt_div_mul[3];
+  int ndt_error;         // 1: voxel grid larger than INT_MAX cells (upstream aborts)
+  int pad[3];
+};
+
+// Read-only description of one cloud resident in HBM.
+struct CloudDesc {
+  const float4* raw;  // [n_input]  original order, .w = original index (int bits)
+  float4* pts;        // [P*kLeaf]  Hilbert order, .w = original index, padding = +inf
+  float4* nodes;      // [4*P]      implicit tree AABBs
+  float4* cov;        // [2*P*kLeaf] GICP covariance of sorted point i: {xx,xy,xz,yy},{yz,zz,0,0}
+  int* corr;          // [P*kLeaf]  scratch: correspondence (sorted target position or -1) when used as a source
+  CloudMeta* meta;
+  int n_input;
+  int P;
+  int sort_off;       // offset of this cloud's segment in the batch sort arrays
+  int pad;
+};
+
+struct TargetView {
+  const float4* nodes;
+  const float4* pts;
+  const float4* cov;
+  const CloudMeta* meta;
+  int P;
+  int pad;
+};
+
+// NDT target tables
+struct NdtTargetView {
+  const int* hash_keys;
+  const int* hash_vals;
+  const NdtCellRec* cells;
+  const CloudMeta* meta;
+  int hash_mask;
+  float inv_leaf;
+};
+
+struct DevResult {
+  float T[16];  // column-major
+  int converged, iterations, lm_tries, pad;
+  double error;
+  double fit_sum;  // sum of d2 over inliers
+  unsigned fit_count;
+  unsigned pad2;
+};
+
+constexpr int kBlock = 256;
+
+// ---- launchers (hgs_kernels.hip) --------------------------------------------------------------------------
+void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw);
+void launch_meta_init(hipStream_t s, const CloudDesc* descs, int ncloud);
+void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n);
+void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals);
+void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int max_slots, const unsigned* sorted_vals);
+void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int max_P);
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k);
+
+void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, int* done_counter);
+void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B);
+void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B);
+void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B);
+void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B, int* done_counter);
+void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out, int B);
+
+void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks, int B);
+void launch_fitness_final(hipStream_t s, const CloudDesc* descs, const double* partials, int max_blocks, DevResult* out, int B);
+void launch_nn_query(hipStream_t s, TargetView tgt, const float4* q, int nq, int* idx, float* d2);
+void launch_transform(hipStream_t s, const float4* raw, int n, const float* T16_colmajor_dev, float4* out);
+
+void launch_ndt_grid_params(hipStream_t s, CloudDesc desc, float inv_leaf);
+void launch_ndt_cell_keys(hipStream_t s, CloudDesc desc, float inv_leaf, unsigned long long* keys, unsigned* vals);
+void launch_ndt_build_cells(hipStream_t s, CloudDesc desc, const unsigned long long* sorted_keys, const unsigned* sorted_vals, int min_points,
+                            int* hash_keys, int* hash_vals, int hash_mask, NdtCellRec* cells);
+void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, int* done_counter);
+void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles, NdtConsts c,
+                            double* partials, int max_blocks, int B);
+void launch_ndt_solve(hipStream_t s, const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c, const double* partials, int max_blocks,
+                      int B, int* done_counter);
+void launch_ndt_results(hipStream_t s, const CloudDesc* descs, const NdtState* states, DevResult* out, int B);
+
+// stage-level test hooks
+void launch_gicp_debug_state(hipStream_t s, GicpState* st, const double* T12_dev);
+void launch_ndt_debug_state(hipStream_t s, NdtState* st, NdtAngles* ang, const double* p6_dev, NdtConsts c);
+void launch_reduce_partials(hipStream_t s, const double* partials, int ntiles, double* out);
+
+}  // namespace hgs

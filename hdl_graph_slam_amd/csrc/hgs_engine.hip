@@ -1,0 +1,1051 @@
+// hgs_engine.hip — host side of the MI355X scan-matching backend: handle/cloud life cycle, batched
+// orchestration of the kernels in hgs_kernels.hip, and the extern "C" boundary declared in
+// include/hgs_registration.h (the replacement for the engines that
+// hdl_graph_slam::select_registration_method constructs, src/hdl_graph_slam/registrations.cpp:22-124).
+//
+// Control flow: every registration (odometry: ScanMatchingOdometryNodelet::matching,
+// apps/scan_matching_odometry_nodelet.cpp:165-262) is a batch of one; LoopDetector::matching
+// (include/hdl_graph_slam/loop_detector.hpp:117-171) is a batch of B candidates.  All B optimisers advance in
+// lock-step "rounds" of a fixed kernel sequence; each problem carries its own LM / Newton state machine in
+// HBM, so there is no per-iteration host decision — the host only polls a done-counter.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/hgs_registration.h"
+#include "hgs_device.h"
+#include "hgs_sort.h"
+
+using namespace hgs;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceBuffer {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct PinnedBuffer {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct hgs_cloud {
+  hgs_handle* owner = nullptr;
+  size_t n_input = 0;
+  int P = 1;
+  void* block = nullptr;
+  size_t block_bytes = 0;
+  CloudDesc desc{};
+  bool has_index = false;
+  bool has_cov = false;
+  int cov_k = 0;
+  // NDT target tables
+  bool has_ndt = false;
+  double ndt_resolution = 0;
+  int ndt_min_points = 0;
+  void* ndt_block = nullptr;
+  int* ndt_hash_keys = nullptr;
+  int* ndt_hash_vals = nullptr;
+  NdtCellRec* ndt_cells = nullptr;
+  int ndt_hash_cap = 0;
+};
+
+struct ProfEvent {
+  int stage;
+  hipEvent_t a, b;
+};
+
+struct hgs_handle {
+  hgs_params prm{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hgs_cloud* target = nullptr;
+  hgs_cloud* source = nullptr;
+  bool own_target = false, own_source = false;
+  float final_T[16];
+
+  DeviceBuffer staging, sort_keys[2], sort_vals[2], sort_tmp, descs, states, angles, partials, partials_err, results, guesses, done, misc;
+  PinnedBuffer h_descs, h_results, h_small;
+
+  bool profiling = false;
+  std::vector<ProfEvent> prof_events;
+  std::vector<ProfEvent> prof_free;
+  double prof_ms[HGS_STAGE_COUNT];
+  uint64_t prof_launches[HGS_STAGE_COUNT];
+};
+
+namespace {
+
+#define HGS_HIP(h, call)                                                                                           \
+  do {                                                                                                             \
+    hipError_t e__ = (call);                                                                                       \
+    if (e__ != hipSuccess) {                                                                                       \
+      char buf__[512];                                                                                             \
+      snprintf(buf__, sizeof(buf__), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__);  \
+      (h)->err = buf__;                                                                                            \
+      return HGS_ERR_HIP;                                                                                          \
+    }                                                                                                              \
+  } while (0)
+
+#define HGS_TRY(expr)             \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != HGS_OK) return rc__; \
+  } while (0)
+
+struct StageTimer {
+  hgs_handle* h;
+  ProfEvent ev{};
+  bool active = false;
+  StageTimer(hgs_handle* h_, int stage) : h(h_) {
+    if (!h->profiling) return;
+    if (!h->prof_free.empty()) {
+      ev = h->prof_free.back();
+      h->prof_free.pop_back();
+    } else {
+      if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+    }
+    ev.stage = stage;
+    active = hipEventRecord(ev.a, h->stream) == hipSuccess;
+  }
+  ~StageTimer() {
+    if (!active) return;
+    (void)hipEventRecord(ev.b, h->stream);
+    h->prof_events.push_back(ev);
+  }
+};
+
+int set_device(hgs_handle* h) {
+  HGS_HIP(h, hipSetDevice(h->device));
+  return HGS_OK;
+}
+
+// ---- cloud allocation --------------------------------------------------------------------------------------
+int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
+  hgs_cloud* c = new hgs_cloud();
+  c->owner = h;
+  c->n_input = n;
+  c->P = next_pow2((int)((n + kLeaf - 1) / kLeaf));
+  if (c->P < 1) c->P = 1;
+  const size_t slots = (size_t)c->P * kLeaf;
+  size_t off = 0;
+  const size_t o_meta = off;
+  off = align_up(off + sizeof(CloudMeta), 256);
+  const size_t o_raw = off;
+  off = align_up(off + std::max<size_t>(n, 1) * sizeof(float4), 256);
+  const size_t o_pts = off;
+  off = align_up(off + slots * sizeof(float4), 256);
+  const size_t o_nodes = off;
+  off = align_up(off + (size_t)4 * c->P * sizeof(float4), 256);
+  const size_t o_cov = off;
+  off = align_up(off + 2 * slots * sizeof(float4), 256);
+  const size_t o_corr = off;
+  off = align_up(off + slots * sizeof(int), 256);
+  c->block_bytes = off;
+  hipError_t e = hipMalloc(&c->block, off);
+  if (e != hipSuccess) {
+    h->err = std::string("hipMalloc(cloud) failed: ") + hipGetErrorString(e);
+    delete c;
+    return HGS_ERR_HIP;
+  }
+  char* base = (char*)c->block;
+  c->desc.meta = (CloudMeta*)(base + o_meta);
+  c->desc.raw = (const float4*)(base + o_raw);
+  c->desc.pts = (float4*)(base + o_pts);
+  c->desc.nodes = (float4*)(base + o_nodes);
+  c->desc.cov = (float4*)(base + o_cov);
+  c->desc.corr = (int*)(base + o_corr);
+  c->desc.n_input = (int)n;
+  c->desc.P = c->P;
+  c->desc.sort_off = 0;
+  c->desc.pad = 0;
+  *out = c;
+  return HGS_OK;
+}
+
+void cloud_free(hgs_cloud* c) {
+  if (!c) return;
+  if (c->block) (void)hipFree(c->block);
+  if (c->ndt_block) (void)hipFree(c->ndt_block);
+  delete c;
+}
+
+// Upload descriptors of a set of clouds (with their sort offsets) into h->descs; returns device pointer.
+int upload_descs(hgs_handle* h, const std::vector<hgs_cloud*>& clouds, bool with_sort_offsets, const CloudDesc** dev, size_t* total_n) {
+  const size_t B = clouds.size();
+  HGS_HIP(h, h->h_descs.reserve(B * sizeof(CloudDesc)));
+  HGS_HIP(h, h->descs.reserve(B * sizeof(CloudDesc)));
+  CloudDesc* hd = h->h_descs.as<CloudDesc>();
+  size_t off = 0;
+  for (size_t i = 0; i < B; i++) {
+    hd[i] = clouds[i]->desc;
+    hd[i].sort_off = with_sort_offsets ? (int)off : 0;
+    off += clouds[i]->n_input;
+  }
+  if (total_n) *total_n = off;
+  HGS_HIP(h, hipMemcpyAsync(h->descs.p, hd, B * sizeof(CloudDesc), hipMemcpyHostToDevice, h->stream));
+  *dev = h->descs.as<CloudDesc>();
+  return HGS_OK;
+}
+
+// Build the search index (Hilbert sort + implicit tree) of every cloud in the list that lacks one — one
+// batched kernel sequence and ONE radix sort for the whole list.
+int ensure_index(hgs_handle* h, const std::vector<hgs_cloud*>& all) {
+  std::vector<hgs_cloud*> todo;
+  for (hgs_cloud* c : all)
+    if (!c->has_index && std::find(todo.begin(), todo.end(), c) == todo.end()) todo.push_back(c);
+  if (todo.empty()) return HGS_OK;
+  // the key carries the cloud ordinal in bits 48.. ; process in chunks of at most 65536 clouds
+  for (size_t start = 0; start < todo.size(); start += 65536) {
+    std::vector<hgs_cloud*> chunk(todo.begin() + start, todo.begin() + std::min(todo.size(), start + 65536));
+    StageTimer tm(h, HGS_STAGE_INDEX);
+    const CloudDesc* d_descs = nullptr;
+    size_t total = 0;
+    HGS_TRY(upload_descs(h, chunk, true, &d_descs, &total));
+    int max_n = 0, max_P = 1;
+    for (hgs_cloud* c : chunk) max_n = std::max(max_n, (int)c->n_input), max_P = std::max(max_P, c->P);
+    const int nc = (int)chunk.size();
+    // meta (nvalid, bbox) was filled at upload time
+    if (total > 0) {
+      for (int i = 0; i < 2; i++) {
+        HGS_HIP(h, h->sort_keys[i].reserve(total * sizeof(uint64_t)));
+        HGS_HIP(h, h->sort_vals[i].reserve(total * sizeof(uint32_t)));
+      }
+      launch_hilbert_keys(h->stream, d_descs, nc, max_n, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
+      int bits = 48;
+      for (int v = nc - 1; v > 0; v >>= 1) bits++;
+      size_t tmp_bytes = 0;
+      int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                      h->sort_vals[1].as<uint32_t>(), total, 0, bits, h->stream);
+      if (rc != 0) {
+        h->err = "rocprim radix_sort_pairs (size query) failed";
+        return HGS_ERR_HIP;
+      }
+      HGS_HIP(h, h->sort_tmp.reserve(tmp_bytes));
+      rc = hgs_sort_pairs_u64_u32(h->sort_tmp.p, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                  h->sort_vals[1].as<uint32_t>(), total, 0, bits, h->stream);
+      if (rc != 0) {
+        h->err = "rocprim radix_sort_pairs failed";
+        return HGS_ERR_HIP;
+      }
+    }
+    launch_gather_sorted(h->stream, d_descs, nc, max_P * kLeaf, h->sort_vals[1].as<unsigned>());
+    launch_build_tree(h->stream, d_descs, nc, max_P);
+    HGS_HIP(h, hipGetLastError());
+    // descs buffer is reused by later stages: make sure this chunk's kernels were enqueued before it is overwritten
+    // (stream order guarantees that; the pinned staging copy needs the H2D to have completed)
+    HGS_HIP(h, hipStreamSynchronize(h->stream));
+    for (hgs_cloud* c : chunk) c->has_index = true;
+  }
+  return HGS_OK;
+}
+
+int ensure_cov(hgs_handle* h, const std::vector<hgs_cloud*>& all, int k) {
+  HGS_TRY(ensure_index(h, all));
+  std::vector<hgs_cloud*> todo;
+  for (hgs_cloud* c : all)
+    if ((!c->has_cov || c->cov_k != k) && std::find(todo.begin(), todo.end(), c) == todo.end()) todo.push_back(c);
+  if (todo.empty()) return HGS_OK;
+  StageTimer tm(h, HGS_STAGE_COVARIANCE);
+  const CloudDesc* d_descs = nullptr;
+  HGS_TRY(upload_descs(h, todo, false, &d_descs, nullptr));
+  int max_n = 0;
+  for (hgs_cloud* c : todo) max_n = std::max(max_n, (int)c->n_input);
+  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k);
+  HGS_HIP(h, hipGetLastError());
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  for (hgs_cloud* c : todo) c->has_cov = true, c->cov_k = k;
+  return HGS_OK;
+}
+
+int ensure_ndt_target(hgs_handle* h, hgs_cloud* c) {
+  const double res = h->prm.resolution;
+  const int min_pts = h->prm.ndt_min_points_per_voxel;
+  if (c->has_ndt && c->ndt_resolution == res && c->ndt_min_points == min_pts) return HGS_OK;
+  StageTimer tm(h, HGS_STAGE_VOXELIZE);
+  const size_t n = c->n_input;
+  const int max_cells = (int)(n / (size_t)std::max(1, min_pts)) + 1;
+  const int cap = next_pow2(std::max(64, 4 * max_cells));
+  if (!c->ndt_block || c->ndt_hash_cap != cap) {
+    if (c->ndt_block) (void)hipFree(c->ndt_block);
+    c->ndt_block = nullptr;
+    const size_t o_keys = 0, o_vals = align_up((size_t)cap * 4, 256), o_cells = o_vals + align_up((size_t)cap * 4, 256);
+    const size_t bytes = o_cells + (size_t)max_cells * sizeof(NdtCellRec);
+    HGS_HIP(h, hipMalloc(&c->ndt_block, bytes));
+    c->ndt_hash_keys = (int*)((char*)c->ndt_block + o_keys);
+    c->ndt_hash_vals = (int*)((char*)c->ndt_block + o_vals);
+    c->ndt_cells = (NdtCellRec*)((char*)c->ndt_block + o_cells);
+    c->ndt_hash_cap = cap;
+  }
+  HGS_HIP(h, hipMemsetAsync(c->ndt_hash_keys, 0xff, (size_t)cap * 4, h->stream));
+  const float inv_leaf = 1.0f / (float)res;
+  launch_ndt_grid_params(h->stream, c->desc, inv_leaf);
+  if (n > 0) {
+    for (int i = 0; i < 2; i++) {
+      HGS_HIP(h, h->sort_keys[i].reserve(n * sizeof(uint64_t)));
+      HGS_HIP(h, h->sort_vals[i].reserve(n * sizeof(uint32_t)));
+    }
+    launch_ndt_cell_keys(h->stream, c->desc, inv_leaf, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
+    size_t tmp_bytes = 0;
+    int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                    h->sort_vals[1].as<uint32_t>(), n, 0, 32, h->stream);
+    if (rc != 0) {
+      h->err = "rocprim radix_sort_pairs (size query) failed";
+      return HGS_ERR_HIP;
+    }
+    HGS_HIP(h, h->sort_tmp.reserve(tmp_bytes));
+    rc = hgs_sort_pairs_u64_u32(h->sort_tmp.p, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                h->sort_vals[1].as<uint32_t>(), n, 0, 32, h->stream);
+    if (rc != 0) {
+      h->err = "rocprim radix_sort_pairs failed";
+      return HGS_ERR_HIP;
+    }
+    launch_ndt_build_cells(h->stream, c->desc, h->sort_keys[1].as<unsigned long long>(), h->sort_vals[1].as<unsigned>(), min_pts, c->ndt_hash_keys,
+                           c->ndt_hash_vals, cap - 1, c->ndt_cells);
+  }
+  HGS_HIP(h, hipGetLastError());
+  c->has_ndt = true;
+  c->ndt_resolution = res;
+  c->ndt_min_points = min_pts;
+  return HGS_OK;
+}
+
+TargetView target_view(const hgs_cloud* c) {
+  TargetView t;
+  t.nodes = c->desc.nodes, t.pts = c->desc.pts, t.cov = c->desc.cov, t.meta = c->desc.meta, t.P = c->P, t.pad = 0;
+  return t;
+}
+
+GicpConsts gicp_consts(const hgs_params& p) {
+  GicpConsts c;
+  const double thr = p.max_correspondence_distance;
+  c.max_corr2 = thr * thr;
+  c.search_bound2 = c.max_corr2 >= (double)FLT_MAX ? FLT_MAX : nextafterf((float)c.max_corr2, FLT_MAX);
+  c.rotation_eps = p.rotation_epsilon;
+  c.translation_eps = p.transformation_epsilon;
+  c.lm_init_lambda_factor = p.lm_init_lambda_factor;
+  c.lm_max_iterations = p.lm_max_iterations;
+  c.max_iterations = p.max_iterations;
+  c.k_correspondences = p.correspondence_randomness;
+  return c;
+}
+
+NdtConsts ndt_consts(const hgs_params& p) {
+  NdtConsts c;
+  const double c1 = 10.0 * (1 - p.ndt_outlier_ratio);
+  const double c2 = p.ndt_outlier_ratio / std::pow(p.resolution, 3);
+  const double d3 = -std::log(c2);
+  c.gauss_d1 = -std::log(c1 + c2) - d3;
+  c.gauss_d2 = -2 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / c.gauss_d1);
+  c.step_size = p.ndt_step_size;
+  c.trans_eps = p.transformation_epsilon;
+  c.max_iterations = p.max_iterations;
+  c.search = p.neighbor_search == HGS_DIRECT1 ? 1 : 2;
+  c.upstream_hd1_sign = p.ndt_upstream_hd1_sign;
+  c.pad = 0;
+  return c;
+}
+
+// Read the device done-counter (tiny pinned D2H + stream sync).
+int read_done(hgs_handle* h, int* out) {
+  HGS_HIP(h, h->h_small.reserve(64));
+  HGS_HIP(h, hipMemcpyAsync(h->h_small.p, h->done.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  *out = *h->h_small.as<int>();
+  return HGS_OK;
+}
+
+// Run all B registrations (sources vs the handle's target) to completion; results land in h->results (device).
+int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float* guesses_host) {
+  const int B = (int)sources.size();
+  hgs_cloud* tgt = h->target;
+  const int method = h->prm.method;
+  if (method == HGS_FAST_VGICP) {
+    h->err = "FAST_VGICP is not implemented on the device yet";
+    return HGS_ERR_UNSUPPORTED;
+  }
+  std::vector<hgs_cloud*> all(sources);
+  if (method == HGS_FAST_GICP) {
+    all.push_back(tgt);
+    HGS_TRY(ensure_cov(h, all, h->prm.correspondence_randomness));
+  } else {
+    HGS_TRY(ensure_ndt_target(h, tgt));
+  }
+  int max_n = 0;
+  for (hgs_cloud* c : sources) max_n = std::max(max_n, (int)c->n_input);
+  const int max_blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
+  const CloudDesc* d_descs = nullptr;
+  HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
+  HGS_HIP(h, h->guesses.reserve((size_t)B * 16 * sizeof(float)));
+  HGS_HIP(h, hipMemcpyAsync(h->guesses.p, guesses_host, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HGS_HIP(h, h->done.reserve(64));
+  HGS_HIP(h, h->results.reserve((size_t)B * sizeof(DevResult)));
+  HGS_HIP(h, h->partials.reserve((size_t)B * max_blocks * kAcc * sizeof(double)));
+  HGS_HIP(h, h->partials_err.reserve((size_t)B * max_blocks * 2 * sizeof(double)));
+  int done = 0;
+  if (method == HGS_FAST_GICP) {
+    const GicpConsts c = gicp_consts(h->prm);
+    HGS_HIP(h, h->states.reserve((size_t)B * sizeof(GicpState)));
+    GicpState* st = h->states.as<GicpState>();
+    launch_gicp_init(h->stream, st, h->guesses.as<float>(), B, h->done.as<int>());
+    const TargetView tv = target_view(tgt);
+    const long max_rounds = (long)std::max(1, c.max_iterations) * std::max(1, c.lm_max_iterations) + 2;
+    long round = 0;
+    int next_check = 3;
+    while (round < max_rounds) {
+      {
+        StageTimer tm(h, HGS_STAGE_LINEARIZE);
+        launch_gicp_linearize(h->stream, d_descs, tv, st, c, h->partials.as<double>(), max_blocks, B);
+      }
+      {
+        StageTimer tm(h, HGS_STAGE_SOLVE);
+        launch_gicp_solve(h->stream, d_descs, st, c, h->partials.as<double>(), max_blocks, B);
+      }
+      {
+        StageTimer tm(h, HGS_STAGE_ERROR);
+        launch_gicp_error(h->stream, d_descs, tv, st, h->partials_err.as<double>(), max_blocks, B);
+      }
+      {
+        StageTimer tm(h, HGS_STAGE_SOLVE);
+        launch_gicp_decide(h->stream, d_descs, st, c, h->partials_err.as<double>(), max_blocks, B, h->done.as<int>());
+      }
+      round++;
+      if (round >= next_check) {
+        HGS_TRY(read_done(h, &done));
+        if (done >= B) break;
+        next_check = (int)round + 2;
+      }
+    }
+    launch_gicp_results(h->stream, st, h->results.as<DevResult>(), B);
+  } else {
+    const NdtConsts c = ndt_consts(h->prm);
+    HGS_HIP(h, h->states.reserve((size_t)B * sizeof(NdtState)));
+    HGS_HIP(h, h->angles.reserve((size_t)B * sizeof(NdtAngles)));
+    NdtState* st = h->states.as<NdtState>();
+    NdtAngles* ang = h->angles.as<NdtAngles>();
+    launch_ndt_init(h->stream, st, ang, h->guesses.as<float>(), c, B, h->done.as<int>());
+    NdtTargetView tv;
+    tv.hash_keys = tgt->ndt_hash_keys, tv.hash_vals = tgt->ndt_hash_vals, tv.cells = tgt->ndt_cells, tv.meta = tgt->desc.meta;
+    tv.hash_mask = tgt->ndt_hash_cap - 1, tv.inv_leaf = 1.0f / (float)h->prm.resolution;
+    const long max_rounds = (long)c.max_iterations + 4;
+    long round = 0;
+    int next_check = 4;
+    while (round < max_rounds) {
+      {
+        StageTimer tm(h, HGS_STAGE_LINEARIZE);
+        launch_ndt_derivatives(h->stream, d_descs, tv, st, ang, c, h->partials.as<double>(), max_blocks, B);
+      }
+      {
+        StageTimer tm(h, HGS_STAGE_SOLVE);
+        launch_ndt_solve(h->stream, d_descs, st, ang, c, h->partials.as<double>(), max_blocks, B, h->done.as<int>());
+      }
+      round++;
+      if (round >= next_check) {
+        HGS_TRY(read_done(h, &done));
+        if (done >= B) break;
+        next_check = (int)round + 3;
+      }
+    }
+    launch_ndt_results(h->stream, d_descs, st, h->results.as<DevResult>(), B);
+  }
+  HGS_HIP(h, hipGetLastError());
+  return HGS_OK;
+}
+
+// fitness of B sources against the target with the poses stored in h->results[b].T; fills fit_sum / fit_count
+int run_fitness(hgs_handle* h, const std::vector<hgs_cloud*>& sources, double max_range) {
+  const int B = (int)sources.size();
+  std::vector<hgs_cloud*> all(sources);
+  all.push_back(h->target);
+  HGS_TRY(ensure_index(h, all));
+  int max_n = 0;
+  for (hgs_cloud* c : sources) max_n = std::max(max_n, (int)c->n_input);
+  const int max_blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
+  const CloudDesc* d_descs = nullptr;
+  HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
+  HGS_HIP(h, h->partials_err.reserve((size_t)B * max_blocks * 2 * sizeof(double)));
+  StageTimer tm(h, HGS_STAGE_FITNESS);
+  launch_fitness(h->stream, d_descs, target_view(h->target), h->results.as<DevResult>(), max_range, h->partials_err.as<double>(), max_blocks, B);
+  launch_fitness_final(h->stream, d_descs, h->partials_err.as<double>(), max_blocks, h->results.as<DevResult>(), B);
+  HGS_HIP(h, hipGetLastError());
+  return HGS_OK;
+}
+
+int fetch_results(hgs_handle* h, int B, std::vector<DevResult>& out) {
+  HGS_HIP(h, h->h_results.reserve((size_t)B * sizeof(DevResult)));
+  HGS_HIP(h, hipMemcpyAsync(h->h_results.p, h->results.p, (size_t)B * sizeof(DevResult), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  out.assign(h->h_results.as<DevResult>(), h->h_results.as<DevResult>() + B);
+  return HGS_OK;
+}
+
+void to_public(const DevResult& d, int candidate, bool with_fitness, hgs_result* r) {
+  std::memcpy(r->final_transformation, d.T, sizeof(float) * 16);
+  r->converged = d.converged;
+  r->iterations = d.iterations;
+  r->error = d.error;
+  r->lm_tries = d.lm_tries;
+  r->candidate_id = candidate;
+  r->reserved = 0;
+  if (with_fitness) {
+    r->num_inliers = d.fit_count;
+    r->fitness_score = d.fit_count > 0 ? d.fit_sum / (double)d.fit_count : std::numeric_limits<double>::max();
+  } else {
+    r->num_inliers = 0;
+    r->fitness_score = std::numeric_limits<double>::quiet_NaN();
+  }
+}
+
+int upload_pose_as_result(hgs_handle* h, const float T[16]) {
+  HGS_HIP(h, h->results.reserve(sizeof(DevResult)));
+  HGS_HIP(h, h->h_results.reserve(sizeof(DevResult)));
+  DevResult* r = h->h_results.as<DevResult>();
+  std::memset(r, 0, sizeof(DevResult));
+  std::memcpy(r->T, T, sizeof(float) * 16);
+  HGS_HIP(h, hipMemcpyAsync(h->results.p, r, sizeof(DevResult), hipMemcpyHostToDevice, h->stream));
+  return HGS_OK;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" {
+
+int hgs_abi_version(void) { return HGS_ABI_VERSION; }
+
+int hgs_params_default(int32_t method, hgs_params* p) {
+  if (!p || method < HGS_FAST_GICP || method > HGS_NDT_OMP) return HGS_ERR_INVALID_ARGUMENT;
+  std::memset(p, 0, sizeof(*p));
+  p->method = method;
+  p->max_iterations = 64;                 // reg_maximum_iterations            registrations.cpp:32,54,110
+  p->transformation_epsilon = 0.01;       // reg_transformation_epsilon        registrations.cpp:31,53,109
+  p->rotation_epsilon = 2e-3;             // fast_gicp LsqRegistration default
+  p->max_correspondence_distance = method == HGS_FAST_GICP ? 2.5 : (double)FLT_MAX;  // registrations.cpp:33 (VGICP: not set)
+  p->correspondence_randomness = 20;      // reg_correspondence_randomness     registrations.cpp:34,55
+  p->neighbor_search = method == HGS_NDT_OMP ? HGS_DIRECT7 : HGS_DIRECT1;  // registrations.cpp:103
+  p->resolution = method == HGS_NDT_OMP ? 0.5 : 1.0;                        // registrations.cpp:93 / :52
+  p->ndt_step_size = 0.1;
+  p->ndt_outlier_ratio = 0.55;
+  p->ndt_min_points_per_voxel = 6;
+  p->ndt_upstream_hd1_sign = 1;
+  p->lm_max_iterations = 10;
+  p->lm_init_lambda_factor = 1e-9;
+  p->device_id = 0;
+  return HGS_OK;
+}
+
+int hgs_create(const hgs_params* p, hgs_handle** out) {
+  if (!p || !out) return HGS_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (p->method < HGS_FAST_GICP || p->method > HGS_NDT_OMP || p->max_iterations < 0 || p->correspondence_randomness < 1 || !(p->resolution > 0)) {
+    g_create_error = "invalid hgs_params";
+    return HGS_ERR_INVALID_ARGUMENT;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0 || p->device_id < 0 || p->device_id >= ndev) {
+    g_create_error = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device ordinal out of range");
+    return HGS_ERR_NO_DEVICE;
+  }
+  hgs_handle* h = new hgs_handle();
+  h->prm = *p;
+  h->device = p->device_id;
+  for (int i = 0; i < 16; i++) h->final_T[i] = (i % 5 == 0) ? 1.f : 0.f;
+  for (int i = 0; i < HGS_STAGE_COUNT; i++) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
+  if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_create_error = "hipSetDevice / hipStreamCreate failed";
+    delete h;
+    return HGS_ERR_HIP;
+  }
+  *out = h;
+  return HGS_OK;
+}
+
+int hgs_destroy(hgs_handle* h) {
+  if (!h) return HGS_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->own_target) cloud_free(h->target);
+  if (h->own_source) cloud_free(h->source);
+  DeviceBuffer* bufs[] = {&h->staging, &h->sort_keys[0], &h->sort_keys[1], &h->sort_vals[0], &h->sort_vals[1], &h->sort_tmp, &h->descs, &h->states,
+                          &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc};
+  for (DeviceBuffer* b : bufs) b->release();
+  h->h_descs.release();
+  h->h_results.release();
+  h->h_small.release();
+  for (auto& ev : h->prof_events) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
+  for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return HGS_OK;
+}
+
+const char* hgs_last_error(const hgs_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, hgs_cloud** out) {
+  if (!h || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
+  HGS_TRY(set_device(h));
+  hgs_cloud* c = nullptr;
+  HGS_TRY(cloud_alloc(h, n, &c));
+  {
+    StageTimer tm(h, HGS_STAGE_UPLOAD);
+    if (n > 0) {
+      hipError_t e = h->staging.reserve(n * stride_bytes);
+      if (e == hipSuccess) e = hipMemcpyAsync(h->staging.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream);
+      if (e != hipSuccess) {
+        h->err = std::string("upload failed: ") + hipGetErrorString(e);
+        cloud_free(c);
+        return HGS_ERR_HIP;
+      }
+      launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)n, const_cast<float4*>(c->desc.raw));
+    }
+    // nvalid + bounding box of the finite points
+    hipError_t e = h->descs.reserve(sizeof(CloudDesc));
+    if (e == hipSuccess) e = h->h_descs.reserve(sizeof(CloudDesc));
+    if (e == hipSuccess) {
+      *h->h_descs.as<CloudDesc>() = c->desc;
+      e = hipMemcpyAsync(h->descs.p, h->h_descs.p, sizeof(CloudDesc), hipMemcpyHostToDevice, h->stream);
+    }
+    if (e == hipSuccess) {
+      launch_meta_init(h->stream, h->descs.as<CloudDesc>(), 1);
+      launch_bbox_count(h->stream, h->descs.as<CloudDesc>(), 1, (int)n);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the caller may free / reuse `pts` after return
+    if (e != hipSuccess) {
+      h->err = std::string("cloud upload failed: ") + hipGetErrorString(e);
+      cloud_free(c);
+      return HGS_ERR_HIP;
+    }
+  }
+  *out = c;
+  return HGS_OK;
+}
+
+int hgs_cloud_destroy(hgs_cloud* c) {
+  if (!c) return HGS_OK;
+  hgs_handle* h = c->owner;
+  if (h) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->target == c) h->target = nullptr, h->own_target = false;
+    if (h->source == c) h->source = nullptr, h->own_source = false;
+  }
+  cloud_free(c);
+  return HGS_OK;
+}
+
+size_t hgs_cloud_size(const hgs_cloud* c) { return c ? c->n_input : 0; }
+
+int hgs_cloud_invalidate(hgs_cloud* c) {
+  if (!c) return HGS_ERR_INVALID_ARGUMENT;
+  c->has_index = false, c->has_cov = false, c->has_ndt = false;
+  return HGS_OK;
+}
+
+int hgs_set_target_cloud(hgs_handle* h, hgs_cloud* c) {
+  if (!h || !c) return HGS_ERR_INVALID_ARGUMENT;
+  if (h->own_target && h->target != c) cloud_free(h->target);
+  h->target = c;
+  h->own_target = false;
+  return HGS_OK;
+}
+int hgs_set_source_cloud(hgs_handle* h, hgs_cloud* c) {
+  if (!h || !c) return HGS_ERR_INVALID_ARGUMENT;
+  if (h->own_source && h->source != c) cloud_free(h->source);
+  h->source = c;
+  h->own_source = false;
+  return HGS_OK;
+}
+int hgs_set_target(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes) {
+  if (!h) return HGS_ERR_INVALID_ARGUMENT;
+  hgs_cloud* c = nullptr;
+  HGS_TRY(hgs_cloud_create(h, pts, n, stride_bytes, &c));
+  if (h->own_target) {
+    (void)hipStreamSynchronize(h->stream);
+    cloud_free(h->target);
+  }
+  h->target = c;
+  h->own_target = true;
+  return HGS_OK;
+}
+int hgs_set_source(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes) {
+  if (!h) return HGS_ERR_INVALID_ARGUMENT;
+  hgs_cloud* c = nullptr;
+  HGS_TRY(hgs_cloud_create(h, pts, n, stride_bytes, &c));
+  if (h->own_source) {
+    (void)hipStreamSynchronize(h->stream);
+    cloud_free(h->source);
+  }
+  h->source = c;
+  h->own_source = true;
+  return HGS_OK;
+}
+
+int hgs_align(hgs_handle* h, const float guess[16], hgs_result* out) {
+  if (!h || !guess || !out) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h->target) return HGS_ERR_NO_TARGET;
+  if (!h->source) return HGS_ERR_NO_SOURCE;
+  HGS_TRY(set_device(h));
+  std::vector<hgs_cloud*> src{h->source};
+  HGS_TRY(run_batch(h, src, guess));
+  std::vector<DevResult> r;
+  HGS_TRY(fetch_results(h, 1, r));
+  to_public(r[0], 0, false, out);
+  std::memcpy(h->final_T, out->final_transformation, sizeof(h->final_T));
+  return HGS_OK;
+}
+
+int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t stride_bytes) {
+  if (!h || !T || !out_pts || stride_bytes < 12) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h->source) return HGS_ERR_NO_SOURCE;
+  HGS_TRY(set_device(h));
+  const size_t n = h->source->n_input;
+  if (n == 0) return HGS_OK;
+  HGS_HIP(h, h->misc.reserve(n * sizeof(float4) + 256));
+  HGS_HIP(h, h->h_small.reserve(64));
+  float* dT = reinterpret_cast<float*>((char*)h->misc.p + n * sizeof(float4));
+  std::memcpy(h->h_small.p, T, 64);
+  HGS_HIP(h, hipMemcpyAsync(dT, h->h_small.p, 64, hipMemcpyHostToDevice, h->stream));
+  launch_transform(h->stream, h->source->desc.raw, (int)n, dT, h->misc.as<float4>());
+  std::vector<float> host(n * 4);
+  HGS_HIP(h, hipMemcpyAsync(host.data(), h->misc.p, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  char* o = (char*)out_pts;
+  for (size_t i = 0; i < n; i++) {
+    float* f = reinterpret_cast<float*>(o + i * stride_bytes);
+    f[0] = host[4 * i], f[1] = host[4 * i + 1], f[2] = host[4 * i + 2];
+    if (stride_bytes >= 16) f[3] = 1.0f;
+  }
+  return HGS_OK;
+}
+
+int hgs_fitness(hgs_handle* h, const float T[16], double max_range, double* score, uint32_t* num_inliers) {
+  if (!h || !T || !score) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h->target) return HGS_ERR_NO_TARGET;
+  if (!h->source) return HGS_ERR_NO_SOURCE;
+  HGS_TRY(set_device(h));
+  HGS_TRY(upload_pose_as_result(h, T));
+  std::vector<hgs_cloud*> src{h->source};
+  HGS_TRY(run_fitness(h, src, max_range));
+  std::vector<DevResult> r;
+  HGS_TRY(fetch_results(h, 1, r));
+  *score = r[0].fit_count > 0 ? r[0].fit_sum / (double)r[0].fit_count : std::numeric_limits<double>::max();
+  if (num_inliers) *num_inliers = r[0].fit_count;
+  return HGS_OK;
+}
+
+int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, const float relpose[16], double max_range, double* score) {
+  if (!h || !cloud1 || !cloud2 || !relpose || !score) return HGS_ERR_INVALID_ARGUMENT;
+  HGS_TRY(set_device(h));
+  hgs_cloud* saved_t = h->target;
+  h->target = cloud1;
+  int rc = upload_pose_as_result(h, relpose);
+  std::vector<hgs_cloud*> src{cloud2};
+  if (rc == HGS_OK) rc = run_fitness(h, src, max_range);
+  std::vector<DevResult> r;
+  if (rc == HGS_OK) rc = fetch_results(h, 1, r);
+  h->target = saved_t;
+  if (rc != HGS_OK) return rc;
+  *score = r[0].fit_count > 0 ? r[0].fit_sum / (double)r[0].fit_count : std::numeric_limits<double>::max();
+  return HGS_OK;
+}
+
+int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_bytes, int32_t* idx, float* d2) {
+  if (!h || (nq > 0 && (!q_xyz || !idx || !d2)) || stride_bytes < 12) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h->target) return HGS_ERR_NO_TARGET;
+  if (nq == 0) return HGS_OK;
+  HGS_TRY(set_device(h));
+  std::vector<hgs_cloud*> all{h->target};
+  HGS_TRY(ensure_index(h, all));
+  HGS_HIP(h, h->staging.reserve(nq * stride_bytes));
+  HGS_HIP(h, h->misc.reserve(nq * (sizeof(float4) + 8) + 512));
+  float4* dq = h->misc.as<float4>();
+  int* didx = reinterpret_cast<int*>((char*)h->misc.p + align_up(nq * sizeof(float4), 256));
+  float* dd2 = reinterpret_cast<float*>(didx + nq);
+  HGS_HIP(h, hipMemcpyAsync(h->staging.p, q_xyz, nq * stride_bytes, hipMemcpyHostToDevice, h->stream));
+  launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)nq, dq);
+  launch_nn_query(h->stream, target_view(h->target), dq, (int)nq, didx, dd2);
+  HGS_HIP(h, hipMemcpyAsync(idx, didx, nq * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipMemcpyAsync(d2, dd2, nq * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  return HGS_OK;
+}
+
+int hgs_select_best(const hgs_result* records, size_t n, int32_t* best) {
+  if (!best || (n > 0 && !records)) return HGS_ERR_INVALID_ARGUMENT;
+  // loop_detector.hpp:124,146-153: best_score starts at DBL_MAX; skip if !converged || score > best_score; else replace
+  double best_score = std::numeric_limits<double>::max();
+  int32_t b = -1;
+  for (size_t i = 0; i < n; i++) {
+    const double score = records[i].fitness_score;
+    if (!records[i].converged || score > best_score || score != score) continue;
+    best_score = score;
+    b = (int32_t)i;
+  }
+  *best = b;
+  return HGS_OK;
+}
+
+int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_candidates, const float* guesses, double max_range, hgs_result* out,
+                         int32_t* best) {
+  if (!h || (n_candidates > 0 && (!candidates || !guesses || !out))) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h->target) return HGS_ERR_NO_TARGET;
+  if (best) *best = -1;
+  if (n_candidates == 0) return HGS_OK;
+  HGS_TRY(set_device(h));
+  std::vector<hgs_cloud*> src(candidates, candidates + n_candidates);
+  for (hgs_cloud* c : src)
+    if (!c) return HGS_ERR_INVALID_ARGUMENT;
+  HGS_TRY(run_batch(h, src, guesses));
+  HGS_TRY(run_fitness(h, src, max_range));
+  std::vector<DevResult> r;
+  HGS_TRY(fetch_results(h, (int)n_candidates, r));
+  for (size_t i = 0; i < n_candidates; i++) to_public(r[i], (int)i, true, &out[i]);
+  if (best) HGS_TRY(hgs_select_best(out, n_candidates, best));
+  return HGS_OK;
+}
+
+int hgs_profile_enable(hgs_handle* h, int enabled) {
+  if (!h) return HGS_ERR_INVALID_ARGUMENT;
+  h->profiling = enabled != 0;
+  return HGS_OK;
+}
+
+int hgs_profile_read(hgs_handle* h, double* ms, uint64_t* launches, int reset) {
+  if (!h) return HGS_ERR_INVALID_ARGUMENT;
+  HGS_TRY(set_device(h));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  for (auto& ev : h->prof_events) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) {
+      h->prof_ms[ev.stage] += (double)t;
+      h->prof_launches[ev.stage]++;
+    }
+    h->prof_free.push_back(ev);
+  }
+  h->prof_events.clear();
+  for (int i = 0; i < HGS_STAGE_COUNT; i++) {
+    if (ms) ms[i] = h->prof_ms[i];
+    if (launches) launches[i] = h->prof_launches[i];
+    if (reset) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
+  }
+  return HGS_OK;
+}
+
+int hgs_synchronize(hgs_handle* h) {
+  if (!h) return HGS_ERR_INVALID_ARGUMENT;
+  HGS_TRY(set_device(h));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  return HGS_OK;
+}
+
+// ---- stage-level hooks for the parity tests ---------------------------------------------------------------
+int hgs_debug_target_covariances(hgs_handle* h, float* out6) {
+  if (!h || !out6) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h->target) return HGS_ERR_NO_TARGET;
+  HGS_TRY(set_device(h));
+  hgs_cloud* t = h->target;
+  std::vector<hgs_cloud*> all{t};
+  HGS_TRY(ensure_cov(h, all, h->prm.correspondence_randomness));
+  const size_t slots = (size_t)t->P * kLeaf;
+  std::vector<float4> pts(slots), cov(2 * slots);
+  int nvalid = 0;
+  HGS_HIP(h, hipMemcpyAsync(pts.data(), t->desc.pts, slots * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipMemcpyAsync(cov.data(), t->desc.cov, 2 * slots * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipMemcpyAsync(&nvalid, &t->desc.meta->nvalid, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  std::memset(out6, 0, t->n_input * 6 * sizeof(float));
+  for (int i = 0; i < nvalid; i++) {
+    int o;
+    std::memcpy(&o, &pts[i].w, 4);
+    if (o < 0 || (size_t)o >= t->n_input) continue;
+    float* p = out6 + (size_t)o * 6;
+    p[0] = cov[2 * i].x, p[1] = cov[2 * i].y, p[2] = cov[2 * i].z, p[3] = cov[2 * i].w, p[4] = cov[2 * i + 1].x, p[5] = cov[2 * i + 1].y;
+  }
+  return HGS_OK;
+}
+
+int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, double* b6, double* err, int32_t* corr) {
+  if (!h || !T12 || !H36 || !b6 || !err) return HGS_ERR_INVALID_ARGUMENT;
+  if (h->prm.method != HGS_FAST_GICP) return HGS_ERR_UNSUPPORTED;
+  if (!h->target) return HGS_ERR_NO_TARGET;
+  if (!h->source) return HGS_ERR_NO_SOURCE;
+  HGS_TRY(set_device(h));
+  hgs_cloud *s = h->source, *t = h->target;
+  std::vector<hgs_cloud*> all{s, t};
+  HGS_TRY(ensure_cov(h, all, h->prm.correspondence_randomness));
+  const int max_blocks = std::max(1, ((int)s->n_input + kBlock - 1) / kBlock);
+  std::vector<hgs_cloud*> src{s};
+  const CloudDesc* d_descs = nullptr;
+  HGS_TRY(upload_descs(h, src, false, &d_descs, nullptr));
+  HGS_HIP(h, h->states.reserve(sizeof(GicpState)));
+  HGS_HIP(h, h->partials.reserve((size_t)max_blocks * kAcc * sizeof(double)));
+  HGS_HIP(h, h->misc.reserve(64 * sizeof(double)));
+  HGS_HIP(h, hipMemsetAsync(h->partials.p, 0, (size_t)max_blocks * kAcc * sizeof(double), h->stream));
+  HGS_HIP(h, hipMemcpyAsync(h->misc.p, T12, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  launch_gicp_debug_state(h->stream, h->states.as<GicpState>(), h->misc.as<double>());
+  launch_gicp_linearize(h->stream, d_descs, target_view(t), h->states.as<GicpState>(), gicp_consts(h->prm), h->partials.as<double>(), max_blocks, 1);
+  double* d_out = h->misc.as<double>() + 16;
+  launch_reduce_partials(h->stream, h->partials.as<double>(), max_blocks, d_out);
+  double acc[kAcc];
+  HGS_HIP(h, hipMemcpyAsync(acc, d_out, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+  const size_t s_slots = (size_t)s->P * kLeaf, t_slots = (size_t)t->P * kLeaf;
+  std::vector<float4> spts, tpts;
+  std::vector<int> dcorr;
+  int s_nvalid = 0;
+  if (corr) {
+    spts.resize(s_slots), tpts.resize(t_slots), dcorr.resize(s_slots);
+    HGS_HIP(h, hipMemcpyAsync(spts.data(), s->desc.pts, s_slots * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    HGS_HIP(h, hipMemcpyAsync(tpts.data(), t->desc.pts, t_slots * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    HGS_HIP(h, hipMemcpyAsync(dcorr.data(), s->desc.corr, s_slots * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HGS_HIP(h, hipMemcpyAsync(&s_nvalid, &s->desc.meta->nvalid, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  }
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  int k = 0;
+  for (int r = 0; r < 6; r++)
+    for (int c = r; c < 6; c++) H36[r * 6 + c] = H36[c * 6 + r] = acc[k++];
+  for (int i = 0; i < 6; i++) b6[i] = acc[21 + i];
+  *err = acc[27];
+  if (corr) {
+    for (size_t i = 0; i < s->n_input; i++) corr[i] = -1;
+    for (int i = 0; i < s_nvalid; i++) {
+      int so, to = -1;
+      std::memcpy(&so, &spts[i].w, 4);
+      const int j = dcorr[i];
+      if (j >= 0 && (size_t)j < t_slots) std::memcpy(&to, &tpts[j].w, 4);
+      if (so >= 0 && (size_t)so < s->n_input) corr[so] = to;
+    }
+  }
+  return HGS_OK;
+}
+
+int hgs_debug_ndt_cells(hgs_handle* h, int32_t cap, int32_t* ijk3, double* mean3, float* icov6, int32_t* npts, int32_t* n_cells) {
+  if (!h || !n_cells) return HGS_ERR_INVALID_ARGUMENT;
+  if (h->prm.method != HGS_NDT_OMP) return HGS_ERR_UNSUPPORTED;
+  if (!h->target) return HGS_ERR_NO_TARGET;
+  HGS_TRY(set_device(h));
+  hgs_cloud* t = h->target;
+  HGS_TRY(ensure_ndt_target(h, t));
+  CloudMeta meta;
+  HGS_HIP(h, hipMemcpyAsync(&meta, t->desc.meta, sizeof(CloudMeta), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  *n_cells = meta.ndt_ncells;
+  const int n = std::min<int>(meta.ndt_ncells, cap);
+  if (n <= 0) return HGS_OK;
+  std::vector<NdtCellRec> cells(n);
+  HGS_HIP(h, hipMemcpyAsync(cells.data(), t->ndt_cells, (size_t)n * sizeof(NdtCellRec), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; i++) {
+    int key;
+    std::memcpy(&key, &cells[i].v1.w, 4);
+    if (ijk3) {
+      const int m1 = meta.ndt_div_mul[1], m2 = meta.ndt_div_mul[2];
+      ijk3[3 * i] = key % m1 + meta.ndt_min_b[0];
+      ijk3[3 * i + 1] = (key % m2) / m1 + meta.ndt_min_b[1];
+      ijk3[3 * i + 2] = key / m2 + meta.ndt_min_b[2];
+    }
+    if (mean3) mean3[3 * i] = cells[i].mean[0], mean3[3 * i + 1] = cells[i].mean[1], mean3[3 * i + 2] = cells[i].mean[2];
+    if (icov6) {
+      float* o = icov6 + 6 * i;
+      o[0] = cells[i].v0.x, o[1] = cells[i].v0.y, o[2] = cells[i].v0.z, o[3] = cells[i].v0.w, o[4] = cells[i].v1.x, o[5] = cells[i].v1.y;
+    }
+    if (npts) npts[i] = (int)cells[i].v1.z;
+  }
+  return HGS_OK;
+}
+
+int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, double* g6, double* H36) {
+  if (!h || !p6 || !score || !g6 || !H36) return HGS_ERR_INVALID_ARGUMENT;
+  if (h->prm.method != HGS_NDT_OMP) return HGS_ERR_UNSUPPORTED;
+  if (!h->target) return HGS_ERR_NO_TARGET;
+  if (!h->source) return HGS_ERR_NO_SOURCE;
+  HGS_TRY(set_device(h));
+  hgs_cloud *s = h->source, *t = h->target;
+  HGS_TRY(ensure_ndt_target(h, t));
+  const int max_blocks = std::max(1, ((int)s->n_input + kBlock - 1) / kBlock);
+  std::vector<hgs_cloud*> src{s};
+  const CloudDesc* d_descs = nullptr;
+  HGS_TRY(upload_descs(h, src, false, &d_descs, nullptr));
+  const NdtConsts c = ndt_consts(h->prm);
+  HGS_HIP(h, h->states.reserve(sizeof(NdtState)));
+  HGS_HIP(h, h->angles.reserve(sizeof(NdtAngles)));
+  HGS_HIP(h, h->partials.reserve((size_t)max_blocks * kAcc * sizeof(double)));
+  HGS_HIP(h, h->misc.reserve(64 * sizeof(double)));
+  HGS_HIP(h, hipMemsetAsync(h->partials.p, 0, (size_t)max_blocks * kAcc * sizeof(double), h->stream));
+  HGS_HIP(h, hipMemcpyAsync(h->misc.p, p6, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  launch_ndt_debug_state(h->stream, h->states.as<NdtState>(), h->angles.as<NdtAngles>(), h->misc.as<double>(), c);
+  NdtTargetView tv;
+  tv.hash_keys = t->ndt_hash_keys, tv.hash_vals = t->ndt_hash_vals, tv.cells = t->ndt_cells, tv.meta = t->desc.meta;
+  tv.hash_mask = t->ndt_hash_cap - 1, tv.inv_leaf = 1.0f / (float)h->prm.resolution;
+  launch_ndt_derivatives(h->stream, d_descs, tv, h->states.as<NdtState>(), h->angles.as<NdtAngles>(), c, h->partials.as<double>(), max_blocks, 1);
+  double* d_out = h->misc.as<double>() + 16;
+  launch_reduce_partials(h->stream, h->partials.as<double>(), max_blocks, d_out);
+  double acc[kAcc];
+  HGS_HIP(h, hipMemcpyAsync(acc, d_out, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  int k = 0;
+  for (int r = 0; r < 6; r++)
+    for (int cc = r; cc < 6; cc++) H36[r * 6 + cc] = H36[cc * 6 + r] = acc[k++];
+  for (int i = 0; i < 6; i++) g6[i] = acc[21 + i];
+  *score = acc[27];
+  return HGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+// hgs_gicp.h — per-point arithmetic and the per-problem Levenberg-Marquardt state machine of the GICP engine
+// (fast_gicp::FastGICP + LsqRegistration; reference call site src/hdl_graph_slam/registrations.cpp:27-36).
+// HGS_HD: the HIP kernels call these; the test-only host harness (tests/emul) calls the very same functions.
+#pragma once
+#include "hgs_bvh.h"
+
+namespace hgs {
+
+// Accumulator layout shared by kernels and the 6x6 stage: [0..20] upper triangle of H (row-major, r<=c),
+// [21..26] b, [27] sum of errors.
+constexpr int kAcc = 28;
+
+struct GicpConsts {
+  double max_corr2;         // max_correspondence_distance^2 (double, compared against float d2 like upstream)
+  float search_bound2;      // float upper bound handed to the tree search
+  double rotation_eps, translation_eps;
+  double lm_init_lambda_factor;
+  int lm_max_iterations;
+  int max_iterations;
+  int k_correspondences;
+};
+
+// Regularised covariance of one point from its k nearest neighbours (fast_gicp calculate_covariances, FROBENIUS):
+//   C = sum (p-mean)(p-mean)^T / k ; C' = ||(C + 1e-3 I)^-1||_F * (C + 1e-3 I)   (== ((C+1e-3I)^-1 / ||.||_F)^-1)
+// s1 = sum (p - q), s2 = sum (p - q)(p - q)^T over the `found` neighbours (shifted by the query for conditioning).
+HGS_HD Sym3 gicp_regularized_cov(const double* s1, const Sym3& s2, int found, int k) {
+  const double inv_f = 1.0 / (double)found, inv_k = 1.0 / (double)k;
+  const double mx = s1[0] * inv_f, my = s1[1] * inv_f, mz = s1[2] * inv_f;
+  // sum (d-m)(d-m)^T = s2 - found * m m^T
+  Sym3 c;
+  c.xx = (s2.xx - found * mx * mx) * inv_k + 1e-3;
+  c.xy = (s2.xy - found * mx * my) * inv_k;
+  c.xz = (s2.xz - found * mx * mz) * inv_k;
+  c.yy = (s2.yy - found * my * my) * inv_k + 1e-3;
+  c.yz = (s2.yz - found * my * mz) * inv_k;
+  c.zz = (s2.zz - found * mz * mz) * inv_k + 1e-3;
+  const Sym3 ci = sym3_inverse(c);
+  const double f = sqrt(ci.xx * ci.xx + ci.yy * ci.yy + ci.zz * ci.zz + 2.0 * (ci.xy * ci.xy + ci.xz * ci.xz + ci.yz * ci.yz));
+  Sym3 o;
+  o.xx = f * c.xx, o.xy = f * c.xy, o.xz = f * c.xz, o.yy = f * c.yy, o.yz = f * c.yz, o.zz = f * c.zz;
+  return o;
+}
+
+// Mahalanobis matrix of one correspondence at the linearisation pose: M = (C_B + R C_A R^T)^-1
+HGS_HD Sym3 gicp_mahalanobis(const double* R /*3x3 row-major*/, const Sym3& ca, const Sym3& cb) {
+  Sym3 rcr = sym3_rotate(R, ca);
+  rcr.xx += cb.xx, rcr.xy += cb.xy, rcr.xz += cb.xz, rcr.yy += cb.yy, rcr.yz += cb.yz, rcr.zz += cb.zz;
+  return sym3_inverse(rcr);
+}
+
+// residual e = b - T a, returns e^T M e; optionally adds J^T M J, J^T M e (J = [skew(Ta) | -I]) to acc[28]
+template <bool WITH_JACOBIAN>
+HGS_HD double gicp_point_terms(const Pose& T, const Sym3& M, float ax, float ay, float az, float bx, float by, float bz, double* acc) {
+  const double x = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];
+  const double y = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
+  const double z = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
+  const double ex = (double)bx - x, ey = (double)by - y, ez = (double)bz - z;
+  const double mex = M.xx * ex + M.xy * ey + M.xz * ez;
+  const double mey = M.xy * ex + M.yy * ey + M.yz * ez;
+  const double mez = M.xz * ex + M.yz * ey + M.zz * ez;
+  const double err = ex * mex + ey * mey + ez * mez;
+  if (WITH_JACOBIAN) {
+    // A = M S, S = skew(ta): S[:,0]=(0,z,-y) S[:,1]=(-z,0,x) S[:,2]=(y,-x,0)
+    const double Mr[3][3] = {{M.xx, M.xy, M.xz}, {M.xy, M.yy, M.yz}, {M.xz, M.yz, M.zz}};
+    double A[3][3];
+    for (int r = 0; r < 3; r++) {
+      A[r][0] = Mr[r][1] * z - Mr[r][2] * y;
+      A[r][1] = -Mr[r][0] * z + Mr[r][2] * x;
+      A[r][2] = Mr[r][0] * y - Mr[r][1] * x;
+    }
+    // H_rr = S^T A ; (S^T X)[0][j] = z X[1][j] - y X[2][j]; [1][j] = -z X[0][j] + x X[2][j]; [2][j] = y X[0][j] - x X[1][j]
+    double Hrr[3][3], Hrt[3][3];
+    for (int j = 0; j < 3; j++) {
+      Hrr[0][j] = z * A[1][j] - y * A[2][j];
+      Hrr[1][j] = -z * A[0][j] + x * A[2][j];
+      Hrr[2][j] = y * A[0][j] - x * A[1][j];
+      Hrt[0][j] = -(z * Mr[1][j] - y * Mr[2][j]);
+      Hrt[1][j] = -(-z * Mr[0][j] + x * Mr[2][j]);
+      Hrt[2][j] = -(y * Mr[0][j] - x * Mr[1][j]);
+    }
+    // upper triangle, row-major: row0: (0,0..5) row1: (1,1..5) ...
+    acc[0] += Hrr[0][0], acc[1] += Hrr[0][1], acc[2] += Hrr[0][2], acc[3] += Hrt[0][0], acc[4] += Hrt[0][1], acc[5] += Hrt[0][2];
+    acc[6] += Hrr[1][1], acc[7] += Hrr[1][2], acc[8] += Hrt[1][0], acc[9] += Hrt[1][1], acc[10] += Hrt[1][2];
+    acc[11] += Hrr[2][2], acc[12] += Hrt[2][0], acc[13] += Hrt[2][1], acc[14] += Hrt[2][2];
+    acc[15] += M.xx, acc[16] += M.xy, acc[17] += M.xz;
+    acc[18] += M.yy, acc[19] += M.yz;
+    acc[20] += M.zz;
+    // b = J^T M e = [ S^T Me ; -Me ]
+    acc[21] += z * mey - y * mez;
+    acc[22] += -z * mex + x * mez;
+    acc[23] += y * mex - x * mey;
+    acc[24] -= mex, acc[25] -= mey, acc[26] -= mez;
+  }
+  return err;
+}
+
+HGS_HD Sym3 sym3_from_floats(float xx, float xy, float xz, float yy, float yz, float zz) {
+  Sym3 s;
+  s.xx = xx, s.xy = xy, s.xz = xz, s.yy = yy, s.yz = yz, s.zz = zz;
+  return s;
+}
+
+// ---- per-problem LM state machine (LsqRegistration::computeTransformation / step_lm / is_converged) ----------
+enum GicpPhase { GICP_LINEARIZE = 0, GICP_TRY = 1, GICP_DONE = 2 };
+
+struct GicpState {
+  Pose x0;        // current estimate
+  Pose xi;        // trial estimate of the running LM try
+  double H[36];   // J^T M J at x0
+  double b[6];
+  double d[6];    // last LM step
+  double y0, yi;
+  double lambda, nu;
+  int phase;
+  int iterations;  // completed outer iterations
+  int lm_try;      // tries within the current step_lm
+  int lm_tries_total;
+  int converged;
+  int pad;
+};
+
+HGS_HD void gicp_state_init(GicpState& s, const float* guess_colmajor) {
+  s.x0 = pose_from_colmajor_f(guess_colmajor);
+  s.xi = s.x0;
+  for (int i = 0; i < 36; i++) s.H[i] = 0;
+  for (int i = 0; i < 6; i++) s.b[i] = 0, s.d[i] = 0;
+  s.y0 = s.yi = 0;
+  s.lambda = -1.0;
+  s.nu = 2.0;
+  s.phase = GICP_LINEARIZE;
+  s.iterations = 0, s.lm_try = 0, s.lm_tries_total = 0, s.converged = 0, s.pad = 0;
+}
+
+HGS_HD bool gicp_is_converged(const Pose& delta, const GicpConsts& c) {
+  double rmax = 0, tmax = 0;
+  for (int r = 0; r < 3; r++)
+    for (int cc = 0; cc < 3; cc++) {
+      const double v = fabs(delta.m[r * 4 + cc] - (r == cc ? 1.0 : 0.0));
+      if (v > rmax) rmax = v;
+    }
+  for (int r = 0; r < 3; r++) {
+    const double v = fabs(delta.m[r * 4 + 3]);
+    if (v > tmax) tmax = v;
+  }
+  const double a = rmax / c.rotation_eps, b = tmax / c.translation_eps;
+  return (a > b ? a : b) < 1.0;
+}
+
+// d = LDLT(H + lambda I).solve(-b); xi = se3_exp(d) * x0
+HGS_HD void gicp_solve_try(GicpState& s, Pose* delta_out) {
+  double A[36], nb[6];
+  for (int i = 0; i < 36; i++) A[i] = s.H[i];
+  for (int i = 0; i < 6; i++) A[i * 7] += s.lambda, nb[i] = -s.b[i];
+  solve_ldlt6(A, nb, s.d);
+  const Pose delta = se3_exp(s.d);
+  s.xi = pose_mul(delta, s.x0);
+  if (delta_out) *delta_out = delta;
+}
+
+// After a linearisation: acc holds the reduced upper-triangle H, b, error at x0.
+HGS_HD void gicp_after_linearize(GicpState& s, const double* acc, const GicpConsts& c) {
+  int k = 0;
+  for (int r = 0; r < 6; r++)
+    for (int cc = r; cc < 6; cc++) {
+      s.H[r * 6 + cc] = acc[k];
+      s.H[cc * 6 + r] = acc[k];
+      k++;
+    }
+  for (int i = 0; i < 6; i++) s.b[i] = acc[21 + i];
+  s.y0 = acc[27];
+  if (s.lambda < 0.0) {
+    double mx = 0;
+    for (int i = 0; i < 6; i++) {
+      const double v = fabs(s.H[i * 7]);
+      if (v > mx) mx = v;
+    }
+    s.lambda = c.lm_init_lambda_factor * mx;
+  }
+  s.nu = 2.0;
+  s.lm_try = 0;
+  gicp_solve_try(s, nullptr);
+  s.phase = GICP_TRY;
+}
+
+// After the trial error yi at xi is known: accept / reject exactly as step_lm + the outer loop do.
+HGS_HD void gicp_after_error(GicpState& s, double yi, const GicpConsts& c) {
+  s.yi = yi;
+  s.lm_try++;
+  s.lm_tries_total++;
+  double denom = 0;
+  for (int i = 0; i < 6; i++) denom += s.d[i] * (s.lambda * s.d[i] - s.b[i]);
+  const double rho = (s.y0 - yi) / denom;
+  const Pose delta = se3_exp(s.d);
+  bool step_ok, finished_step;
+  if (rho < 0) {
+    if (gicp_is_converged(delta, c)) {
+      step_ok = true, finished_step = true;  // step_lm returns true without moving x0
+    } else {
+      s.lambda = s.nu * s.lambda;
+      s.nu = 2 * s.nu;
+      if (s.lm_try >= c.lm_max_iterations) {
+        step_ok = false, finished_step = true;  // "lm not converged": outer loop breaks
+      } else {
+        gicp_solve_try(s, nullptr);  // next try against the same linearisation
+        return;                      // stay in GICP_TRY
+      }
+    }
+  } else {
+    s.x0 = s.xi;
+    const double t = 2 * rho - 1;
+    const double f = 1.0 - t * t * t;
+    s.lambda = s.lambda * (f > 1.0 / 3.0 ? f : 1.0 / 3.0);
+    step_ok = true, finished_step = true;
+  }
+  (void)finished_step;
+  s.iterations++;
+  if (!step_ok) {
+    s.converged = 0;
+    s.phase = GICP_DONE;
+    return;
+  }
+  s.converged = gicp_is_converged(delta, c) ? 1 : 0;
+  if (s.converged || s.iterations >= c.max_iterations) {
+    s.phase = GICP_DONE;
+  } else {
+    s.phase = GICP_LINEARIZE;
+  }
+}
+
+}  // namespace hgs

@@ -1,0 +1,711 @@
+// hgs_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the scan-matching hot path that
+// hdl_graph_slam reaches through select_registration_method (src/hdl_graph_slam/registrations.cpp:22-124):
+//   * search index  : Hilbert sort keys, implicit bounding-interval tree build (replaces the kd-trees of
+//                     pcl::Registration::tree_ and fast_gicp)
+//   * GICP          : k-NN covariance pre-pass, fused 1-NN correspondence + J^T M J accumulation, LM trial error,
+//                     on-device 6x6 solve / LM control (fast_gicp::FastGICP, registrations.cpp:27-36)
+//   * NDT           : Gaussian voxel table build, DIRECT1/7 derivative pass, on-device Newton control
+//                     (pclomp::NormalDistributionsTransform, registrations.cpp:101-120)
+//   * fitness score : pcl::Registration::getFitnessScore (information_matrix_calculator.cpp:49-80)
+// All kernels are batched: blockIdx.y selects the problem (loop-closure candidate, loop_detector.hpp:135-154);
+// the odometry path is the batch of one.  Work is HBM/L2-latency bound pointer chasing plus small fp64 algebra:
+// no MFMA (the contraction is 6x6), coalesced float4 loads, wave64 shuffle reductions, deterministic two-stage sums.
+#include <hip/hip_runtime.h>
+#include "hgs_device.h"
+
+namespace hgs {
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ bool finite3(const float4& p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
+
+// Blocks of one launch land on XCD (blockIdx % 8); give every XCD a contiguous range of tiles so that each
+// private 4 MiB L2 caches one spatial slab of the (Hilbert-ordered) target tree instead of all of it.
+__device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  return xcd * q + (xcd < r ? xcd : r) + slot;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum N per-thread doubles over a 256-thread block in a fixed order; thread k < N stores result k.
+template <int N>
+__device__ __forceinline__ void block_reduce_store(const double* acc, double* out, double* lds /* [4*N] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) lds[wave * N + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) out[threadIdx.x] = (lds[threadIdx.x] + lds[N + threadIdx.x]) + (lds[2 * N + threadIdx.x] + lds[3 * N + threadIdx.x]);
+}
+
+__device__ __forceinline__ BvhView view_of(const TargetView& t) {
+  BvhView v;
+  v.nodes = t.nodes, v.pts = t.pts, v.P = t.P, v.n = t.meta->nvalid;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ upload
+__global__ __launch_bounds__(kBlock) void k_pack_aos(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ raw) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float* f = reinterpret_cast<const float*>(staging + (size_t)i * stride);
+  raw[i] = make_float4(f[0], f[1], f[2], __int_as_float(i));
+}
+void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_pack_aos, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const char*)staging, stride, n, raw);
+}
+
+// ------------------------------------------------------------------------------------------------ search index
+__global__ void k_meta_init(const CloudDesc* descs, int ncloud) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncloud) return;
+  CloudMeta* m = descs[c].meta;
+  m->nvalid = 0;
+  for (int d = 0; d < 3; d++) m->bbmin[d] = 0xffffffffu, m->bbmax[d] = 0u;
+}
+void launch_meta_init(hipStream_t s, const CloudDesc* descs, int ncloud) {
+  hipLaunchKernelGGL(k_meta_init, dim3((ncloud + 63) / 64), dim3(64), 0, s, descs, ncloud);
+}
+
+__global__ __launch_bounds__(kBlock) void k_bbox_count(const CloudDesc* descs) {
+  const CloudDesc d = descs[blockIdx.y];
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int cnt = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.n_input; i += gridDim.x * kBlock) {
+    const float4 p = d.raw[i];
+    if (finite3(p)) {
+      cnt++;
+      mn[0] = fminf(mn[0], p.x), mn[1] = fminf(mn[1], p.y), mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt += __shfl_down(cnt, off, 64);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      mn[k] = fminf(mn[k], __shfl_down(mn[k], off, 64));
+      mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0 && cnt > 0) {
+    atomicAdd(&d.meta->nvalid, cnt);
+    for (int k = 0; k < 3; k++) {
+      atomicMin(&d.meta->bbmin[k], f2ord(mn[k]));
+      atomicMax(&d.meta->bbmax[k], f2ord(mx[k]));
+    }
+  }
+}
+void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n) {
+  int gx = (max_n + kBlock * 8 - 1) / (kBlock * 8);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_bbox_count, dim3(gx, ncloud), dim3(kBlock), 0, s, descs);
+}
+
+__global__ __launch_bounds__(kBlock) void k_hilbert_keys(const CloudDesc* descs, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+  const CloudDesc d = descs[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= d.n_input) return;
+  const float4 p = d.raw[i];
+  unsigned long long code = 0xffffffffffffull;
+  if (finite3(p)) {
+    const float mnx = ord2f(d.meta->bbmin[0]), mny = ord2f(d.meta->bbmin[1]), mnz = ord2f(d.meta->bbmin[2]);
+    const float ex = ord2f(d.meta->bbmax[0]) - mnx, ey = ord2f(d.meta->bbmax[1]) - mny, ez = ord2f(d.meta->bbmax[2]) - mnz;
+    const float ext = fmaxf(ex, fmaxf(ey, ez));
+    const float sc = ext > 0.f ? 65535.f / ext : 0.f;
+    const unsigned qx = min(65535u, (unsigned)((p.x - mnx) * sc));
+    const unsigned qy = min(65535u, (unsigned)((p.y - mny) * sc));
+    const unsigned qz = min(65535u, (unsigned)((p.z - mnz) * sc));
+    code = hilbert48(qx, qy, qz);
+    if (code == 0xffffffffffffull) code--;  // reserve all-ones for non-finite points
+  }
+  keys[d.sort_off + i] = ((unsigned long long)blockIdx.y << 48) | code;
+  vals[d.sort_off + i] = (unsigned)i;
+}
+void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals) {
+  if (max_n <= 0) return;
+  hipLaunchKernelGGL(k_hilbert_keys, dim3((max_n + kBlock - 1) / kBlock, ncloud), dim3(kBlock), 0, s, descs, keys, vals);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_sorted(const CloudDesc* descs, const unsigned* __restrict__ sorted_vals) {
+  const CloudDesc d = descs[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= d.P * kLeaf) return;
+  float4 p = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(-1));
+  if (i < d.meta->nvalid) p = d.raw[sorted_vals[d.sort_off + i]];
+  d.pts[i] = p;
+}
+void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int max_slots, const unsigned* sorted_vals) {
+  if (max_slots <= 0) return;
+  hipLaunchKernelGGL(k_gather_sorted, dim3((max_slots + kBlock - 1) / kBlock, ncloud), dim3(kBlock), 0, s, descs, sorted_vals);
+}
+
+// Leaves + the 8 tree levels above them: one block owns 256 consecutive leaves, merges in LDS.
+__global__ __launch_bounds__(kBlock) void k_build_bottom(const CloudDesc* descs) {
+  const CloudDesc d = descs[blockIdx.y];
+  const int P = d.P;
+  const int leaf0 = blockIdx.x * kBlock;
+  if (leaf0 >= P) return;
+  __shared__ float smn[2][kBlock][3], smx[2][kBlock][3];
+  const int t = threadIdx.x;
+  const int nvalid = d.meta->nvalid;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const int leaf = leaf0 + t;
+  if (leaf < P) {
+#pragma unroll
+    for (int l = 0; l < kLeaf; l++) {
+      const int idx = leaf * kLeaf + l;
+      if (idx < nvalid) {
+        const float4 p = d.pts[idx];
+        mn[0] = fminf(mn[0], p.x), mn[1] = fminf(mn[1], p.y), mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
+      }
+    }
+    d.nodes[2 * (P + leaf)] = make_float4(mn[0], mn[1], mn[2], 0.f);
+    d.nodes[2 * (P + leaf) + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+  }
+  for (int k = 0; k < 3; k++) smn[0][t][k] = mn[k], smx[0][t][k] = mx[k];
+  int cur = 0, width = P < kBlock ? P : kBlock, level_nodes = P, first = leaf0;
+  while (width > 1) {
+    __syncthreads();
+    const int nw = width >> 1;
+    level_nodes >>= 1;
+    first >>= 1;
+    if (t < nw) {
+      float a[3], b[3];
+      for (int k = 0; k < 3; k++) {
+        a[k] = fminf(smn[cur][2 * t][k], smn[cur][2 * t + 1][k]);
+        b[k] = fmaxf(smx[cur][2 * t][k], smx[cur][2 * t + 1][k]);
+        smn[cur ^ 1][t][k] = a[k];
+        smx[cur ^ 1][t][k] = b[k];
+      }
+      const int id = level_nodes + first + t;
+      d.nodes[2 * id] = make_float4(a[0], a[1], a[2], 0.f);
+      d.nodes[2 * id + 1] = make_float4(b[0], b[1], b[2], 0.f);
+    }
+    cur ^= 1;
+    width = nw;
+  }
+}
+// Remaining top levels (only when P > 256): one block per cloud walks them level by level.
+__global__ __launch_bounds__(kBlock) void k_build_top(const CloudDesc* descs) {
+  const CloudDesc d = descs[blockIdx.x];
+  if (d.P <= kBlock) return;
+  for (int level_nodes = (d.P / kBlock) >> 1; level_nodes >= 1; level_nodes >>= 1) {
+    for (int t = threadIdx.x; t < level_nodes; t += kBlock) {
+      const int id = level_nodes + t;
+      const float4 a0 = d.nodes[4 * id], a1 = d.nodes[4 * id + 1], b0 = d.nodes[4 * id + 2], b1 = d.nodes[4 * id + 3];
+      d.nodes[2 * id] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0.f);
+      d.nodes[2 * id + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0.f);
+    }
+    __syncthreads();
+  }
+}
+void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int max_P) {
+  hipLaunchKernelGGL(k_build_bottom, dim3((max_P + kBlock - 1) / kBlock, ncloud), dim3(kBlock), 0, s, descs);
+  if (max_P > kBlock) hipLaunchKernelGGL(k_build_top, dim3(ncloud), dim3(kBlock), 0, s, descs);
+}
+
+// ------------------------------------------------------------------------------------------------ GICP covariances
+// One thread per (Hilbert-sorted) point: neighbouring lanes walk nearly the same tree path, so the node reads
+// of a wave coalesce into a handful of L2 lines.  Algorithmic bytes: 16 (query) + k*16 (neighbours) + 24 (cov).
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int k) {
+  const CloudDesc d = descs[blockIdx.y];
+  const int n = d.meta->nvalid;
+  const int ntiles = (n + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int i = xcd_tile(blockIdx.x, ntiles) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  BvhView tv;
+  tv.nodes = d.nodes, tv.pts = d.pts, tv.P = d.P, tv.n = n;
+  const float4 qp = d.pts[i];
+  const F3 q = {qp.x, qp.y, qp.z};
+  KnnList<KMAX> list;
+  bvh_knn<KMAX>(tv, q, k, list);
+  double s1[3] = {0, 0, 0};
+  Sym3 s2 = {0, 0, 0, 0, 0, 0};
+  int found = 0;
+#pragma unroll
+  for (int j = 0; j < KMAX; j++) {
+    if (list.pos[j] >= 0) {
+      const float4 p = d.pts[list.pos[j]];
+      const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
+      s1[0] += dx, s1[1] += dy, s1[2] += dz;
+      s2.xx += dx * dx, s2.xy += dx * dy, s2.xz += dx * dz, s2.yy += dy * dy, s2.yz += dy * dz, s2.zz += dz * dz;
+      found++;
+    }
+  }
+  const Sym3 c = gicp_regularized_cov(s1, s2, found, k);
+  d.cov[2 * i] = make_float4((float)c.xx, (float)c.xy, (float)c.xz, (float)c.yy);
+  d.cov[2 * i + 1] = make_float4((float)c.yz, (float)c.zz, 0.f, 0.f);
+}
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k) {
+  if (max_n <= 0) return;
+  const dim3 grid((max_n + kBlock - 1) / kBlock, ncloud), block(kBlock);
+  if (k <= 8) hipLaunchKernelGGL(k_knn_cov<8>, grid, block, 0, s, descs, k);
+  else if (k <= 16) hipLaunchKernelGGL(k_knn_cov<16>, grid, block, 0, s, descs, k);
+  else if (k <= 20) hipLaunchKernelGGL(k_knn_cov<20>, grid, block, 0, s, descs, k);
+  else if (k <= 32) hipLaunchKernelGGL(k_knn_cov<32>, grid, block, 0, s, descs, k);
+  else hipLaunchKernelGGL(k_knn_cov<64>, grid, block, 0, s, descs, k < 64 ? k : 64);
+}
+
+// ------------------------------------------------------------------------------------------------ GICP iteration
+__global__ void k_gicp_init(GicpState* states, const float* guesses, int B, int* done_counter) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) *done_counter = 0;
+  if (b >= B) return;
+  gicp_state_init(states[b], guesses + 16 * b);
+}
+void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, int* done_counter) {
+  hipLaunchKernelGGL(k_gicp_init, dim3((B + 63) / 64), dim3(64), 0, s, states, guesses, B, done_counter);
+}
+
+__device__ __forceinline__ Sym3 load_cov(const float4* cov, int i) {
+  const float4 a = cov[2 * i], b = cov[2 * i + 1];
+  return sym3_from_floats(a.x, a.y, a.z, a.w, b.x, b.y);
+}
+
+// update_correspondences + linearize fused: per source point 1-NN in the target tree, Mahalanobis matrix,
+// 6x6 normal-equation terms; wave shuffle + LDS reduction to one 28-double partial per block.
+// Algorithmic bytes per source point: 16 (a_i) + 24 (C_A) + 4 (corr) + 16 (b_j) + 24 (C_B) = 84.
+__global__ __launch_bounds__(kBlock) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
+                                                           double* __restrict__ partials, int max_blocks) {
+  const int b = blockIdx.y;
+  if (states[b].phase != GICP_LINEARIZE) return;
+  const CloudDesc d = descs[b];
+  const int n = d.meta->nvalid;
+  const int ntiles = (n + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int i = tile * kBlock + threadIdx.x;
+  __shared__ double lds[4 * kAcc];
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+  const Pose T = states[b].x0;
+  if (i < n) {
+    float Tf[12];
+    pose_to_float(T, Tf);
+    const float4 a = d.pts[i];
+    const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
+    float d2;
+    int orig;
+    const BvhView tv = view_of(tgt);
+    int j = bvh_nn1(tv, q, c.search_bound2, &d2, &orig);
+    if (j >= 0 && !((double)d2 < c.max_corr2)) j = -1;
+    d.corr[i] = j;
+    if (j >= 0) {
+      const double R[9] = {T.m[0], T.m[1], T.m[2], T.m[4], T.m[5], T.m[6], T.m[8], T.m[9], T.m[10]};
+      const Sym3 M = gicp_mahalanobis(R, load_cov(d.cov, i), load_cov(tgt.cov, j));
+      const float4 bp = tgt.pts[j];
+      acc[27] = gicp_point_terms<true>(T, M, a.x, a.y, a.z, bp.x, bp.y, bp.z, acc);
+    }
+  }
+  block_reduce_store<kAcc>(acc, partials + ((size_t)b * max_blocks + tile) * kAcc, lds);
+}
+void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
+                           int max_blocks, int B) {
+  hipLaunchKernelGGL(k_gicp_linearize, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks);
+}
+
+__global__ __launch_bounds__(64) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
+                                                  int max_blocks) {
+  const int b = blockIdx.x;
+  GicpState& st = states[b];
+  if (st.phase != GICP_LINEARIZE) return;
+  __shared__ double acc[kAcc];
+  const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
+  if (threadIdx.x < kAcc) {
+    double s = 0;
+    const double* p = partials + (size_t)b * max_blocks * kAcc + threadIdx.x;
+    for (int t = 0; t < ntiles; t++) s += p[(size_t)t * kAcc];
+    acc[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) gicp_after_linearize(st, acc, c);
+}
+void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B) {
+  hipLaunchKernelGGL(k_gicp_solve, dim3(B), dim3(64), 0, s, descs, states, c, partials, max_blocks);
+}
+
+// compute_error(xi): same correspondences, Mahalanobis matrices of the linearisation pose x0, residuals at xi.
+__global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, TargetView tgt, const GicpState* states, double* __restrict__ partials_err,
+                                                       int max_blocks) {
+  const int b = blockIdx.y;
+  if (states[b].phase != GICP_TRY) return;
+  const CloudDesc d = descs[b];
+  const int n = d.meta->nvalid;
+  const int ntiles = (n + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int i = tile * kBlock + threadIdx.x;
+  __shared__ double lds[4];
+  double err = 0.0;
+  if (i < n) {
+    const int j = d.corr[i];
+    if (j >= 0) {
+      const Pose T0 = states[b].x0;
+      const Pose Ti = states[b].xi;
+      const double R[9] = {T0.m[0], T0.m[1], T0.m[2], T0.m[4], T0.m[5], T0.m[6], T0.m[8], T0.m[9], T0.m[10]};
+      const Sym3 M = gicp_mahalanobis(R, load_cov(d.cov, i), load_cov(tgt.cov, j));
+      const float4 a = d.pts[i], bp = tgt.pts[j];
+      err = gicp_point_terms<false>(Ti, M, a.x, a.y, a.z, bp.x, bp.y, bp.z, nullptr);
+    }
+  }
+  block_reduce_store<1>(&err, partials_err + (size_t)b * max_blocks + tile, lds);
+}
+void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B) {
+  hipLaunchKernelGGL(k_gicp_error, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks);
+}
+
+__global__ __launch_bounds__(64) void k_gicp_decide(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials_err,
+                                                   int max_blocks, int* done_counter) {
+  const int b = blockIdx.x;
+  GicpState& st = states[b];
+  if (st.phase != GICP_TRY) return;
+  const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
+  double s = 0;
+  for (int t = threadIdx.x; t < ntiles; t += 64) s += partials_err[(size_t)b * max_blocks + t];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    gicp_after_error(st, s, c);
+    if (st.phase == GICP_DONE) atomicAdd(done_counter, 1);
+  }
+}
+void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B,
+                        int* done_counter) {
+  hipLaunchKernelGGL(k_gicp_decide, dim3(B), dim3(64), 0, s, descs, states, c, partials_err, max_blocks, done_counter);
+}
+
+__global__ void k_gicp_results(const GicpState* states, DevResult* out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const GicpState& st = states[b];
+  DevResult r;
+  pose_to_colmajor_f(st.x0, r.T);
+  r.converged = st.converged, r.iterations = st.iterations, r.lm_tries = st.lm_tries_total, r.pad = 0;
+  r.error = st.y0;
+  r.fit_sum = 0, r.fit_count = 0, r.pad2 = 0;
+  out[b] = r;
+}
+void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out, int B) {
+  hipLaunchKernelGGL(k_gicp_results, dim3((B + 63) / 64), dim3(64), 0, s, states, out, B);
+}
+
+// ------------------------------------------------------------------------------------------------ fitness / NN queries
+// getFitnessScore: per source point exact (unbounded) 1-NN in the target; sum d2 over d2 <= max_range.
+// Algorithmic bytes per source point: 16 + 16 = 32.
+__global__ __launch_bounds__(kBlock) void k_fitness(const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range,
+                                                    double* __restrict__ partials, int max_blocks) {
+  const int b = blockIdx.y;
+  const CloudDesc d = descs[b];
+  const int n = d.meta->nvalid;
+  const int ntiles = (n + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int i = tile * kBlock + threadIdx.x;
+  __shared__ double lds[4 * 2];
+  double acc[2] = {0.0, 0.0};
+  if (i < n) {
+    float Tf[12];
+    const float* Tc = poses[b].T;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++) Tf[r * 4 + cc] = Tc[cc * 4 + r];
+    const float4 a = d.pts[i];
+    const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
+    float d2;
+    int orig;
+    const int j = bvh_nn1(view_of(tgt), q, FLT_MAX, &d2, &orig);
+    if (j >= 0 && (double)d2 <= max_range) acc[0] = (double)d2, acc[1] = 1.0;
+  }
+  block_reduce_store<2>(acc, partials + ((size_t)b * max_blocks + tile) * 2, lds);
+}
+void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks,
+                    int B) {
+  hipLaunchKernelGGL(k_fitness, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, poses, max_range, partials, max_blocks);
+}
+__global__ __launch_bounds__(64) void k_fitness_final(const CloudDesc* descs, const double* __restrict__ partials, int max_blocks, DevResult* out) {
+  const int b = blockIdx.x;
+  const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
+  double s = 0, c = 0;
+  for (int t = threadIdx.x; t < ntiles; t += 64) {
+    s += partials[((size_t)b * max_blocks + t) * 2];
+    c += partials[((size_t)b * max_blocks + t) * 2 + 1];
+  }
+  s = wave_sum(s), c = wave_sum(c);
+  if (threadIdx.x == 0) out[b].fit_sum = s, out[b].fit_count = (unsigned)(c + 0.5);
+}
+void launch_fitness_final(hipStream_t s, const CloudDesc* descs, const double* partials, int max_blocks, DevResult* out, int B) {
+  hipLaunchKernelGGL(k_fitness_final, dim3(B), dim3(64), 0, s, descs, partials, max_blocks, out);
+}
+
+__global__ __launch_bounds__(kBlock) void k_nn_query(TargetView tgt, const float4* __restrict__ q, int nq, int* __restrict__ idx, float* __restrict__ d2out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nq) return;
+  const float4 p = q[i];
+  float d2;
+  int orig;
+  const int j = bvh_nn1(view_of(tgt), F3{p.x, p.y, p.z}, FLT_MAX, &d2, &orig);
+  idx[i] = j >= 0 ? orig : -1;
+  d2out[i] = d2;
+}
+void launch_nn_query(hipStream_t s, TargetView tgt, const float4* q, int nq, int* idx, float* d2) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(k_nn_query, dim3((nq + kBlock - 1) / kBlock), dim3(kBlock), 0, s, tgt, q, nq, idx, d2);
+}
+
+__global__ __launch_bounds__(kBlock) void k_transform(const float4* __restrict__ raw, int n, const float* __restrict__ T16, float4* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float Tf[12];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) Tf[r * 4 + cc] = T16[cc * 4 + r];
+  const float4 a = raw[i];
+  const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
+  out[i] = make_float4(q.x, q.y, q.z, 1.0f);
+}
+void launch_transform(hipStream_t s, const float4* raw, int n, const float* T16_dev, float4* out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_transform, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, raw, n, T16_dev, out);
+}
+
+// ------------------------------------------------------------------------------------------------ NDT target voxelisation
+__global__ void k_ndt_grid_params(CloudDesc d, float inv_leaf) {
+  CloudMeta* m = d.meta;
+  m->ndt_ncells = 0;
+  m->ndt_error = 0;
+  if (m->nvalid <= 0) {
+    for (int k = 0; k < 3; k++) m->ndt_min_b[k] = 0, m->ndt_max_b[k] = -1, m->ndt_div_mul[k] = 0;
+    return;
+  }
+  long long div[3];
+  for (int k = 0; k < 3; k++) {
+    m->ndt_min_b[k] = (int)floorf(ord2f(m->bbmin[k]) * inv_leaf);
+    m->ndt_max_b[k] = (int)floorf(ord2f(m->bbmax[k]) * inv_leaf);
+    div[k] = (long long)m->ndt_max_b[k] - m->ndt_min_b[k] + 1;
+  }
+  if (div[0] * div[1] * div[2] > 2147483647LL) m->ndt_error = 1;
+  m->ndt_div_mul[0] = 1, m->ndt_div_mul[1] = (int)div[0], m->ndt_div_mul[2] = (int)(div[0] * div[1]);
+}
+void launch_ndt_grid_params(hipStream_t s, CloudDesc desc, float inv_leaf) { hipLaunchKernelGGL(k_ndt_grid_params, dim3(1), dim3(1), 0, s, desc, inv_leaf); }
+
+__global__ __launch_bounds__(kBlock) void k_ndt_cell_keys(CloudDesc d, float inv_leaf, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= d.n_input) return;
+  const float4 p = d.raw[i];
+  unsigned long long key = 0xffffffffull;
+  const CloudMeta* m = d.meta;
+  if (finite3(p) && !m->ndt_error) {
+    const int cx = (int)floorf(p.x * inv_leaf) - m->ndt_min_b[0];
+    const int cy = (int)floorf(p.y * inv_leaf) - m->ndt_min_b[1];
+    const int cz = (int)floorf(p.z * inv_leaf) - m->ndt_min_b[2];
+    key = (unsigned long long)(unsigned)(cx * m->ndt_div_mul[0] + cy * m->ndt_div_mul[1] + cz * m->ndt_div_mul[2]);
+  }
+  keys[i] = key;
+  vals[i] = (unsigned)i;
+}
+void launch_ndt_cell_keys(hipStream_t s, CloudDesc desc, float inv_leaf, unsigned long long* keys, unsigned* vals) {
+  if (desc.n_input <= 0) return;
+  hipLaunchKernelGGL(k_ndt_cell_keys, dim3((desc.n_input + kBlock - 1) / kBlock), dim3(kBlock), 0, s, desc, inv_leaf, keys, vals);
+}
+
+// One thread per segment head accumulates its cell (double), finalises it and inserts it into the hash table.
+__global__ __launch_bounds__(kBlock) void k_ndt_build_cells(CloudDesc d, const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                            int min_points, int* hash_keys, int* hash_vals, int hash_mask, NdtCellRec* cells) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= d.n_input) return;
+  const unsigned long long key = keys[i];
+  if (key == 0xffffffffull) return;
+  if (i > 0 && keys[i - 1] == key) return;
+  double sum[3] = {0, 0, 0};
+  Sym3 sq = {0, 0, 0, 0, 0, 0};
+  int n = 0;
+  for (int j = i; j < d.n_input && keys[j] == key; j++) {
+    const float4 p = d.raw[vals[j]];
+    const double x = p.x, y = p.y, z = p.z;
+    sum[0] += x, sum[1] += y, sum[2] += z;
+    sq.xx += x * x, sq.xy += x * y, sq.xz += x * z, sq.yy += y * y, sq.yz += y * z, sq.zz += z * z;
+    n++;
+  }
+  double mean[3];
+  Sym3 icov;
+  if (!ndt_finalize_cell(n, sum, sq, min_points, mean, &icov)) return;
+  const int slot_c = atomicAdd(&d.meta->ndt_ncells, 1);
+  NdtCellRec rec;
+  rec.v0 = make_float4((float)icov.xx, (float)icov.xy, (float)icov.xz, (float)icov.yy);
+  rec.v1 = make_float4((float)icov.yz, (float)icov.zz, (float)n, __int_as_float((int)key));
+  rec.mean[0] = mean[0], rec.mean[1] = mean[1], rec.mean[2] = mean[2], rec.pad = 0.0;
+  cells[slot_c] = rec;
+  unsigned slot = (ndt_hash((int)key) >> 7) & (unsigned)hash_mask;
+  for (;;) {
+    const int prev = atomicCAS(&hash_keys[slot], -1, (int)key);
+    if (prev == -1) {
+      hash_vals[slot] = slot_c;
+      break;
+    }
+    slot = (slot + 1) & (unsigned)hash_mask;
+  }
+}
+void launch_ndt_build_cells(hipStream_t s, CloudDesc desc, const unsigned long long* sorted_keys, const unsigned* sorted_vals, int min_points,
+                            int* hash_keys, int* hash_vals, int hash_mask, NdtCellRec* cells) {
+  if (desc.n_input <= 0) return;
+  hipLaunchKernelGGL(k_ndt_build_cells, dim3((desc.n_input + kBlock - 1) / kBlock), dim3(kBlock), 0, s, desc, sorted_keys, sorted_vals, min_points,
+                     hash_keys, hash_vals, hash_mask, cells);
+}
+
+// ------------------------------------------------------------------------------------------------ NDT iteration
+__global__ void k_ndt_init(NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, int* done_counter) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) *done_counter = 0;
+  if (b >= B) return;
+  ndt_state_init(states[b], guesses + 16 * b);
+  ndt_angle_tables(states[b].p, c.upstream_hd1_sign, angles[b]);
+}
+void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, int* done_counter) {
+  hipLaunchKernelGGL(k_ndt_init, dim3((B + 63) / 64), dim3(64), 0, s, states, angles, guesses, c, B, done_counter);
+}
+
+// computeDerivatives: per source point, transform, visit the DIRECT1/DIRECT7 cells, accumulate score / gradient /
+// Hessian.  Algorithmic bytes per source point: 16 + 7*40 = 296 (DIRECT7), 56 (DIRECT1).
+__global__ __launch_bounds__(kBlock) void k_ndt_derivatives(const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles,
+                                                            NdtConsts c, double* __restrict__ partials, int max_blocks) {
+  const int b = blockIdx.y;
+  if (states[b].phase != NDT_DERIV) return;
+  const CloudDesc d = descs[b];
+  const int n = d.n_input;
+  const int ntiles = (n + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tile = blockIdx.x;
+  const int i = tile * kBlock + threadIdx.x;
+  __shared__ double lds[4 * kAcc];
+  __shared__ NdtAngles ang;
+  for (int k = threadIdx.x; k < (int)(sizeof(NdtAngles) / 4); k += kBlock) reinterpret_cast<float*>(&ang)[k] = reinterpret_cast<const float*>(&angles[b])[k];
+  __syncthreads();
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+  if (i < n) {
+    const float4 x = d.raw[i];
+    if (finite3(x)) {
+      NdtGrid g;
+      g.hash_keys = tgt.hash_keys, g.hash_vals = tgt.hash_vals, g.cells = tgt.cells, g.hash_mask = tgt.hash_mask, g.inv_leaf = tgt.inv_leaf;
+      for (int k = 0; k < 3; k++) g.min_b[k] = tgt.meta->ndt_min_b[k], g.max_b[k] = tgt.meta->ndt_max_b[k], g.div_mul[k] = tgt.meta->ndt_div_mul[k];
+      const F3 xt = transform_point_f(ang.T, x.x, x.y, x.z);
+      const int cx = (int)floorf(xt.x * g.inv_leaf), cy = (int)floorf(xt.y * g.inv_leaf), cz = (int)floorf(xt.z * g.inv_leaf);
+      NdtPointDeriv pd;
+      ndt_point_derivatives(ang, x.x, x.y, x.z, pd);
+      const int nn = c.search == 1 ? 1 : 7;
+      for (int o = 0; o < nn; o++) {
+        const int ox = (o == 1) - (o == 2), oy = (o == 3) - (o == 4), oz = (o == 5) - (o == 6);
+        const int ci = ndt_lookup(g, cx + ox, cy + oy, cz + oz);
+        if (ci < 0) continue;
+        const NdtCellRec rec = g.cells[ci];
+        const float icov[6] = {rec.v0.x, rec.v0.y, rec.v0.z, rec.v0.w, rec.v1.x, rec.v1.y};
+        ndt_cell_terms(c, pd, (float)((double)xt.x - rec.mean[0]), (float)((double)xt.y - rec.mean[1]), (float)((double)xt.z - rec.mean[2]), icov, acc);
+      }
+    }
+  }
+  block_reduce_store<kAcc>(acc, partials + ((size_t)b * max_blocks + tile) * kAcc, lds);
+}
+void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles, NdtConsts c,
+                            double* partials, int max_blocks, int B) {
+  hipLaunchKernelGGL(k_ndt_derivatives, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, angles, c, partials, max_blocks);
+}
+
+__global__ __launch_bounds__(64) void k_ndt_solve(const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c,
+                                                 const double* __restrict__ partials, int max_blocks, int* done_counter) {
+  const int b = blockIdx.x;
+  NdtState& st = states[b];
+  if (st.phase != NDT_DERIV) return;
+  __shared__ double acc[kAcc];
+  const int ntiles = (descs[b].n_input + kBlock - 1) / kBlock;
+  if (threadIdx.x < kAcc) {
+    double s = 0;
+    const double* p = partials + (size_t)b * max_blocks * kAcc + threadIdx.x;
+    for (int t = 0; t < ntiles; t++) s += p[(size_t)t * kAcc];
+    acc[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ndt_after_derivatives(st, acc, c);
+    if (st.phase == NDT_DONE) atomicAdd(done_counter, 1);
+    else ndt_angle_tables(st.p, c.upstream_hd1_sign, angles[b]);
+  }
+}
+void launch_ndt_solve(hipStream_t s, const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c, const double* partials, int max_blocks,
+                      int B, int* done_counter) {
+  hipLaunchKernelGGL(k_ndt_solve, dim3(B), dim3(64), 0, s, descs, states, angles, c, partials, max_blocks, done_counter);
+}
+
+__global__ void k_ndt_results(const CloudDesc* descs, const NdtState* states, DevResult* out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const NdtState& st = states[b];
+  DevResult r;
+  pose_to_colmajor_f(st.final_T, r.T);
+  r.converged = st.converged, r.iterations = st.iterations, r.lm_tries = st.passes, r.pad = 0;
+  const int n = descs[b].meta->nvalid;
+  r.error = n > 0 ? st.score / (double)n : 0.0;
+  r.fit_sum = 0, r.fit_count = 0, r.pad2 = 0;
+  out[b] = r;
+}
+void launch_ndt_results(hipStream_t s, const CloudDesc* descs, const NdtState* states, DevResult* out, int B) {
+  hipLaunchKernelGGL(k_ndt_results, dim3((B + 63) / 64), dim3(64), 0, s, descs, states, out, B);
+}
+
+}  // namespace hgs
+
+// ------------------------------------------------------------------------------------------------ stage-level test hooks
+namespace hgs {
+
+__global__ void k_gicp_debug_state(GicpState* st, const double* T12) {
+  float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  gicp_state_init(st[0], I);
+  for (int i = 0; i < 12; i++) st[0].x0.m[i] = T12[i], st[0].xi.m[i] = T12[i];
+}
+void launch_gicp_debug_state(hipStream_t s, GicpState* st, const double* T12_dev) { hipLaunchKernelGGL(k_gicp_debug_state, dim3(1), dim3(1), 0, s, st, T12_dev); }
+
+__global__ void k_ndt_debug_state(NdtState* st, NdtAngles* ang, const double* p6, NdtConsts c) {
+  float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  ndt_state_init(st[0], I);
+  for (int i = 0; i < 6; i++) st[0].p[i] = p6[i], st[0].p_acc[i] = p6[i];
+  ndt_angle_tables(st[0].p, c.upstream_hd1_sign, ang[0]);
+}
+void launch_ndt_debug_state(hipStream_t s, NdtState* st, NdtAngles* ang, const double* p6_dev, NdtConsts c) {
+  hipLaunchKernelGGL(k_ndt_debug_state, dim3(1), dim3(1), 0, s, st, ang, p6_dev, c);
+}
+
+// out[k] = sum over tiles of partials[t*kAcc + k], in tile order (what k_gicp_solve / k_ndt_solve do first)
+__global__ __launch_bounds__(64) void k_reduce_partials(const double* __restrict__ partials, int ntiles, double* out) {
+  if (threadIdx.x < kAcc) {
+    double s = 0;
+    for (int t = 0; t < ntiles; t++) s += partials[(size_t)t * kAcc + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+void launch_reduce_partials(hipStream_t s, const double* partials, int ntiles, double* out) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, s, partials, ntiles, out);
+}
+
+}  // namespace hgs

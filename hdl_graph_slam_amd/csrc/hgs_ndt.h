@@ -1,0 +1,327 @@
+// hgs_ndt.h — per-cell / per-point arithmetic and the Newton state machine of the NDT engine
+// (pclomp::NormalDistributionsTransform + VoxelGridCovariance; reference call site
+// src/hdl_graph_slam/registrations.cpp:101-120).  HGS_HD like hgs_gicp.h.
+#pragma once
+#include "hgs_bvh.h"
+
+namespace hgs {
+
+// One Gaussian cell in HBM: 64 bytes (algorithmic 40 B: mean 12, icov 24, n 4).  The mean stays in double — the
+// residual x' - mean is formed in double and rounded once, exactly as ndt_omp does, which keeps the Newton
+// trajectory on the oracle's; the inverse covariance is consumed in float upstream, so it is stored in float.
+//   v0 = (icov.xx, icov.xy, icov.xz, icov.yy)  v1 = (icov.yz, icov.zz, n, key)  mean[3], pad
+struct alignas(16) NdtCellRec {
+  Float4 v0, v1;
+  double mean[3];
+  double pad;
+};
+
+struct NdtGrid {
+  const int* hash_keys;       // open addressing, -1 = empty; key = linear cell index inside the bounding grid
+  const int* hash_vals;       // -> index into cells
+  const NdtCellRec* cells;
+  int hash_mask;              // capacity - 1 (power of two)
+  int min_b[3], max_b[3];
+  int div_mul[3];             // (1, div.x, div.x*div.y)
+  float inv_leaf;
+};
+
+HGS_HD uint32_t ndt_hash(int key) { return (uint32_t)key * 2654435761u; }
+
+HGS_HD int ndt_lookup(const NdtGrid& g, int cx, int cy, int cz) {
+  if (cx < g.min_b[0] || cx > g.max_b[0] || cy < g.min_b[1] || cy > g.max_b[1] || cz < g.min_b[2] || cz > g.max_b[2]) return -1;
+  const int key = (cx - g.min_b[0]) * g.div_mul[0] + (cy - g.min_b[1]) * g.div_mul[1] + (cz - g.min_b[2]) * g.div_mul[2];
+  uint32_t slot = (ndt_hash(key) >> 7) & (uint32_t)g.hash_mask;
+  for (;;) {
+    const int k = g.hash_keys[slot];
+    if (k == key) return g.hash_vals[slot];
+    if (k == -1) return -1;
+    slot = (slot + 1) & (uint32_t)g.hash_mask;
+  }
+}
+
+// VoxelGridCovariance second pass for one cell: from n, sum p, sum p p^T (double) to mean / inverse covariance.
+// Returns false if the cell is rejected (fewer than min_points, bad eigenvalues, non-finite inverse).
+HGS_HD bool ndt_finalize_cell(int n, const double* sum, const Sym3& sq, int min_points, double* mean, Sym3* icov) {
+  const double dn = (double)n;
+  mean[0] = sum[0] / dn, mean[1] = sum[1] / dn, mean[2] = sum[2] / dn;
+  if (n < min_points) return false;
+  // cov = (sum pp^T - 2 sum_p mean^T)/n + mean mean^T, then *(n-1)/n  (upstream's single-pass form)
+  const double f = (dn - 1.0) / dn;
+  double C[9];
+  C[0] = ((sq.xx - 2.0 * (sum[0] * mean[0])) / dn + mean[0] * mean[0]) * f;
+  C[1] = ((sq.xy - 2.0 * (sum[0] * mean[1])) / dn + mean[0] * mean[1]) * f;
+  C[2] = ((sq.xz - 2.0 * (sum[0] * mean[2])) / dn + mean[0] * mean[2]) * f;
+  C[4] = ((sq.yy - 2.0 * (sum[1] * mean[1])) / dn + mean[1] * mean[1]) * f;
+  C[5] = ((sq.yz - 2.0 * (sum[1] * mean[2])) / dn + mean[1] * mean[2]) * f;
+  C[8] = ((sq.zz - 2.0 * (sum[2] * mean[2])) / dn + mean[2] * mean[2]) * f;
+  C[3] = C[1], C[6] = C[2], C[7] = C[5];
+  double w[3], V[9];
+  eig_sym3(C, w, V);
+  if (w[0] < 0 || w[1] < 0 || w[2] <= 0) return false;
+  const double mn = 0.01 * w[2];
+  if (w[0] < mn) {
+    w[0] = mn;
+    if (w[1] < mn) w[1] = mn;
+    // cov = V diag(w) V^-1
+    double Vi[9], VL[9];
+    mat3_inverse(V, Vi);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) VL[r * 3 + c] = V[r * 3 + c] * w[c];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) C[r * 3 + c] = VL[r * 3 + 0] * Vi[0 * 3 + c] + VL[r * 3 + 1] * Vi[1 * 3 + c] + VL[r * 3 + 2] * Vi[2 * 3 + c];
+  }
+  double Ci[9];
+  mat3_inverse(C, Ci);
+  for (int i = 0; i < 9; i++)
+    if (isinf(Ci[i])) return false;
+  icov->xx = Ci[0], icov->xy = Ci[1], icov->xz = Ci[2], icov->yy = Ci[4], icov->yz = Ci[5], icov->zz = Ci[8];
+  return true;
+}
+
+struct NdtConsts {
+  double gauss_d1, gauss_d2;
+  double step_size, trans_eps;
+  int max_iterations;
+  int search;  // HGS_DIRECT1 = 1 / HGS_DIRECT7 = 2
+  int upstream_hd1_sign;
+  int pad;
+};
+
+// Angular derivative tables (computeAngleDerivatives): 8 j_ang rows and 15 h_ang rows as float triples.
+struct NdtAngles {
+  float j[8][3];
+  float h[15][3];
+  float T[12];  // float pose row-major 3x4 used to transform the cloud
+};
+
+HGS_HD Pose ndt_pose_from_p(const double* p) {
+  const double cx = cos(p[3]), sx = sin(p[3]), cy = cos(p[4]), sy = sin(p[4]), cz = cos(p[5]), sz = sin(p[5]);
+  Pose T;
+  T.m[0] = cy * cz, T.m[1] = -cy * sz, T.m[2] = sy, T.m[3] = p[0];
+  T.m[4] = cx * sz + sx * sy * cz, T.m[5] = cx * cz - sx * sy * sz, T.m[6] = -sx * cy, T.m[7] = p[1];
+  T.m[8] = sx * sz - cx * sy * cz, T.m[9] = cx * sy * sz + sx * cz, T.m[10] = cx * cy, T.m[11] = p[2];
+  return T;
+}
+
+HGS_HD void ndt_angle_tables(const double* p, int upstream_hd1_sign, NdtAngles& a) {
+  double cx, cy, cz, sx, sy, sz;
+  if (fabs(p[3]) < 10e-5) cx = 1.0, sx = 0.0; else cx = cos(p[3]), sx = sin(p[3]);
+  if (fabs(p[4]) < 10e-5) cy = 1.0, sy = 0.0; else cy = cos(p[4]), sy = sin(p[4]);
+  if (fabs(p[5]) < 10e-5) cz = 1.0, sz = 0.0; else cz = cos(p[5]), sz = sin(p[5]);
+  const double j[8][3] = {{-sx * sz + cx * sy * cz, -sx * cz - cx * sy * sz, -cx * cy}, {cx * sz + sx * sy * cz, cx * cz - sx * sy * sz, -sx * cy},
+                          {-sy * cz, sy * sz, cy},                                     {sx * cy * cz, -sx * cy * sz, sx * sy},
+                          {-cx * cy * cz, cx * cy * sz, -cx * sy},                      {-cy * sz, -cy * cz, 0},
+                          {cx * cz - sx * sy * sz, -cx * sz - sx * sy * cz, 0},         {sx * cz + cx * sy * sz, cx * sy * cz - sx * sz, 0}};
+  const double hd1z = upstream_hd1_sign ? sy : -sy;
+  const double h[15][3] = {{-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, sx * cy},  {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, -cx * cy},
+                           {cx * cy * cz, -cx * cy * sz, cx * sy},                       {sx * cy * cz, -sx * cy * sz, sx * sy},
+                           {-sx * cz - cx * sy * sz, sx * sz - cx * sy * cz, 0},         {cx * cz - sx * sy * sz, -sx * sy * cz - cx * sz, 0},
+                           {-cy * cz, cy * sz, hd1z},                                    {-sx * sy * cz, sx * sy * sz, sx * cy},
+                           {cx * sy * cz, -cx * sy * sz, -cx * cy},                      {sy * sz, sy * cz, 0},
+                           {-sx * cy * sz, -sx * cy * cz, 0},                            {cx * cy * sz, cx * cy * cz, 0},
+                           {-cy * cz, cy * sz, 0},                                       {-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, 0},
+                           {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0}};
+  for (int r = 0; r < 8; r++)
+    for (int c = 0; c < 3; c++) a.j[r][c] = (float)j[r][c];
+  for (int r = 0; r < 15; r++)
+    for (int c = 0; c < 3; c++) a.h[r][c] = (float)h[r][c];
+  const Pose T = ndt_pose_from_p(p);
+  pose_to_float(T, a.T);
+}
+
+// Per-point derivative temporaries (computePointDerivatives), float like ndt_omp.
+struct NdtPointDeriv {
+  float xj[8];   // j_ang rows . x
+  float xh[15];  // h_ang rows . x
+};
+
+HGS_HD void ndt_point_derivatives(const NdtAngles& a, float x, float y, float z, NdtPointDeriv& d) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+#pragma unroll
+  for (int r = 0; r < 8; r++) d.xj[r] = a.j[r][0] * x + a.j[r][1] * y + a.j[r][2] * z;
+#pragma unroll
+  for (int r = 0; r < 15; r++) d.xh[r] = a.h[r][0] * x + a.h[r][1] * y + a.h[r][2] * z;
+}
+
+// updateDerivatives for one (point, cell): adds to acc[28] = {H upper 21, g 6, score}. Float temporaries, double
+// accumulation, exactly the operation order of the oracle (oracle/ndt.hpp) so the two agree to float rounding.
+HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx, float qy, float qz,  // q = x' - mean (float)
+                           const float* ci /*icov xx,xy,xz,yy,yz,zz*/, double* acc) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const float d1 = (float)c.gauss_d1, d2 = (float)c.gauss_d2;
+  const float C[3][3] = {{ci[0], ci[1], ci[2]}, {ci[1], ci[3], ci[4]}, {ci[2], ci[4], ci[5]}};
+  float qC[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) qC[s] = qx * C[0][s] + qy * C[1][s] + qz * C[2][s];
+  const float qCq = qC[0] * qx + qC[1] * qy + qC[2] * qz;
+  float e = expf(-d2 * qCq * 0.5f);
+  const float score_inc = -d1 * e;
+  e = d2 * e;
+  if (e > 1.f || e < 0.f || e != e) return;
+  e *= d1;
+  acc[27] += (double)score_inc;
+  // point gradient (3x6): identity | columns 3..5 from xj
+  float pg[3][6];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) pg[r][k] = (r == k) ? 1.f : 0.f;
+  pg[1][3] = pd.xj[0], pg[2][3] = pd.xj[1];
+  pg[0][4] = pd.xj[2], pg[1][4] = pd.xj[3], pg[2][4] = pd.xj[4];
+  pg[0][5] = pd.xj[5], pg[1][5] = pd.xj[6], pg[2][5] = pd.xj[7];
+  float Cpg[3][6], qCpg[6];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) Cpg[r][k] = C[r][0] * pg[0][k] + C[r][1] * pg[1][k] + C[r][2] * pg[2][k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) qCpg[k] = qx * Cpg[0][k] + qy * Cpg[1][k] + qz * Cpg[2][k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc[21 + k] += (double)(e * qCpg[k]);
+  // second derivatives d2x'/dp_i dp_j (3-vectors), non-zero for i,j in {3,4,5}
+  const float ph[6][3] = {{0.f, pd.xh[0], pd.xh[1]},          // (3,3) a
+                          {0.f, pd.xh[2], pd.xh[3]},          // (3,4) b
+                          {0.f, pd.xh[4], pd.xh[5]},          // (3,5) c
+                          {pd.xh[6], pd.xh[7], pd.xh[8]},     // (4,4) d
+                          {pd.xh[9], pd.xh[10], pd.xh[11]},   // (4,5) e
+                          {pd.xh[12], pd.xh[13], pd.xh[14]}}; // (5,5) f
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++) {
+      float qCh = 0.f;
+      if (i >= 3) {
+        const int hidx = (i == 3) ? (j - 3) : (i == 4 ? (j - 4 + 3) : 5);
+        qCh = qC[0] * ph[hidx][0] + qC[1] * ph[hidx][1] + qC[2] * ph[hidx][2];
+      }
+      const float pgCpg = pg[0][j] * Cpg[0][i] + pg[1][j] * Cpg[1][i] + pg[2][j] * Cpg[2][i];
+      acc[k] += (double)(e * (-d2 * qCpg[i] * qCpg[j] + qCh + pgCpg));
+      k++;
+    }
+}
+
+// Eigen's eulerAngles(0,1,2) on the float rotation of the guess (ndt_omp's initial p)
+HGS_HD void ndt_euler_xyz_f(const float* g16_colmajor, float* out) {
+  const float R00 = g16_colmajor[0], R01 = g16_colmajor[4], R02 = g16_colmajor[8];
+  const float R10 = g16_colmajor[1], R11 = g16_colmajor[5], R12 = g16_colmajor[9];
+  const float R20 = g16_colmajor[2], R21 = g16_colmajor[6], R22 = g16_colmajor[10];
+  float r0 = atan2f(R12, R22);
+  const float c2 = sqrtf(R00 * R00 + R01 * R01);
+  float r1;
+  if (r0 > 0.f) {
+    r0 -= 3.14159265358979323846f;
+    r1 = atan2f(-R02, -c2);
+  } else {
+    r1 = atan2f(-R02, c2);
+  }
+  const float s1 = sinf(r0), c1 = cosf(r0);
+  const float r2 = atan2f(s1 * R20 - c1 * R10, c1 * R11 - s1 * R21);
+  out[0] = -r0, out[1] = -r1, out[2] = -r2;
+}
+
+// ---- per-problem Newton state machine (computeTransformation + computeStepLengthMT without the dead MT loop) --
+enum NdtPhase { NDT_DERIV = 0, NDT_DONE = 1 };
+
+struct NdtState {
+  double p[6];      // parameters the NEXT derivative pass is evaluated at
+  double p_acc[6];  // upstream's `p` (accumulated; differs from the evaluation point only by rounding)
+  double dp[6];     // unit direction of the pending step
+  double a_t;       // pending step length
+  double score;
+  Pose final_T;
+  int phase;
+  int iterations;
+  int passes;
+  int converged;
+  int first;  // 1 until the initial derivative pass has been consumed
+  int pad;
+};
+
+HGS_HD void ndt_state_init(NdtState& s, const float* guess_colmajor) {
+  float e[3];
+  ndt_euler_xyz_f(guess_colmajor, e);
+  s.p[0] = guess_colmajor[12], s.p[1] = guess_colmajor[13], s.p[2] = guess_colmajor[14];
+  s.p[3] = e[0], s.p[4] = e[1], s.p[5] = e[2];
+  for (int i = 0; i < 6; i++) s.p_acc[i] = s.p[i], s.dp[i] = 0;
+  s.a_t = 0, s.score = 0;
+  s.final_T = pose_from_colmajor_f(guess_colmajor);
+  s.phase = NDT_DERIV;
+  s.iterations = 0, s.passes = 0, s.converged = 0, s.first = 1, s.pad = 0;
+}
+
+// Consumes the reduced {H, g, score} of a derivative pass evaluated at s.p and prepares the next evaluation point.
+HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConsts& c) {
+  double H[36], g[6];
+  int k = 0;
+  for (int r = 0; r < 6; r++)
+    for (int cc = r; cc < 6; cc++) {
+      H[r * 6 + cc] = acc[k];
+      H[cc * 6 + r] = acc[k];
+      k++;
+    }
+  for (int i = 0; i < 6; i++) g[i] = acc[21 + i];
+  s.score = acc[27];
+  s.passes++;
+  if (!s.first) {
+    // finish the iteration whose step produced this pass: p += dp * a_t ; convergence test ; iter++
+    for (int i = 0; i < 6; i++) s.p_acc[i] += s.dp[i] * s.a_t;
+    s.final_T = ndt_pose_from_p(s.p);
+    const bool conv = (s.iterations > c.max_iterations) || (s.iterations && fabs(s.a_t) < c.trans_eps);
+    s.iterations++;
+    if (conv) {
+      s.converged = 1;
+      s.phase = NDT_DONE;
+      return;
+    }
+  }
+  s.first = 0;
+  for (;;) {
+    // Newton direction: dp = SVD-solve(H, -g)
+    double ng[6], dp[6];
+    for (int i = 0; i < 6; i++) ng[i] = -g[i];
+    solve_svd6(H, ng, dp);
+    double nrm = 0;
+    for (int i = 0; i < 6; i++) nrm += dp[i] * dp[i];
+    nrm = sqrt(nrm);
+    if (nrm == 0 || nrm != nrm) {
+      s.converged = (nrm == nrm) ? 1 : 0;
+      s.phase = NDT_DONE;
+      return;
+    }
+    for (int i = 0; i < 6; i++) dp[i] /= nrm;
+    double d_phi_0 = 0;
+    for (int i = 0; i < 6; i++) d_phi_0 -= g[i] * dp[i];
+    if (d_phi_0 >= 0) {
+      if (d_phi_0 == 0) {
+        // step length 0: no new derivative pass; the iteration completes immediately with a_t = 0
+        const bool conv = (s.iterations > c.max_iterations) || (s.iterations && 0.0 < c.trans_eps);
+        s.iterations++;
+        if (conv) {
+          s.converged = 1;
+          s.phase = NDT_DONE;
+          return;
+        }
+        continue;  // same H, g -> same direction: upstream would spin until max_iterations; so do we
+      }
+      for (int i = 0; i < 6; i++) dp[i] = -dp[i];
+    }
+    double a_t = nrm < c.step_size ? nrm : c.step_size;
+    const double step_min = c.trans_eps / 2;
+    a_t = a_t > step_min ? a_t : step_min;
+    for (int i = 0; i < 6; i++) {
+      s.dp[i] = dp[i];
+      s.p[i] = s.p_acc[i] + dp[i] * a_t;
+    }
+    s.a_t = a_t;
+    s.phase = NDT_DERIV;
+    return;
+  }
+}
+
+}  // namespace hgs

@@ -1,0 +1,14 @@
+// hgs_sort.hip — device-wide key/value radix sort used to order points along the Hilbert curve (search index)
+// and by voxel key (Gaussian cell build).  Plain library sort (rocPRIM); everything domain-specific is in
+// hgs_kernels.hip.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "hgs_sort.h"
+
+extern "C" int hgs_sort_pairs_u64_u32(void* temp, size_t* temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
+                                      uint32_t* vals_out, size_t n, int begin_bit, int end_bit, void* stream) {
+  hipError_t e = rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out, n, (unsigned)begin_bit, (unsigned)end_bit,
+                                           (hipStream_t)stream, false);
+  return (int)e;
+}

@@ -1,0 +1,221 @@
+"""pcl::Registration-shaped front-end of the MI355X backend.
+
+Mirrors the surface hdl_graph_slam's callers use on the object returned by select_registration_method
+(reference: apps/scan_matching_odometry_nodelet.cpp:172-246,298-335 and
+include/hdl_graph_slam/loop_detector.hpp:122-153): setInputTarget / setInputSource / align / hasConverged /
+getFinalTransformation / getFitnessScore / getSearchMethodTarget()->nearestKSearch.  Every call goes through the
+C-ABI of include/hgs_registration.h into the HIP library; nothing here computes on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class HgsError(RuntimeError):
+    pass
+
+
+class DeviceCloud:
+    """A cloud resident in HBM (hgs_cloud): a KeyFrame::cloud uploaded once and reused as loop-closure candidate."""
+
+    def __init__(self, reg: "RegistrationHIP", cloud: np.ndarray):
+        arr, n, stride = L.cloud_args(cloud)
+        self._reg = reg
+        self._h = C.c_void_p()
+        reg._check(L.lib().hgs_cloud_create(reg._h, arr.ctypes.data_as(C.c_void_p), n, stride, C.byref(self._h)))
+        self.size = n
+
+    def invalidate(self):
+        L.lib().hgs_cloud_invalidate(self._h)
+
+    def close(self):
+        if self._h:
+            L.lib().hgs_cloud_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self._reg._h:
+                self.close()
+        except Exception:
+            pass
+
+
+class _SearchMethodTarget:
+    def __init__(self, reg):
+        self._reg = reg
+
+    def nearestKSearch(self, points: np.ndarray, k: int = 1):
+        """(indices [n], squared distances [n]) of the exact nearest target point of every query (k must be 1)."""
+        if k != 1:
+            raise NotImplementedError("the callers only use k = 1 (scan_matching_odometry_nodelet.cpp:316)")
+        arr, n, stride = L.cloud_args(points)
+        idx = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        self._reg._check(L.lib().hgs_nn_target(self._reg._h, arr.ctypes.data_as(C.c_void_p), n, stride, idx.ctypes.data_as(C.c_void_p),
+                                               d2.ctypes.data_as(C.c_void_p)))
+        return idx, d2
+
+
+class RegistrationHIP:
+    def __init__(self, params: L.HgsParams):
+        self.params = params
+        self._h = C.c_void_p()
+        rc = L.lib().hgs_create(C.byref(params), C.byref(self._h))
+        if rc != L.HGS_OK:
+            msg = L.lib().hgs_last_error(None)
+            raise HgsError(f"hgs_create failed: {L.STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
+        self._result = None
+        self._source_n = 0
+        self._source_stride = 0
+        self._keep = {}
+
+    # ---- life cycle
+    def close(self):
+        if self._h:
+            L.lib().hgs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != L.HGS_OK:
+            msg = L.lib().hgs_last_error(self._h)
+            raise HgsError(f"{L.STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    # ---- pcl::Registration surface
+    def setInputTarget(self, cloud):
+        if isinstance(cloud, DeviceCloud):
+            self._keep["t"] = cloud
+            self._check(L.lib().hgs_set_target_cloud(self._h, cloud._h))
+        else:
+            arr, n, stride = L.cloud_args(cloud)
+            self._check(L.lib().hgs_set_target(self._h, arr.ctypes.data_as(C.c_void_p), n, stride))
+
+    def setInputSource(self, cloud):
+        if isinstance(cloud, DeviceCloud):
+            self._keep["s"] = cloud
+            self._source_n = cloud.size
+            self._check(L.lib().hgs_set_source_cloud(self._h, cloud._h))
+        else:
+            arr, n, stride = L.cloud_args(cloud)
+            self._source_n = n
+            self._check(L.lib().hgs_set_source(self._h, arr.ctypes.data_as(C.c_void_p), n, stride))
+
+    def align(self, guess=None, return_cloud: bool = False):
+        """registration->align(*aligned, guess). Returns the hgs_result (and the aligned xyz cloud if requested)."""
+        g = L.colmajor16(np.eye(4) if guess is None else guess)
+        r = L.HgsResult()
+        self._check(L.lib().hgs_align(self._h, L.fptr(g), C.byref(r)))
+        self._result = r
+        if return_cloud:
+            return r, self.transformed_source(r.matrix())
+        return r
+
+    def transformed_source(self, T) -> np.ndarray:
+        out = np.zeros((self._source_n, 4), np.float32)
+        g = L.colmajor16(T)
+        self._check(L.lib().hgs_transform_source(self._h, L.fptr(g), out.ctypes.data_as(C.c_void_p), 16))
+        return out
+
+    def hasConverged(self) -> bool:
+        return bool(self._result.converged) if self._result is not None else False
+
+    def getFinalTransformation(self) -> np.ndarray:
+        return self._result.matrix() if self._result is not None else np.eye(4, dtype=np.float32)
+
+    def getFitnessScore(self, max_range: float = L.DBL_MAX, T=None) -> float:
+        g = L.colmajor16(self.getFinalTransformation() if T is None else T)
+        score, ninl = C.c_double(), C.c_uint32()
+        self._check(L.lib().hgs_fitness(self._h, L.fptr(g), float(max_range), C.byref(score), C.byref(ninl)))
+        self.last_num_inliers = ninl.value
+        return score.value
+
+    def getSearchMethodTarget(self) -> _SearchMethodTarget:
+        return _SearchMethodTarget(self)
+
+    # ---- device clouds / batch (LoopDetector::matching)
+    def upload(self, cloud) -> DeviceCloud:
+        return DeviceCloud(self, cloud)
+
+    def loop_match_batch(self, candidates, guesses, max_range: float = L.DBL_MAX):
+        """Register every candidate DeviceCloud against the current target; returns (records ndarray, best index)."""
+        n = len(candidates)
+        ptrs = (C.c_void_p * max(n, 1))(*[c._h for c in candidates])
+        g = np.ascontiguousarray(np.stack([L.colmajor16(T) for T in guesses]) if n else np.zeros((0, 16), np.float32))
+        out = np.zeros(n, dtype=L.RESULT_DTYPE)
+        best = C.c_int32(-1)
+        self._check(L.lib().hgs_loop_match_batch(self._h, ptrs, n, g.ctypes.data_as(C.c_void_p), float(max_range), out.ctypes.data_as(C.c_void_p),
+                                                 C.byref(best)))
+        return out, best.value
+
+    def calc_fitness_score(self, cloud1: DeviceCloud, cloud2: DeviceCloud, relpose, max_range: float = L.DBL_MAX) -> float:
+        """InformationMatrixCalculator::calc_fitness_score (src/hdl_graph_slam/information_matrix_calculator.cpp:49-80)."""
+        g = L.colmajor16(relpose)
+        score = C.c_double()
+        self._check(L.lib().hgs_calc_fitness_score(self._h, cloud1._h, cloud2._h, L.fptr(g), float(max_range), C.byref(score)))
+        return score.value
+
+    # ---- stage-level hooks (parity tests)
+    def nn_target(self, q_xyz):
+        return self.getSearchMethodTarget().nearestKSearch(q_xyz, 1)
+
+    def target_covariances(self, n_target: int) -> np.ndarray:
+        out = np.zeros((n_target, 6), np.float32)
+        self._check(L.lib().hgs_debug_target_covariances(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def gicp_linearize(self, T):
+        T12 = np.ascontiguousarray(np.asarray(T, np.float64)[:3, :4])
+        H, b, e = np.zeros((6, 6)), np.zeros(6), np.zeros(1)
+        corr = np.empty(self._source_n, np.int32)
+        vp = C.c_void_p
+        self._check(L.lib().hgs_debug_gicp_linearize(self._h, T12.ctypes.data_as(vp), H.ctypes.data_as(vp), b.ctypes.data_as(vp), e.ctypes.data_as(vp),
+                                                     corr.ctypes.data_as(vp)))
+        return H, b, float(e[0]), corr
+
+    def ndt_cells(self, cap: int = 1 << 20):
+        ijk, mean, icov, npts = np.zeros((cap, 3), np.int32), np.zeros((cap, 3)), np.zeros((cap, 6), np.float32), np.zeros(cap, np.int32)
+        n = C.c_int32()
+        vp = C.c_void_p
+        self._check(L.lib().hgs_debug_ndt_cells(self._h, cap, ijk.ctypes.data_as(vp), mean.ctypes.data_as(vp), icov.ctypes.data_as(vp),
+                                                npts.ctypes.data_as(vp), C.byref(n)))
+        k = min(n.value, cap)
+        return ijk[:k].copy(), mean[:k].copy(), icov[:k].copy(), npts[:k].copy()
+
+    def ndt_derivatives(self, p6):
+        p = np.ascontiguousarray(p6, np.float64)
+        s, g, H = np.zeros(1), np.zeros(6), np.zeros((6, 6))
+        vp = C.c_void_p
+        self._check(L.lib().hgs_debug_ndt_derivatives(self._h, p.ctypes.data_as(vp), s.ctypes.data_as(vp), g.ctypes.data_as(vp), H.ctypes.data_as(vp)))
+        return float(s[0]), g, H
+
+    # ---- measurement
+    def profile_enable(self, on: bool = True):
+        self._check(L.lib().hgs_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset: bool = True):
+        ms = np.zeros(len(L.STAGES))
+        cnt = np.zeros(len(L.STAGES), np.uint64)
+        self._check(L.lib().hgs_profile_read(self._h, ms.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p), int(reset)))
+        return {s: (float(m), int(c)) for s, m, c in zip(L.STAGES, ms, cnt)}
+
+    def synchronize(self):
+        self._check(L.lib().hgs_synchronize(self._h))
+
+
+def select_best(records: np.ndarray) -> int:
+    """The sequential selection rule of loop_detector.hpp:146-153 applied to gathered per-candidate records."""
+    rec = np.ascontiguousarray(records)
+    best = C.c_int32(-1)
+    rc = L.lib().hgs_select_best(rec.ctypes.data_as(C.c_void_p), len(rec), C.byref(best))
+    if rc != L.HGS_OK:
+        raise HgsError(L.STATUS.get(rc, rc))
+    return best.value

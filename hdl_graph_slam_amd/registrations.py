@@ -1,0 +1,54 @@
+"""select_registration_method — Python mirror of include/hdl_graph_slam/registrations.hpp:17 /
+src/hdl_graph_slam/registrations.cpp:22-124 for the engines this backend implements.
+
+`pnh` is any mapping of the nodelet's private rosparams (the same keys and defaults the reference reads with
+pnh.param<T>(name, default)).  Returns a RegistrationHIP whose methods mirror pcl::Registration."""
+from __future__ import annotations
+
+import sys
+
+from . import _lib as L
+from .registration import RegistrationHIP
+
+# engines the reference factory builds from third-party CPU libraries and that are NOT rebuilt here
+_CPU_ONLY = ("ICP", "GICP", "GICP_OMP", "NDT")
+
+
+def params_from_rosparams(pnh) -> L.HgsParams:
+    get = pnh.get
+    method = str(get("registration_method", "NDT_OMP"))                            # registrations.cpp:26
+    if method in ("FAST_GICP", "FAST_GICP_HIP"):                                   # registrations.cpp:27-36
+        p = L.default_params(L.HGS_FAST_GICP)
+        p.transformation_epsilon = float(get("reg_transformation_epsilon", 0.01))
+        p.max_iterations = int(get("reg_maximum_iterations", 64))
+        p.max_correspondence_distance = float(get("reg_max_correspondence_distance", 2.5))
+        p.correspondence_randomness = int(get("reg_correspondence_randomness", 20))
+        return p
+    if method in ("FAST_VGICP", "FAST_VGICP_CUDA", "FAST_VGICP_HIP"):              # registrations.cpp:37-56
+        p = L.default_params(L.HGS_FAST_VGICP)
+        p.resolution = float(get("reg_resolution", 1.0))
+        p.transformation_epsilon = float(get("reg_transformation_epsilon", 0.01))
+        p.max_iterations = int(get("reg_maximum_iterations", 64))
+        p.correspondence_randomness = int(get("reg_correspondence_randomness", 20))
+        return p
+    if method in _CPU_ONLY:
+        raise NotImplementedError(f"registration_method={method} stays on the reference's CPU engine (pcl / pclomp); "
+                                  "the MI355X backend implements FAST_GICP, FAST_VGICP and NDT_OMP")
+    if "NDT" not in method:                                                         # registrations.cpp:88-91
+        print(f"warning: unknown registration type({method})\n       : use NDT", file=sys.stderr)
+    p = L.default_params(L.HGS_NDT_OMP)                                             # registrations.cpp:93,101-120
+    p.resolution = float(get("reg_resolution", 0.5))
+    p.transformation_epsilon = float(get("reg_transformation_epsilon", 0.01))
+    p.max_iterations = int(get("reg_maximum_iterations", 64))
+    nn = str(get("reg_nn_search_method", "DIRECT7"))
+    if nn == "KDTREE":
+        raise NotImplementedError("reg_nn_search_method=KDTREE is not implemented on the device (DIRECT1 / DIRECT7 are)")
+    p.neighbor_search = L.HGS_DIRECT1 if nn == "DIRECT1" else L.HGS_DIRECT7
+    return p
+
+
+def select_registration_method(pnh, device_id: int = 0) -> RegistrationHIP:
+    p = params_from_rosparams(pnh)
+    p.device_id = device_id
+    # reg_num_threads (registrations.cpp:30,51,102) has no meaning on the device: parallelism is over points and candidates
+    return RegistrationHIP(p)

@@ -155,6 +155,17 @@ int hgs_profile_read(hgs_handle* h, double* ms, uint64_t* launches, int reset);
 /* Block until everything enqueued on the handle's stream has finished. */
 int hgs_synchronize(hgs_handle* h);
 
+/* ---- stage-level hooks (parity tests: one kernel stage at a caller-chosen pose; not used by the adapters) ------ */
+/* GICP covariances of the current target, original point order: out6[n][6] = xx,xy,xz,yy,yz,zz (float as stored). */
+int hgs_debug_target_covariances(hgs_handle* h, float* out6);
+/* One fused correspondence + linearisation pass at pose T (double, row-major 3x4): H[36] row-major, b[6], sum of
+ * errors, and per source point (original order) the original target index of its correspondence or -1. */
+int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, double* b6, double* err, int32_t* corr);
+/* Valid Gaussian cells of the NDT target (any order): linear key, grid coordinates, mean, inverse covariance, count. */
+int hgs_debug_ndt_cells(hgs_handle* h, int32_t cap, int32_t* ijk3, double* mean3, float* icov6, int32_t* npts, int32_t* n_cells);
+/* One NDT derivative pass at p = (tx,ty,tz,rx,ry,rz): score, gradient[6], Hessian[36]. */
+int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, double* g6, double* H36);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,468 @@
+// tests/emul/emul.cpp — TEST-ONLY host harness.  Compiles the HGS_HD per-item functions of
+// hdl_graph_slam_amd/csrc/{hgs_math,hgs_bvh,hgs_gicp,hgs_ndt}.h with g++ and drives them serially in the same
+// order the HIP kernels of hgs_kernels.hip do (one "thread" per point, 256-point tiles, tile-ordered sums).
+// Purpose: validate tree traversal, per-point arithmetic and the LM / Newton state machines against the oracle on
+// the CPU-only build box before the kernels run on an MI355X.  It is never part of the product library and is
+// not a fallback: hdl_graph_slam_amd/ does not reference it.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <unordered_map>
+#include <vector>
+
+#include "../../hdl_graph_slam_amd/csrc/hgs_gicp.h"
+#include "../../hdl_graph_slam_amd/csrc/hgs_ndt.h"
+#include "../../include/hgs_registration.h"
+
+using namespace hgs;
+
+struct ECloud {
+  std::vector<Float4> raw, pts, nodes, cov;
+  std::vector<int> corr;
+  int n_input = 0, nvalid = 0, P = 1;
+  float bbmin[3], bbmax[3];
+  BvhView view() const { return BvhView{nodes.data(), pts.data(), P, nvalid}; }
+};
+
+static bool finite3(const Float4& p) { return std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z); }
+
+static void build_cloud(ECloud& c, const float* xyz, int n, size_t stride_floats) {
+  c.n_input = n;
+  c.raw.resize(n);
+  for (int i = 0; i < n; i++) c.raw[i] = Float4{xyz[i * stride_floats], xyz[i * stride_floats + 1], xyz[i * stride_floats + 2], int_as_float_hd(i)};
+  for (int k = 0; k < 3; k++) c.bbmin[k] = INFINITY, c.bbmax[k] = -INFINITY;
+  c.nvalid = 0;
+  for (auto& p : c.raw)
+    if (finite3(p)) {
+      c.nvalid++;
+      c.bbmin[0] = fminf(c.bbmin[0], p.x), c.bbmin[1] = fminf(c.bbmin[1], p.y), c.bbmin[2] = fminf(c.bbmin[2], p.z);
+      c.bbmax[0] = fmaxf(c.bbmax[0], p.x), c.bbmax[1] = fmaxf(c.bbmax[1], p.y), c.bbmax[2] = fmaxf(c.bbmax[2], p.z);
+    }
+  c.P = 1;
+  while (c.P * kLeaf < n) c.P <<= 1;
+  // k_hilbert_keys
+  std::vector<uint64_t> keys(n);
+  std::vector<uint32_t> vals(n);
+  const float ext = fmaxf(c.bbmax[0] - c.bbmin[0], fmaxf(c.bbmax[1] - c.bbmin[1], c.bbmax[2] - c.bbmin[2]));
+  const float sc = ext > 0.f ? 65535.f / ext : 0.f;
+  for (int i = 0; i < n; i++) {
+    uint64_t code = 0xffffffffffffull;
+    const Float4 p = c.raw[i];
+    if (finite3(p)) {
+      const uint32_t qx = std::min(65535u, (uint32_t)((p.x - c.bbmin[0]) * sc));
+      const uint32_t qy = std::min(65535u, (uint32_t)((p.y - c.bbmin[1]) * sc));
+      const uint32_t qz = std::min(65535u, (uint32_t)((p.z - c.bbmin[2]) * sc));
+      code = hilbert48(qx, qy, qz);
+      if (code == 0xffffffffffffull) code--;
+    }
+    keys[i] = code;
+    vals[i] = i;
+  }
+  std::stable_sort(vals.begin(), vals.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+  // k_gather_sorted
+  c.pts.assign((size_t)c.P * kLeaf, Float4{INFINITY, INFINITY, INFINITY, int_as_float_hd(-1)});
+  for (int i = 0; i < c.nvalid; i++) c.pts[i] = c.raw[vals[i]];
+  // k_build_bottom / k_build_top
+  c.nodes.assign((size_t)4 * c.P, Float4{0, 0, 0, 0});
+  for (int leaf = 0; leaf < c.P; leaf++) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int l = 0; l < kLeaf; l++) {
+      const int idx = leaf * kLeaf + l;
+      if (idx < c.nvalid) {
+        const Float4 p = c.pts[idx];
+        mn[0] = fminf(mn[0], p.x), mn[1] = fminf(mn[1], p.y), mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
+      }
+    }
+    c.nodes[2 * (c.P + leaf)] = Float4{mn[0], mn[1], mn[2], 0};
+    c.nodes[2 * (c.P + leaf) + 1] = Float4{mx[0], mx[1], mx[2], 0};
+  }
+  for (int id = c.P - 1; id >= 1; id--) {
+    const Float4 a0 = c.nodes[4 * id], a1 = c.nodes[4 * id + 1], b0 = c.nodes[4 * id + 2], b1 = c.nodes[4 * id + 3];
+    c.nodes[2 * id] = Float4{fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0};
+    c.nodes[2 * id + 1] = Float4{fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0};
+  }
+  c.cov.clear();
+  c.corr.assign((size_t)c.P * kLeaf, -1);
+}
+
+template <int KMAX>
+static void knn_cov_t(ECloud& c, int k) {
+  c.cov.assign((size_t)2 * c.P * kLeaf, Float4{0, 0, 0, 0});
+  const BvhView tv = c.view();
+  for (int i = 0; i < c.nvalid; i++) {
+    const Float4 qp = c.pts[i];
+    const F3 q = {qp.x, qp.y, qp.z};
+    KnnList<KMAX> list;
+    bvh_knn<KMAX>(tv, q, k, list);
+    double s1[3] = {0, 0, 0};
+    Sym3 s2 = {0, 0, 0, 0, 0, 0};
+    int found = 0;
+    for (int j = 0; j < KMAX; j++)
+      if (list.pos[j] >= 0) {
+        const Float4 p = c.pts[list.pos[j]];
+        const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
+        s1[0] += dx, s1[1] += dy, s1[2] += dz;
+        s2.xx += dx * dx, s2.xy += dx * dy, s2.xz += dx * dz, s2.yy += dy * dy, s2.yz += dy * dz, s2.zz += dz * dz;
+        found++;
+      }
+    const Sym3 cv = gicp_regularized_cov(s1, s2, found, k);
+    c.cov[2 * i] = Float4{(float)cv.xx, (float)cv.xy, (float)cv.xz, (float)cv.yy};
+    c.cov[2 * i + 1] = Float4{(float)cv.yz, (float)cv.zz, 0, 0};
+  }
+}
+static void knn_cov(ECloud& c, int k) {
+  if (k <= 8) knn_cov_t<8>(c, k);
+  else if (k <= 16) knn_cov_t<16>(c, k);
+  else if (k <= 20) knn_cov_t<20>(c, k);
+  else knn_cov_t<32>(c, k);
+}
+static Sym3 load_cov(const std::vector<Float4>& cov, int i) {
+  const Float4 a = cov[2 * i], b = cov[2 * i + 1];
+  return sym3_from_floats(a.x, a.y, a.z, a.w, b.x, b.y);
+}
+
+static GicpConsts gicp_consts(const hgs_params& p) {
+  GicpConsts c;
+  c.max_corr2 = p.max_correspondence_distance * p.max_correspondence_distance;
+  c.search_bound2 = c.max_corr2 >= (double)FLT_MAX ? FLT_MAX : nextafterf((float)c.max_corr2, FLT_MAX);
+  c.rotation_eps = p.rotation_epsilon, c.translation_eps = p.transformation_epsilon;
+  c.lm_init_lambda_factor = p.lm_init_lambda_factor, c.lm_max_iterations = p.lm_max_iterations, c.max_iterations = p.max_iterations;
+  c.k_correspondences = p.correspondence_randomness;
+  return c;
+}
+
+// k_gicp_linearize over all tiles, partials summed in tile order (k_gicp_solve)
+static void gicp_linearize(ECloud& src, const ECloud& tgt, const Pose& T, const GicpConsts& c, double* acc_out) {
+  const int ntiles = (src.nvalid + 255) / 256;
+  std::vector<double> total(kAcc, 0.0);
+  const BvhView tv = tgt.view();
+  float Tf[12];
+  pose_to_float(T, Tf);
+  for (int tile = 0; tile < ntiles; tile++) {
+    double part[kAcc] = {0};
+    for (int t = 0; t < 256; t++) {
+      const int i = tile * 256 + t;
+      if (i >= src.nvalid) break;
+      double acc[kAcc] = {0};
+      const Float4 a = src.pts[i];
+      const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
+      float d2;
+      int orig;
+      int j = bvh_nn1(tv, q, c.search_bound2, &d2, &orig);
+      if (j >= 0 && !((double)d2 < c.max_corr2)) j = -1;
+      src.corr[i] = j;
+      if (j >= 0) {
+        const double R[9] = {T.m[0], T.m[1], T.m[2], T.m[4], T.m[5], T.m[6], T.m[8], T.m[9], T.m[10]};
+        const Sym3 M = gicp_mahalanobis(R, load_cov(src.cov, i), load_cov(tgt.cov, j));
+        const Float4 bp = tgt.pts[j];
+        acc[27] = gicp_point_terms<true>(T, M, a.x, a.y, a.z, bp.x, bp.y, bp.z, acc);
+      }
+      for (int k = 0; k < kAcc; k++) part[k] += acc[k];
+    }
+    for (int k = 0; k < kAcc; k++) total[k] += part[k];
+  }
+  for (int k = 0; k < kAcc; k++) acc_out[k] = total[k];
+}
+static double gicp_error(const ECloud& src, const ECloud& tgt, const Pose& T0, const Pose& Ti) {
+  double total = 0;
+  for (int i = 0; i < src.nvalid; i++) {
+    const int j = src.corr[i];
+    if (j < 0) continue;
+    const double R[9] = {T0.m[0], T0.m[1], T0.m[2], T0.m[4], T0.m[5], T0.m[6], T0.m[8], T0.m[9], T0.m[10]};
+    const Sym3 M = gicp_mahalanobis(R, load_cov(src.cov, i), load_cov(tgt.cov, j));
+    const Float4 a = src.pts[i], bp = tgt.pts[j];
+    total += gicp_point_terms<false>(Ti, M, a.x, a.y, a.z, bp.x, bp.y, bp.z, nullptr);
+  }
+  return total;
+}
+
+// ---- NDT target
+struct ENdt {
+  std::vector<int> hash_keys, hash_vals;
+  std::vector<NdtCellRec> cells;
+  NdtGrid grid;
+};
+static void ndt_build(ENdt& e, const ECloud& c, double resolution, int min_points) {
+  const float inv_leaf = 1.0f / (float)resolution;
+  NdtGrid& g = e.grid;
+  g.inv_leaf = inv_leaf;
+  long long div[3];
+  for (int k = 0; k < 3; k++) {
+    g.min_b[k] = (int)floorf(c.bbmin[k] * inv_leaf);
+    g.max_b[k] = (int)floorf(c.bbmax[k] * inv_leaf);
+    div[k] = (long long)g.max_b[k] - g.min_b[k] + 1;
+  }
+  g.div_mul[0] = 1, g.div_mul[1] = (int)div[0], g.div_mul[2] = (int)(div[0] * div[1]);
+  std::vector<std::pair<uint32_t, int>> kv;
+  for (int i = 0; i < c.n_input; i++) {
+    const Float4 p = c.raw[i];
+    if (!finite3(p)) continue;
+    const int cx = (int)floorf(p.x * inv_leaf) - g.min_b[0], cy = (int)floorf(p.y * inv_leaf) - g.min_b[1], cz = (int)floorf(p.z * inv_leaf) - g.min_b[2];
+    kv.push_back({(uint32_t)(cx * g.div_mul[0] + cy * g.div_mul[1] + cz * g.div_mul[2]), i});
+  }
+  std::stable_sort(kv.begin(), kv.end(), [](auto& a, auto& b) { return a.first < b.first; });
+  int cap = 64;
+  while (cap < 4 * (int)(c.n_input / std::max(1, min_points) + 1)) cap <<= 1;
+  e.hash_keys.assign(cap, -1);
+  e.hash_vals.assign(cap, -1);
+  e.cells.clear();
+  g.hash_mask = cap - 1;
+  for (size_t i = 0; i < kv.size();) {
+    size_t j = i;
+    double sum[3] = {0, 0, 0};
+    Sym3 sq = {0, 0, 0, 0, 0, 0};
+    int n = 0;
+    for (; j < kv.size() && kv[j].first == kv[i].first; j++) {
+      const Float4 p = c.raw[kv[j].second];
+      const double x = p.x, y = p.y, z = p.z;
+      sum[0] += x, sum[1] += y, sum[2] += z;
+      sq.xx += x * x, sq.xy += x * y, sq.xz += x * z, sq.yy += y * y, sq.yz += y * z, sq.zz += z * z;
+      n++;
+    }
+    double mean[3];
+    Sym3 icov;
+    if (ndt_finalize_cell(n, sum, sq, min_points, mean, &icov)) {
+      NdtCellRec rec;
+      rec.v0 = Float4{(float)icov.xx, (float)icov.xy, (float)icov.xz, (float)icov.yy};
+      rec.v1 = Float4{(float)icov.yz, (float)icov.zz, (float)n, int_as_float_hd((int)kv[i].first)};
+      rec.mean[0] = mean[0], rec.mean[1] = mean[1], rec.mean[2] = mean[2], rec.pad = 0.0;
+      const int slot_c = (int)e.cells.size();
+      e.cells.push_back(rec);
+      uint32_t slot = (ndt_hash((int)kv[i].first) >> 7) & (uint32_t)g.hash_mask;
+      while (e.hash_keys[slot] != -1) slot = (slot + 1) & (uint32_t)g.hash_mask;
+      e.hash_keys[slot] = (int)kv[i].first;
+      e.hash_vals[slot] = slot_c;
+    }
+    i = j;
+  }
+  g.hash_keys = e.hash_keys.data(), g.hash_vals = e.hash_vals.data(), g.cells = e.cells.data();
+}
+static void ndt_derivatives(const ECloud& src, const ENdt& e, const NdtAngles& ang, const NdtConsts& c, double* acc_out) {
+  const int ntiles = (src.n_input + 255) / 256;
+  std::vector<double> total(kAcc, 0.0);
+  const NdtGrid& g = e.grid;
+  for (int tile = 0; tile < ntiles; tile++) {
+    double part[kAcc] = {0};
+    for (int t = 0; t < 256; t++) {
+      const int i = tile * 256 + t;
+      if (i >= src.n_input) break;
+      const Float4 x = src.raw[i];
+      if (!finite3(x)) continue;
+      double acc[kAcc] = {0};
+      const F3 xt = transform_point_f(ang.T, x.x, x.y, x.z);
+      const int cx = (int)floorf(xt.x * g.inv_leaf), cy = (int)floorf(xt.y * g.inv_leaf), cz = (int)floorf(xt.z * g.inv_leaf);
+      NdtPointDeriv pd;
+      ndt_point_derivatives(ang, x.x, x.y, x.z, pd);
+      const int nn = c.search == 1 ? 1 : 7;
+      for (int o = 0; o < nn; o++) {
+        const int ox = (o == 1) - (o == 2), oy = (o == 3) - (o == 4), oz = (o == 5) - (o == 6);
+        const int ci = ndt_lookup(g, cx + ox, cy + oy, cz + oz);
+        if (ci < 0) continue;
+        const NdtCellRec rec = g.cells[ci];
+        const float icov[6] = {rec.v0.x, rec.v0.y, rec.v0.z, rec.v0.w, rec.v1.x, rec.v1.y};
+        ndt_cell_terms(c, pd, (float)((double)xt.x - rec.mean[0]), (float)((double)xt.y - rec.mean[1]), (float)((double)xt.z - rec.mean[2]), icov, acc);
+      }
+      for (int k = 0; k < kAcc; k++) part[k] += acc[k];
+    }
+    for (int k = 0; k < kAcc; k++) total[k] += part[k];
+  }
+  for (int k = 0; k < kAcc; k++) acc_out[k] = total[k];
+}
+static NdtConsts ndt_consts(const hgs_params& p) {
+  NdtConsts c;
+  const double c1 = 10.0 * (1 - p.ndt_outlier_ratio), c2 = p.ndt_outlier_ratio / std::pow(p.resolution, 3), d3 = -std::log(c2);
+  c.gauss_d1 = -std::log(c1 + c2) - d3;
+  c.gauss_d2 = -2 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / c.gauss_d1);
+  c.step_size = p.ndt_step_size, c.trans_eps = p.transformation_epsilon, c.max_iterations = p.max_iterations;
+  c.search = p.neighbor_search == HGS_DIRECT1 ? 1 : 2;
+  c.upstream_hd1_sign = p.ndt_upstream_hd1_sign, c.pad = 0;
+  return c;
+}
+
+struct EmulHandle {
+  hgs_params prm;
+  ECloud src, tgt;
+  ENdt ndt;
+  bool have_src = false, have_tgt = false;
+};
+
+extern "C" {
+
+EmulHandle* emul_create(const hgs_params* p) {
+  auto* h = new EmulHandle();
+  h->prm = *p;
+  return h;
+}
+void emul_destroy(EmulHandle* h) { delete h; }
+
+static void prep(EmulHandle* h, ECloud& c, const void* pts, size_t n, size_t stride, bool is_target) {
+  build_cloud(c, (const float*)pts, (int)n, stride / 4);
+  if (h->prm.method == HGS_FAST_GICP) knn_cov(c, h->prm.correspondence_randomness);
+  if (h->prm.method == HGS_NDT_OMP && is_target) ndt_build(h->ndt, c, h->prm.resolution, h->prm.ndt_min_points_per_voxel);
+}
+int emul_set_target(EmulHandle* h, const void* pts, size_t n, size_t stride) {
+  prep(h, h->tgt, pts, n, stride, true);
+  h->have_tgt = true;
+  return 0;
+}
+int emul_set_source(EmulHandle* h, const void* pts, size_t n, size_t stride) {
+  prep(h, h->src, pts, n, stride, false);
+  h->have_src = true;
+  return 0;
+}
+
+int emul_align(EmulHandle* h, const float* guess, hgs_result* out) {
+  if (h->prm.method == HGS_FAST_GICP) {
+    const GicpConsts c = gicp_consts(h->prm);
+    GicpState st;
+    gicp_state_init(st, guess);
+    long rounds = 0;
+    while (st.phase != GICP_DONE && rounds < 100000) {
+      if (st.phase == GICP_LINEARIZE) {
+        double acc[kAcc];
+        gicp_linearize(h->src, h->tgt, st.x0, c, acc);
+        gicp_after_linearize(st, acc, c);
+      }
+      if (st.phase == GICP_TRY) {
+        const double yi = gicp_error(h->src, h->tgt, st.x0, st.xi);
+        gicp_after_error(st, yi, c);
+      }
+      rounds++;
+    }
+    pose_to_colmajor_f(st.x0, out->final_transformation);
+    out->converged = st.converged, out->iterations = st.iterations, out->lm_tries = st.lm_tries_total, out->error = st.y0;
+  } else {
+    const NdtConsts c = ndt_consts(h->prm);
+    NdtState st;
+    NdtAngles ang;
+    ndt_state_init(st, guess);
+    ndt_angle_tables(st.p, c.upstream_hd1_sign, ang);
+    long rounds = 0;
+    while (st.phase != NDT_DONE && rounds < 100000) {
+      double acc[kAcc];
+      ndt_derivatives(h->src, h->ndt, ang, c, acc);
+      ndt_after_derivatives(st, acc, c);
+      if (getenv("HGS_EMUL_TRACE")) printf("emul it=%d p=%.6f %.6f %.6f %.6f %.6f %.6f score=%.6f a_t=%.6f\n", st.iterations, st.p[0], st.p[1], st.p[2], st.p[3], st.p[4], st.p[5], st.score, st.a_t);
+      if (st.phase != NDT_DONE) ndt_angle_tables(st.p, c.upstream_hd1_sign, ang);
+      rounds++;
+    }
+    pose_to_colmajor_f(st.final_T, out->final_transformation);
+    out->converged = st.converged, out->iterations = st.iterations, out->lm_tries = st.passes;
+    out->error = h->src.nvalid > 0 ? st.score / h->src.nvalid : 0.0;
+  }
+  out->fitness_score = std::numeric_limits<double>::quiet_NaN();
+  out->num_inliers = 0, out->candidate_id = 0, out->reserved = 0;
+  return 0;
+}
+
+int emul_fitness(EmulHandle* h, const float* T16, double max_range, double* score, uint32_t* ninl) {
+  float Tf[12];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) Tf[r * 4 + c] = T16[c * 4 + r];
+  const int ntiles = (h->src.nvalid + 255) / 256;
+  double s = 0, cnt = 0;
+  const BvhView tv = h->tgt.view();
+  for (int tile = 0; tile < ntiles; tile++) {
+    double ps = 0, pc = 0;
+    for (int t = 0; t < 256 && tile * 256 + t < h->src.nvalid; t++) {
+      const Float4 a = h->src.pts[tile * 256 + t];
+      const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
+      float d2;
+      int orig;
+      const int j = bvh_nn1(tv, q, FLT_MAX, &d2, &orig);
+      if (j >= 0 && (double)d2 <= max_range) ps += (double)d2, pc += 1.0;
+    }
+    s += ps, cnt += pc;
+  }
+  *ninl = (uint32_t)(cnt + 0.5);
+  *score = cnt > 0 ? s / cnt : std::numeric_limits<double>::max();
+  return 0;
+}
+
+int emul_nn_target(EmulHandle* h, const float* q, size_t nq, size_t stride, int32_t* idx, float* d2) {
+  const BvhView tv = h->tgt.view();
+  for (size_t i = 0; i < nq; i++) {
+    const float* f = (const float*)((const char*)q + i * stride);
+    int orig;
+    const int j = bvh_nn1(tv, F3{f[0], f[1], f[2]}, FLT_MAX, &d2[i], &orig);
+    idx[i] = j >= 0 ? orig : -1;
+  }
+  return 0;
+}
+
+// covariances of the target in ORIGINAL order: out[n][6]
+int emul_target_covariances(EmulHandle* h, float* out6) {
+  for (int i = 0; i < h->tgt.n_input * 6; i++) out6[i] = 0.f;
+  for (int i = 0; i < h->tgt.nvalid; i++) {
+    const int o = float_as_int_hd(h->tgt.pts[i].w);
+    const Float4 a = h->tgt.cov[2 * i], b = h->tgt.cov[2 * i + 1];
+    float* p = out6 + (size_t)o * 6;
+    p[0] = a.x, p[1] = a.y, p[2] = a.z, p[3] = a.w, p[4] = b.x, p[5] = b.y;
+  }
+  return 0;
+}
+
+int emul_gicp_linearize(EmulHandle* h, const double* T12, double* H36, double* b6, double* err, int32_t* corr_orig) {
+  Pose T;
+  for (int i = 0; i < 12; i++) T.m[i] = T12[i];
+  double acc[kAcc];
+  gicp_linearize(h->src, h->tgt, T, gicp_consts(h->prm), acc);
+  int k = 0;
+  for (int r = 0; r < 6; r++)
+    for (int c = r; c < 6; c++) H36[r * 6 + c] = H36[c * 6 + r] = acc[k++];
+  for (int i = 0; i < 6; i++) b6[i] = acc[21 + i];
+  *err = acc[27];
+  if (corr_orig) {
+    for (int i = 0; i < h->src.n_input; i++) corr_orig[i] = -1;
+    for (int i = 0; i < h->src.nvalid; i++) {
+      const int j = h->src.corr[i];
+      corr_orig[float_as_int_hd(h->src.pts[i].w)] = j >= 0 ? float_as_int_hd(h->tgt.pts[j].w) : -1;
+    }
+  }
+  return 0;
+}
+
+int emul_ndt_cells(EmulHandle* h, int cap, int32_t* key, double* mean3, float* icov6, int32_t* npts) {
+  const int n = (int)h->ndt.cells.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    const NdtCellRec& r = h->ndt.cells[i];
+    key[i] = float_as_int_hd(r.v1.w);
+    mean3[3 * i] = r.mean[0], mean3[3 * i + 1] = r.mean[1], mean3[3 * i + 2] = r.mean[2];
+    float* o = icov6 + 6 * i;
+    o[0] = r.v0.x, o[1] = r.v0.y, o[2] = r.v0.z, o[3] = r.v0.w, o[4] = r.v1.x, o[5] = r.v1.y;
+    npts[i] = (int)r.v1.z;
+  }
+  return n;
+}
+int emul_ndt_grid(EmulHandle* h, int32_t* min_b, int32_t* div_mul) {
+  for (int k = 0; k < 3; k++) min_b[k] = h->ndt.grid.min_b[k], div_mul[k] = h->ndt.grid.div_mul[k];
+  return 0;
+}
+int emul_ndt_derivatives(EmulHandle* h, const double* p6, double* score, double* g6, double* H36) {
+  const NdtConsts c = ndt_consts(h->prm);
+  NdtAngles ang;
+  ndt_angle_tables(p6, c.upstream_hd1_sign, ang);
+  double acc[kAcc];
+  ndt_derivatives(h->src, h->ndt, ang, c, acc);
+  int k = 0;
+  for (int r = 0; r < 6; r++)
+    for (int cc = r; cc < 6; cc++) H36[r * 6 + cc] = H36[cc * 6 + r] = acc[k++];
+  for (int i = 0; i < 6; i++) g6[i] = acc[21 + i];
+  *score = acc[27];
+  return 0;
+}
+
+// tree statistics for tuning: average nodes + leaves visited by a 1-NN query is not measurable through the
+// product path; this returns the tree's sorted point order so tests can check it is a permutation.
+int emul_sorted_order(EmulHandle* h, int target, int32_t* out) {
+  const ECloud& c = target ? h->tgt : h->src;
+  for (int i = 0; i < c.nvalid; i++) out[i] = float_as_int_hd(c.pts[i].w);
+  return c.nvalid;
+}
+
+}  // extern "C"

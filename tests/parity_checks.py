@@ -1,0 +1,94 @@
+"""Shared parity assertions: an engine under test (the HIP path through the C-ABI on a GPU, or the host execution of
+the same device functions in tests/emul) against the CPU oracle on identical inputs.
+
+Tolerances (north_star): final SE(3) pose within 1e-3 m / 1e-3 rad of the oracle; index / integer work bit-exact."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle as O
+from hdl_graph_slam_amd import synth
+
+POSE_TOL_M = 1e-3
+POSE_TOL_RAD = 1e-3
+
+
+def make_oracle(params_like) -> O.OracleRegistration:
+    p = O.HgsParams()
+    for name, _ in O.HgsParams._fields_:
+        setattr(p, name, getattr(params_like, name))
+    return O.OracleRegistration(p)
+
+
+def load_pair(engine, oracle, tgt, src):
+    for r in (engine, oracle):
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+
+
+def check_nn(engine, oracle, queries):
+    """Exact nearest neighbour: indices and float distances bit-identical to the oracle's kd-tree."""
+    ie, de = engine.nn_target(queries)
+    io, do = oracle.nn_target(queries)
+    assert np.array_equal(ie, io), f"{(ie != io).sum()} / {len(io)} nearest-neighbour indices differ"
+    assert np.array_equal(de, do)
+
+
+def check_covariances(engine, tgt, k=20):
+    got = engine.target_covariances(len(tgt)).astype(np.float64)
+    ref = O.covariances(tgt, k)
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    rel = np.abs(got - ref) / scale
+    # float storage (6e-8) + different summation order
+    assert rel.max() < 5e-6, f"covariance mismatch: max rel {rel.max():.3e}"
+
+
+def check_gicp_linearize(engine, oracle, T):
+    He, be, ee, ce = engine.gicp_linearize(T)
+    Ho, bo, eo, co = oracle.gicp_linearize(T)
+    assert np.array_equal(ce, co), f"{(ce != co).sum()} correspondences differ"
+    assert np.abs(He - Ho).max() <= 2e-5 * np.abs(Ho).max()
+    assert np.abs(be - bo).max() <= 2e-5 * max(np.abs(bo).max(), 1e-9 * np.abs(Ho).max())
+    assert abs(ee - eo) <= 1e-6 * abs(eo)
+
+
+def check_align(engine, oracle, guess, tol_m=POSE_TOL_M, tol_rad=POSE_TOL_RAD, same_iterations=True):
+    re = engine.align(guess)
+    ro = oracle.align(guess)
+    dt, dr = synth.pose_error(re.matrix(), ro.matrix())
+    assert dt <= tol_m and dr <= tol_rad, f"pose differs from the oracle by {dt:.3e} m / {dr:.3e} rad"
+    assert bool(re.converged) == bool(ro.converged)
+    if same_iterations:
+        assert re.iterations == ro.iterations and re.lm_tries == ro.lm_tries, (re.iterations, ro.iterations, re.lm_tries, ro.lm_tries)
+    return re, ro
+
+
+def check_fitness(engine, oracle, T, max_ranges=(np.finfo(np.float64).max, 4.0, 0.25, 1e-12)):
+    for mr in max_ranges:
+        fe = engine.getFitnessScore(mr, T=T)
+        fo = oracle.getFitnessScore(mr, T=T)
+        assert engine.last_num_inliers == oracle.last_num_inliers, (mr, engine.last_num_inliers, oracle.last_num_inliers)
+        if oracle.last_num_inliers == 0:
+            assert fe == fo == np.finfo(np.float64).max
+        else:
+            assert abs(fe - fo) <= 1e-9 * abs(fo), (mr, fe, fo)
+
+
+def check_ndt_cells(engine, oracle):
+    ie, me, ce, ne = engine.ndt_cells()
+    io, mo, co, no = oracle.ndt_cells()
+    assert len(ie) == len(io), (len(ie), len(io))
+    key = {tuple(k): i for i, k in enumerate(io)}
+    idx = np.array([key[tuple(k)] for k in ie])
+    assert len(set(idx.tolist())) == len(idx)
+    assert np.array_equal(ne, no[idx])
+    assert np.abs(me - mo[idx]).max() < 1e-9
+    assert (np.abs(ce - co[idx]).max(axis=1) / np.abs(co[idx]).max(axis=1)).max() < 2e-6
+
+
+def check_ndt_derivatives(engine, oracle, p6, rel=2e-5):
+    se, ge, He = engine.ndt_derivatives(p6)
+    so, go, Ho = oracle.ndt_derivatives(p6)
+    assert abs(se - so) <= rel * abs(so)
+    assert np.abs(ge - go).max() <= rel * np.abs(go).max()
+    assert np.abs(He - Ho).max() <= rel * np.abs(Ho).max()
