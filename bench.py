@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — registrations/sec of the MI355X scan-matching backend on BASELINE.json's metric.
+
+Workload (config.workload): the loop-closure batch of LoopDetector::matching (include/hdl_graph_slam/loop_detector.hpp:117-171)
+on 64-beam ~120 k-point keyframes: per step every rank registers `--candidates` candidate keyframes (cold: search index +
+20-NN covariances are recomputed for the target and every candidate, as the reference does per setInputSource) against one
+query keyframe with FAST_GICP at the launch-file parameters (launch/hdl_graph_slam.launch:73-82,127-136: eps 0.01,
+max_iterations 64, max_correspondence_distance 2.5, k 20) and evaluates getFitnessScore for each.  Inputs are resident in HBM
+before the timed region.  N > 1: candidates are sharded over the ranks (weak scaling: per-GPU work fixed) and the per-candidate
+records are all-gathered over RCCL once per step (the path's only exchange step).
+
+One JSON line on rank 0:  value = registrations/sec over all ranks (whole job)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES = {  # algorithmic bytes per unit of work
+    "covariance": ("k_knn_cov", 360.0),    # per point (16 query + 20*16 neighbours + 24 covariance out)
+    "linearize": ("k_gicp_linearize", 84.0),  # per source point per linearisation
+    "error": ("k_gicp_error", 84.0),       # per source point per LM trial
+    "fitness": ("k_fitness", 32.0),        # per source point
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--candidates", type=int, default=16, help="candidate keyframes per GPU per step")
+    ap.add_argument("--sensor", default="HDL-64E")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct ray-cast scans behind the candidates")
+    ap.add_argument("--method", default="FAST_GICP", choices=["FAST_GICP", "NDT_OMP"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=3, help="candidates registered by the CPU oracle for cpu_baseline")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from hdl_graph_slam_amd import synth, workloads, _lib as L
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    from hdl_graph_slam_amd.registration import select_best
+    from hdl_graph_slam_amd.distributed import CandidateShard
+
+    pnh = {"registration_method": args.method}
+    if args.method == "NDT_OMP":
+        pnh["reg_resolution"] = 1.0   # launch files use 1.0 (factory default 0.5)
+    B = args.candidates
+    # every rank holds the query keyframe (replicated target) and its own shard of the N*B candidates
+    wl = workloads.make_loop_closure_set(args.sensor, scene_seed=0, n_candidates=B, n_distinct=min(args.distinct, B))
+    rng = np.random.default_rng(100 + rank)
+    if rank > 0:  # different guesses per rank so that the shards are not identical problems
+        for g in wl.guesses:
+            g[:3, 3] += rng.normal(0, 0.05, 3).astype(np.float32)
+            g[2, 3] = 0.0
+
+    reg = select_registration_method(pnh, device_id=local_rank)
+    d_target = reg.upload(wl.target)
+    d_cands = [reg.upload(c) for c in wl.candidates]
+    n_pts = [len(c) for c in wl.candidates]
+    shard = CandidateShard(rank, world, device=torch.device("cuda", local_rank)) if world > 1 else None
+
+    def step():
+        d_target.invalidate()
+        for c in d_cands:
+            c.invalidate()
+        reg.setInputTarget(d_target)
+        rec, best = reg.loop_match_batch(d_cands, wl.guesses, L.DBL_MAX)
+        if shard is not None:
+            rec["candidate_id"] = np.arange(rank, world * B, world, dtype=np.int32)
+            allrec = shard.gather_records(rec, world * B)
+            best = select_best(allrec)
+        return rec, best
+
+    def barrier():
+        reg.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec, best = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- accuracy of the timed results (rank-local): vs ground truth
+    et = [synth.pose_error(np.array(r["final_transformation"]).reshape(4, 4).T, Tg) for r, Tg in zip(rec, wl.T_gt)]
+    rmse_t = float(np.sqrt(np.mean([e[0] ** 2 for e in et])))
+    rmse_r = float(np.sqrt(np.mean([e[1] ** 2 for e in et])))
+
+    # ---- roofline of the dominant kernel: HIP events on the handle's stream around every launch of each stage
+    reg.profile_enable(True)
+    reg.profile_read(reset=True)
+    prof_steps = 2
+    for _ in range(prof_steps):
+        rec_p, _ = step()
+    prof = reg.profile_read(reset=True)
+    reg.profile_enable(False)
+    total_pts = sum(n_pts) + len(wl.target)
+    units = {
+        "covariance": prof_steps * total_pts,
+        "linearize": prof_steps * float(np.sum(rec_p["iterations"].astype(np.float64) * np.array(n_pts))),
+        "error": prof_steps * float(np.sum(rec_p["lm_tries"].astype(np.float64) * np.array(n_pts))),
+        "fitness": prof_steps * sum(n_pts),
+    }
+    if args.method == "NDT_OMP":
+        ALG_BYTES["linearize"] = ("k_ndt_derivatives", 296.0)
+        units["linearize"] = prof_steps * float(np.sum(rec_p["lm_tries"].astype(np.float64) * np.array(n_pts)))
+        units["covariance"] = units["error"] = 0.0
+    dom = max((s for s in ALG_BYTES if prof[s][1] > 0), key=lambda s: prof[s][0])
+    ms, launches = prof[dom]
+    kname, bytes_per_unit = ALG_BYTES[dom]
+    achieved = units[dom] * bytes_per_unit / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches": launches,
+                "algorithmic_bytes_per_launch": round(units[dom] * bytes_per_unit / max(launches, 1), 1),
+                "stage_ms_per_step": {s: round(prof[s][0] / prof_steps, 3) for s in prof}}
+
+    # ---- CPU baseline: the oracle (port of fast_gicp / ndt_omp, OpenMP over points) on a bounded sample, rank 0, N == 1
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        p = O.HgsParams()
+        for name, _ in O.HgsParams._fields_:
+            setattr(p, name, getattr(reg.params, name))
+        ncores = O.set_num_threads(os.cpu_count() or 1)
+        o = O.OracleRegistration(p)
+        o.setInputTarget(wl.target)   # target structures are built once per batch in the reference too
+        o.setInputSource(wl.candidates[0])
+        o.align(wl.guesses[0])        # warm-up (first-touch, thread pool, target covariances)
+        k = min(args.cpu_sample, B)
+        tc = time.perf_counter()
+        dpose = []
+        for i in range(k):
+            o.setInputSource(wl.candidates[i])
+            ro = o.align(wl.guesses[i])
+            o.getFitnessScore()
+            dpose.append(synth.pose_error(np.array(rec[i]["final_transformation"]).reshape(4, 4).T, ro.matrix()))
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": round(k / tcpu, 4), "unit": "registrations/sec", "cores": ncores, "kind": "port",
+               "sample": f"{k} of the {B} candidate registrations (setInputSource + align + getFitnessScore), target structures prebuilt",
+               "max_pose_diff_vs_gpu_m": float(max(d[0] for d in dpose)), "max_pose_diff_vs_gpu_rad": float(max(d[1] for d in dpose))}
+
+    if rank == 0:
+        regs = world * B * args.steps
+        out = {
+            "metric": "registrations/sec (64-beam ~120k-pt pair), loop-closure batch", "value": round(regs / dt, 3), "unit": "registrations/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.method == "FAST_GICP" else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"loop-closure batch: {B} candidate keyframes/GPU x {args.sensor} (~{int(np.mean(n_pts))} pts) vs 1 query keyframe, "
+                                   f"{args.method} + getFitnessScore, cold (index + covariances rebuilt every step)",
+                       "candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": args.method,
+                       "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU"},
+            "pose_rmse_vs_ground_truth": {"translation_m": round(rmse_t, 5), "rotation_rad": round(rmse_r, 6)},
+            "converged": int(np.sum(rec["converged"])), "mean_iterations": float(np.mean(rec["iterations"])), "best_candidate": int(best),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    reg.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ from .registration import RegistrationHIP, DeviceCloud, select_best
 from .registrations import select_registration_method
 
 
-@dataclasses.dataclass
+@dataclasses.dataclass(eq=False)
 class KeyFrame:
     """The fields of hdl_graph_slam::KeyFrame (include/hdl_graph_slam/keyframe.hpp:24-52) the loop detector reads."""
     cloud: np.ndarray                 # PointXYZI records
@@ -29,7 +29,7 @@ class KeyFrame:
     device_cloud: Optional[DeviceCloud] = None   # resident copy (uploaded once, reused for every later detection)
 
 
-@dataclasses.dataclass
+@dataclasses.dataclass(eq=False)
 class Loop:
     key1: KeyFrame         # new keyframe (loop end)
     key2: KeyFrame         # matched candidate (loop begin)

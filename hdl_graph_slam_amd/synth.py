@@ -245,8 +245,11 @@ def transform_cloud(cloud: np.ndarray, T: np.ndarray) -> np.ndarray:
 def pose_error(T_a: np.ndarray, T_b: np.ndarray):
     """(translation error [m], rotation error [rad]) between two 4x4 poses."""
     D = np.linalg.inv(np.asarray(T_a, dtype=np.float64)) @ np.asarray(T_b, dtype=np.float64)
-    c = np.clip((np.trace(D[:3, :3]) - 1.0) / 2.0, -1.0, 1.0)
-    return float(np.linalg.norm(D[:3, 3])), float(np.arccos(c))
+    # rotation angle from the skew part (well conditioned near 0, unlike arccos of the trace of float32 matrices)
+    R = D[:3, :3]
+    s = 0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    c = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
+    return float(np.linalg.norm(D[:3, 3])), float(np.arctan2(s, c))
 
 
 def make_dense_pair(scene_seed: int, n_points: int, extent: float = 60.0):

@@ -1,0 +1,55 @@
+"""Synthetic workloads for BASELINE.json's configs built on hdl_graph_slam_amd.synth."""
+from __future__ import annotations
+
+import dataclasses
+from typing import List
+
+import numpy as np
+
+from . import synth
+
+
+@dataclasses.dataclass
+class LoopClosureSet:
+    target: np.ndarray                # PointXYZI records: the new keyframe (loop_detector.hpp:122)
+    candidates: List[np.ndarray]      # PointXYZI records: candidate keyframes (loop_detector.hpp:135)
+    T_gt: List[np.ndarray]            # ground-truth candidate -> target transforms (4x4 float64)
+    guesses: List[np.ndarray]         # initial guesses: GT + noise, z forced to 0 (loop_detector.hpp:137-142)
+
+
+def make_loop_closure_set(sensor: str, scene_seed: int, n_candidates: int, n_distinct: int = 8, downsample: float | None = None,
+                          guess_noise=(0.3, 1.0), spread: float = 4.0) -> LoopClosureSet:
+    """1 query keyframe + n_candidates candidate keyframes (config 4).
+
+    `n_distinct` scans are ray-cast at poses within `spread` metres of the query (candidates pass the reference's
+    distance gate, launch/hdl_graph_slam.launch:121); every candidate is one of those scans expressed in its own randomly
+    displaced sensor frame, so each has a distinct, known ground-truth pose relative to the query."""
+    rng = np.random.default_rng(7000 + scene_seed)
+    scene = synth.make_scene(scene_seed)
+    pose_t = synth.pose_matrix([0.0, 0.0, 0.0], [0.0, 0.0, 0.0])
+    target = synth.scan(scene, sensor, pose_t, 1000 + scene_seed)
+    if downsample:
+        target = synth.voxel_downsample(target, downsample)
+    scans, poses = [], []
+    for j in range(n_distinct):
+        xy = rng.uniform(-spread, spread, 2)
+        xy[1] *= 0.3   # stay inside the free corridor of the scene
+        pose = synth.pose_matrix([xy[0], xy[1], 0.0], np.deg2rad([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-8, 8)]))
+        sc = synth.scan(scene, sensor, pose, 3000 + 17 * scene_seed + j)
+        if downsample:
+            sc = synth.voxel_downsample(sc, downsample)
+        scans.append(sc)
+        poses.append(pose)
+    cands, T_gt, guesses = [], [], []
+    for c in range(n_candidates):
+        j = c % n_distinct
+        D = synth.pose_matrix(rng.uniform(-1.0, 1.0, 3) * [1.0, 1.0, 0.05], np.deg2rad(rng.uniform(-1.0, 1.0, 3) * [1.0, 1.0, 10.0]))
+        cloud = synth.transform_cloud(scans[j], np.linalg.inv(D)) if c >= n_distinct else scans[j]
+        Tg = np.linalg.inv(pose_t) @ poses[j] @ (D if c >= n_distinct else np.eye(4))
+        noise = synth.pose_matrix(rng.normal(0, guess_noise[0] / np.sqrt(3), 3), np.deg2rad(rng.normal(0, guess_noise[1] / np.sqrt(3), 3)))
+        g = (Tg @ noise).astype(np.float32)
+        g[2, 3] = 0.0
+        cands.append(cloud)
+        T_gt.append(Tg)
+        guesses.append(g)
+    return LoopClosureSet(target, cands, T_gt, guesses)

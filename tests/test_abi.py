@@ -1,0 +1,92 @@
+"""The C-ABI library: builds, loads, exports every symbol include/hgs_registration.h declares, fails loudly without a
+GPU, and its pure-host helper (the loop-closure selection rule) follows loop_detector.hpp:146-153."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from hdl_graph_slam_amd import build
+    build.build_lib()
+    from hdl_graph_slam_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def test_every_declared_symbol_is_exported(L):
+    hdr = open(os.path.join(ROOT, "include", "hgs_registration.h")).read()
+    declared = set(re.findall(r"^\s*(?:const char\*|int|size_t)\s+(hgs_[a-z0-9_]+)\s*\(", hdr, re.M))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    lib = L.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hgs_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(L):
+    import oracle as O
+    import subprocess
+    import tempfile
+    src = '#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu\\n", sizeof(hgs_params), sizeof(hgs_result));return 0;}\n' % os.path.join(
+        ROOT, "include", "hgs_registration.h")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "sz.c"), "w").write(src)          # the header is plain C
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", os.path.join(d, "sz.c"), "-o", os.path.join(d, "sz")], check=True)
+        sizes = [int(v) for v in subprocess.run([os.path.join(d, "sz")], capture_output=True, text=True, check=True).stdout.split()]
+    assert C.sizeof(L.HgsParams) == C.sizeof(O.HgsParams) == sizes[0]
+    assert C.sizeof(L.HgsResult) == C.sizeof(O.HgsResult) == sizes[1] == L.RESULT_DTYPE.itemsize
+
+
+def test_params_default_are_the_factory_defaults(L):
+    import oracle as O
+    for m in (L.HGS_FAST_GICP, L.HGS_FAST_VGICP, L.HGS_NDT_OMP):
+        a, b = L.default_params(m), O.default_params(m)
+        for name, _ in L.HgsParams._fields_:
+            assert getattr(a, name) == getattr(b, name), (m, name)
+    assert L.lib().hgs_params_default(7, C.byref(L.HgsParams())) != 0
+
+
+def test_rosparam_mapping_follows_registrations_cpp(L):
+    from hdl_graph_slam_amd.registrations import params_from_rosparams
+    p = params_from_rosparams({})                                    # default: NDT_OMP, resolution 0.5, DIRECT7
+    assert (p.method, p.resolution, p.neighbor_search, p.transformation_epsilon, p.max_iterations) == (L.HGS_NDT_OMP, 0.5, L.HGS_DIRECT7, 0.01, 64)
+    p = params_from_rosparams({"registration_method": "FAST_GICP", "reg_max_correspondence_distance": 2.0, "reg_transformation_epsilon": 0.1})
+    assert (p.method, p.max_correspondence_distance, p.transformation_epsilon, p.correspondence_randomness) == (L.HGS_FAST_GICP, 2.0, 0.1, 20)
+    p = params_from_rosparams({"registration_method": "NDT_OMP", "reg_nn_search_method": "DIRECT1", "reg_resolution": 1.0})
+    assert (p.neighbor_search, p.resolution) == (L.HGS_DIRECT1, 1.0)
+    p = params_from_rosparams({"registration_method": "bogus"})      # unknown -> NDT with a warning (registrations.cpp:88-91)
+    assert p.method == L.HGS_NDT_OMP
+    with pytest.raises(NotImplementedError):
+        params_from_rosparams({"registration_method": "GICP_OMP"})
+    # stale un-prefixed keys of launch/hdl_graph_slam_imu.launch:70-77 are ignored -> factory defaults
+    p = params_from_rosparams({"registration_method": "NDT_OMP", "ndt_resolution": 2.0, "transformation_epsilon": 0.5})
+    assert (p.resolution, p.transformation_epsilon) == (0.5, 0.01)
+
+
+def test_create_fails_loudly_without_a_gpu(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from hdl_graph_slam_amd.registration import RegistrationHIP, HgsError
+    with pytest.raises(HgsError, match="no usable HIP device"):
+        RegistrationHIP(L.default_params(L.HGS_FAST_GICP))
+
+
+def test_select_best_is_the_sequential_rule(L):
+    from hdl_graph_slam_amd.registration import select_best
+    rec = np.zeros(6, dtype=L.RESULT_DTYPE)
+    rec["converged"] = [1, 1, 0, 1, 1, 1]
+    rec["fitness_score"] = [0.9, 0.4, 0.1, 0.4, 0.7, np.nan]
+    assert select_best(rec) == 3               # ties replace: the LAST minimal converged candidate wins; NaN never wins
+    rec["converged"] = 0
+    assert select_best(rec) == -1
+    assert select_best(rec[:0]) == -1
+    rec["converged"] = 1
+    rec["fitness_score"] = np.finfo(np.float64).max   # score == DBL_MAX is not > best_score: accepted (loop_detector.hpp:147)
+    assert select_best(rec) == 5
