@@ -120,7 +120,7 @@ def cloud_args(cloud: np.ndarray):
     cloud = np.ascontiguousarray(cloud, dtype=np.float32)
     if cloud.ndim != 2 or cloud.shape[1] < 3:
         raise ValueError("expected [n, >=3] float32 or PointXYZI records")
-    return cloud, cloud.shape[0], cloud.strides[0]
+    return cloud, cloud.shape[0], cloud.shape[1] * 4  # (numpy reports stride 0 for empty arrays)
 
 
 def colmajor16(T) -> np.ndarray:

@@ -159,7 +159,7 @@ HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx
 #pragma unroll
   for (int s = 0; s < 3; s++) qC[s] = qx * C[0][s] + qy * C[1][s] + qz * C[2][s];
   const float qCq = qC[0] * qx + qC[1] * qy + qC[2] * qz;
-  float e = expf(-d2 * qCq * 0.5f);
+  float e = (float)exp((double)(-d2 * qCq * 0.5f));  // double exp rounded once: identical on CPU and GPU libm
   const float score_inc = -d1 * e;
   e = d2 * e;
   if (e > 1.f || e < 0.f || e != e) return;

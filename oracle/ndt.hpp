@@ -297,7 +297,8 @@ public:
         float qC[3];  // q^T C^-1 (row)
         for (int s = 0; s < 3; s++) qC[s] = q[0] * ci3[0][s] + q[1] * ci3[1][s] + q[2] * ci3[2][s];
         const float qCq = qC[0] * q[0] + qC[1] * q[1] + qC[2] * q[2];
-        float e_x_cov_x = std::exp(-d2 * qCq * 0.5f);
+        // upstream: float exp(); evaluated in double and rounded once so that CPU and GPU libm agree bit-for-bit
+        float e_x_cov_x = (float)std::exp((double)(-d2 * qCq * 0.5f));
         const float score_inc = -d1 * e_x_cov_x;
         e_x_cov_x = d2 * e_x_cov_x;
         if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;

@@ -119,7 +119,7 @@ def _cloud_args(cloud: np.ndarray):
     if cloud.dtype.fields is not None:
         return cloud, len(cloud), cloud.dtype.itemsize
     cloud = np.ascontiguousarray(cloud, dtype=np.float32)
-    return cloud, cloud.shape[0], cloud.strides[0]
+    return cloud, cloud.shape[0], cloud.shape[1] * 4
 
 
 def colmajor16(T: np.ndarray):

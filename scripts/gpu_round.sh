@@ -7,8 +7,9 @@ cd "${GRAFT_REPO_ROOT:-.}"
 echo "== rocm-smi" > gpurun_out/env.log; rocm-smi --showproductname 2>&1 | head -20 >> gpurun_out/env.log; nproc >> gpurun_out/env.log; lscpu | grep "Model name" >> gpurun_out/env.log
 echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" | tee -a gpurun_out/smoke.log; tail -5 gpurun_out/smoke.log
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout 400 --timeout-method=thread -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/pytest_gpu.log; tail -40 gpurun_out/pytest_gpu.log
+if [ -n "${DIAG:-}" ]; then echo "== diag"; timeout 1200 python scripts/gpu_diag.py $DIAG > gpurun_out/diag.log 2>&1; echo "diag exit $?"; cat gpurun_out/diag.log | tail -40; fi
 echo "== bench"; timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.log 2>&1; echo "bench exit $?" | tee -a gpurun_out/bench.log; tail -3 gpurun_out/bench.log
 if [ "${DO_PROF:-1}" = "1" ]; then
-  echo "== rocprofv3"; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > "$OLDPWD/gpurun_out/prof.log" 2>&1); echo "prof exit $?"
+  echo "== rocprofv3"; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > "$OLDPWD/gpurun_out/prof.log" 2>&1); echo "prof exit $?"
   find gpurun_out/prof -name "*kernel_stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
 fi

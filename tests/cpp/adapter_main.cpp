@@ -1,0 +1,63 @@
+// TEST ONLY — drives adapters/registration_hip.hpp the way the reference's callers drive a pcl::Registration:
+//   first frame:  setInputTarget(keyframe)                    apps/scan_matching_odometry_nodelet.cpp:166-174
+//   every frame:  setInputSource(filtered); align(*aligned, guess); hasConverged(); getFinalTransformation()   :176-221
+// Usage: adapter_main <method 0|2> <target.bin> <source.bin>   (raw PointXYZI records); prints the final transform.
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <stdexcept>
+#include <pcl/point_types.h>
+#include "../../adapters/registration_hip.hpp"
+
+using PointT = pcl::PointXYZI;
+
+static pcl::PointCloud<PointT>::Ptr load(const char* path) {
+  auto c = std::make_shared<pcl::PointCloud<PointT>>();
+  FILE* f = std::fopen(path, "rb");
+  if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+  PointT p;
+  while (std::fread(&p, sizeof(PointT), 1, f) == 1) c->points.push_back(p);
+  std::fclose(f);
+  return c;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    std::fprintf(stderr, "usage: %s method target.bin source.bin\n", argv[0]);
+    return 2;
+  }
+  try {
+    // what the new factory branch does: construct + setters from the reg_* rosparams
+    pcl::Registration<PointT, PointT>::Ptr registration;
+    {
+      auto reg = std::make_shared<hgs_hip::RegistrationHIP<PointT, PointT>>(std::atoi(argv[1]));
+      reg->setTransformationEpsilon(0.01);
+      reg->setMaximumIterations(64);
+      if (std::atoi(argv[1]) == HGS_FAST_GICP) {
+        reg->setMaxCorrespondenceDistance(2.5);
+        reg->setCorrespondenceRandomness(20);
+      } else {
+        reg->setResolution(1.0);
+        reg->setNeighborhoodSearchMethod(HGS_DIRECT7);
+      }
+      registration = reg;
+    }
+    auto keyframe = load(argv[2]);
+    auto filtered = load(argv[3]);
+    registration->setInputTarget(keyframe);
+    registration->setInputSource(filtered);
+    pcl::PointCloud<PointT> aligned;
+    registration->align(aligned, pcl::MockMatrix4f::Identity());
+    const auto T = registration->getFinalTransformation();
+    std::printf("converged %d\n", (int)registration->hasConverged());
+    for (int i = 0; i < 16; i++) std::printf("%.9g ", T.data()[i]);
+    std::printf("\n");
+    auto* hip = dynamic_cast<hgs_hip::RegistrationHIP<PointT, PointT>*>(registration.get());
+    std::printf("fitness %.12g\n", hip->fitnessScoreHIP());
+    std::printf("aligned0 %.6f %.6f %.6f n %zu\n", aligned.points[0].x, aligned.points[0].y, aligned.points[0].z, aligned.size());
+  } catch (const std::exception& e) {
+    std::printf("exception: %s\n", e.what());
+    return 3;
+  }
+  return 0;
+}

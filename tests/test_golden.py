@@ -1,0 +1,78 @@
+"""Known-answer tests against tests/golden/vlp16_pair_seed1.npz (made by tests/golden/make_golden.py; the reference has no
+golden vectors of its own — "parity unpinned", these are the pins this repo creates).
+CPU: the oracle still reproduces them.  GPU (-m gpu): the HIP path reproduces them through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from hdl_graph_slam_amd import synth
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vlp16_pair_seed1.npz"))
+
+
+def _check_engine(make, tol_pose, rel_stage, exact_counts=True):
+    e = make(O.default_params(O.HGS_FAST_GICP))
+    e.setInputTarget(G["target_xyz"])
+    e.setInputSource(G["source_xyz"])
+    idx, d2 = e.nn_target(G["nn_queries"])
+    assert np.array_equal(idx, G["nn_idx"]) and np.array_equal(d2, G["nn_d2"])
+    H, b, err, corr = e.gicp_linearize(np.eye(4))
+    assert np.array_equal(corr, G["gicp_corr_identity"])
+    assert np.abs(H - G["gicp_H_identity"]).max() <= rel_stage * np.abs(G["gicp_H_identity"]).max()
+    assert np.abs(b - G["gicp_b_identity"]).max() <= rel_stage * np.abs(G["gicp_b_identity"]).max()
+    assert abs(err - G["gicp_err_identity"]) <= rel_stage * G["gicp_err_identity"]
+    r = e.align(np.eye(4))
+    dt, dr = synth.pose_error(r.matrix(), G["gicp_final"])
+    assert dt <= tol_pose and dr <= tol_pose
+    assert r.converged == G["gicp_converged"]
+    if exact_counts:
+        assert r.iterations == G["gicp_iterations"] and r.lm_tries == G["gicp_lm_tries"]
+    for mr, (score, n) in zip(G["fitness_ranges"], G["fitness"]):
+        s = e.getFitnessScore(mr, T=G["gicp_final"])
+        assert e.last_num_inliers == int(n) and abs(s - score) <= 1e-9 * score
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution = 1.0
+    n = make(p)
+    n.setInputTarget(G["target_xyz"])
+    n.setInputSource(G["source_xyz"])
+    ijk, mean, icov, npts = n.ndt_cells()
+    assert len(ijk) == len(G["ndt_cells_ijk"])
+    key = {tuple(k): i for i, k in enumerate(G["ndt_cells_ijk"])}
+    order = np.array([key[tuple(k)] for k in ijk])
+    assert np.array_equal(npts, G["ndt_cells_n"][order]) and np.abs(mean - G["ndt_cells_mean"][order]).max() < 1e-9
+    s, g, Hn = n.ndt_derivatives(G["ndt_p0"])
+    assert abs(s - G["ndt_score_p0"]) <= rel_stage * G["ndt_score_p0"]
+    assert np.abs(g - G["ndt_g_p0"]).max() <= rel_stage * np.abs(G["ndt_g_p0"]).max()
+    assert np.abs(Hn - G["ndt_H_p0"]).max() <= rel_stage * np.abs(G["ndt_H_p0"]).max()
+    rn = n.align(G["ndt_guess"])
+    dt, dr = synth.pose_error(rn.matrix(), G["ndt_final"])
+    assert dt <= tol_pose and dr <= tol_pose and rn.iterations == G["ndt_iterations"]
+    return e, n
+
+
+def test_oracle_reproduces_golden():
+    _check_engine(O.OracleRegistration, tol_pose=1e-7, rel_stage=1e-9)
+    cov = O.covariances(G["target_xyz"], 20)
+    assert np.abs(cov - G["target_cov"]).max() <= 1e-12 * np.abs(G["target_cov"]).max()
+    tr = G["gicp_trace"]
+    assert len(tr) == G["gicp_iterations"] and np.all(np.diff(tr[:, 12]) <= 0)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden():
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+
+    def make(params):
+        p = L.HgsParams()
+        for name, _ in L.HgsParams._fields_:
+            setattr(p, name, getattr(params, name))
+        return RegistrationHIP(p)
+
+    e, n = _check_engine(make, tol_pose=1e-3, rel_stage=2e-5)
+    cov = e.target_covariances(len(G["target_xyz"]))
+    assert (np.abs(cov - G["target_cov"]).max(axis=1) / np.abs(G["target_cov"]).max(axis=1)).max() < 5e-6
+    e.close()
+    n.close()
