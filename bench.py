@@ -154,23 +154,31 @@ def main():
         p = O.HgsParams()
         for name, _ in O.HgsParams._fields_:
             setattr(p, name, getattr(reg.params, name))
-        ncores = O.set_num_threads(os.cpu_count() or 1)
-        o = O.OracleRegistration(p)
-        o.setInputTarget(wl.target)   # target structures are built once per batch in the reference too
-        o.setInputSource(wl.candidates[0])
-        o.align(wl.guesses[0])        # warm-up (first-touch, thread pool, target covariances)
+        # reg_num_threads = 0 means "all cores" upstream; on many-core hosts that oversubscribes badly (256 threads are
+        # ~40x slower than 32 on a 2 x EPYC 9575F box), so the baseline is the BEST of a few thread counts.
+        ncpu = os.cpu_count() or 1
         k = min(args.cpu_sample, B)
-        tc = time.perf_counter()
-        dpose = []
-        for i in range(k):
-            o.setInputSource(wl.candidates[i])
-            ro = o.align(wl.guesses[i])
-            o.getFitnessScore()
-            dpose.append(synth.pose_error(np.array(rec[i]["final_transformation"]).reshape(4, 4).T, ro.matrix()))
-        tcpu = time.perf_counter() - tc
-        cpu = {"value": round(k / tcpu, 4), "unit": "registrations/sec", "cores": ncores, "kind": "port",
-               "sample": f"{k} of the {B} candidate registrations (setInputSource + align + getFitnessScore), target structures prebuilt",
-               "max_pose_diff_vs_gpu_m": float(max(d[0] for d in dpose)), "max_pose_diff_vs_gpu_rad": float(max(d[1] for d in dpose))}
+        best_cpu = None
+        for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+            O.set_num_threads(nt)
+            o = O.OracleRegistration(p)
+            o.setInputTarget(wl.target)   # target structures are built once per batch in the reference too
+            o.setInputSource(wl.candidates[0])
+            o.align(wl.guesses[0])        # warm-up (first-touch, thread pool, target covariances)
+            tc = time.perf_counter()
+            dpose = []
+            for i in range(k):
+                o.setInputSource(wl.candidates[i])
+                ro = o.align(wl.guesses[i])
+                o.getFitnessScore()
+                dpose.append(synth.pose_error(np.array(rec[i]["final_transformation"]).reshape(4, 4).T, ro.matrix()))
+            tcpu = time.perf_counter() - tc
+            if best_cpu is None or k / tcpu > best_cpu[0]:
+                best_cpu = (k / tcpu, nt, dpose)
+        cpu = {"value": round(best_cpu[0], 4), "unit": "registrations/sec", "cores": best_cpu[1], "kind": "port", "host_threads_available": ncpu,
+               "sample": f"{k} of the {B} candidate registrations (setInputSource + align + getFitnessScore), target structures prebuilt; "
+                         f"best of OMP thread counts 8/16/32/64",
+               "max_pose_diff_vs_gpu_m": float(max(d[0] for d in best_cpu[2])), "max_pose_diff_vs_gpu_rad": float(max(d[1] for d in best_cpu[2]))}
 
     if rank == 0:
         regs = world * B * args.steps

@@ -398,7 +398,7 @@ NdtConsts ndt_consts(const hgs_params& p) {
   c.max_iterations = p.max_iterations;
   c.search = p.neighbor_search == HGS_DIRECT1 ? 1 : 2;
   c.upstream_hd1_sign = p.ndt_upstream_hd1_sign;
-  c.pad = 0;
+  c.pad = std::getenv("HGS_TRACE") ? 1 : 0;  // device-side per-iteration trace (parity debugging)
   return c;
 }
 

@@ -53,6 +53,27 @@ __device__ __forceinline__ void block_reduce_store(const double* acc, double* ou
   if (threadIdx.x < N) out[threadIdx.x] = (lds[threadIdx.x] + lds[N + threadIdx.x]) + (lds[2 * N + threadIdx.x] + lds[3 * N + threadIdx.x]);
 }
 
+// Second reduction stage: out[k] = sum over tiles of p[tile*kAcc + k], k < kAcc, for a 256-thread block.
+// 252 = 9 x 28 threads read 252 consecutive doubles per step (fully coalesced), each thread owns one (row, column)
+// and walks tiles row, row+9, ... ; the 9 rows are then added in a fixed order -> bitwise reproducible.
+__device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int ntiles, double* out /* LDS [kAcc] */, double* scratch /* LDS [9*kAcc] */) {
+  const int t = threadIdx.x;
+  if (t < 9 * kAcc) {
+    const int col = t % kAcc, row = t / kAcc;
+    double s = 0;
+    for (int tile = row; tile < ntiles; tile += 9) s += p[(size_t)tile * kAcc + col];
+    scratch[row * kAcc + col] = s;
+  }
+  __syncthreads();
+  if (t < kAcc) {
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < 9; r++) s += scratch[r * kAcc + t];
+    out[t] = s;
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ BvhView view_of(const TargetView& t) {
   BvhView v;
   v.nodes = t.nodes, v.pts = t.pts, v.P = t.P, v.n = t.meta->nvalid;
@@ -325,24 +346,19 @@ void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt
   hipLaunchKernelGGL(k_gicp_linearize, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks);
 }
 
-__global__ __launch_bounds__(64) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
-                                                  int max_blocks) {
+__global__ __launch_bounds__(kBlock) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
+                                                      int max_blocks) {
   const int b = blockIdx.x;
   GicpState& st = states[b];
   if (st.phase != GICP_LINEARIZE) return;
   __shared__ double acc[kAcc];
+  __shared__ double scratch[9 * kAcc];
   const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
-  if (threadIdx.x < kAcc) {
-    double s = 0;
-    const double* p = partials + (size_t)b * max_blocks * kAcc + threadIdx.x;
-    for (int t = 0; t < ntiles; t++) s += p[(size_t)t * kAcc];
-    acc[threadIdx.x] = s;
-  }
-  __syncthreads();
+  reduce_tiles(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);
   if (threadIdx.x == 0) gicp_after_linearize(st, acc, c);
 }
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B) {
-  hipLaunchKernelGGL(k_gicp_solve, dim3(B), dim3(64), 0, s, descs, states, c, partials, max_blocks);
+  hipLaunchKernelGGL(k_gicp_solve, dim3(B), dim3(kBlock), 0, s, descs, states, c, partials, max_blocks);
 }
 
 // compute_error(xi): same correspondences, Mahalanobis matrices of the linearisation pose x0, residuals at xi.
@@ -633,29 +649,27 @@ void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView
   hipLaunchKernelGGL(k_ndt_derivatives, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, angles, c, partials, max_blocks);
 }
 
-__global__ __launch_bounds__(64) void k_ndt_solve(const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c,
-                                                 const double* __restrict__ partials, int max_blocks, int* done_counter) {
+__global__ __launch_bounds__(kBlock) void k_ndt_solve(const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c,
+                                                     const double* __restrict__ partials, int max_blocks, int* done_counter) {
   const int b = blockIdx.x;
   NdtState& st = states[b];
   if (st.phase != NDT_DERIV) return;
   __shared__ double acc[kAcc];
+  __shared__ double scratch[9 * kAcc];
   const int ntiles = (descs[b].n_input + kBlock - 1) / kBlock;
-  if (threadIdx.x < kAcc) {
-    double s = 0;
-    const double* p = partials + (size_t)b * max_blocks * kAcc + threadIdx.x;
-    for (int t = 0; t < ntiles; t++) s += p[(size_t)t * kAcc];
-    acc[threadIdx.x] = s;
-  }
-  __syncthreads();
+  reduce_tiles(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);
   if (threadIdx.x == 0) {
     ndt_after_derivatives(st, acc, c);
+    if (c.pad)  // HGS_TRACE=1: per-iteration trace for parity debugging
+      printf("hgs ndt b=%d it=%d passes=%d p=%.9f %.9f %.9f %.9f %.9f %.9f score=%.9f a_t=%.9f phase=%d\n", b, st.iterations, st.passes, st.p[0], st.p[1],
+             st.p[2], st.p[3], st.p[4], st.p[5], st.score, st.a_t, st.phase);
     if (st.phase == NDT_DONE) atomicAdd(done_counter, 1);
     else ndt_angle_tables(st.p, c.upstream_hd1_sign, angles[b]);
   }
 }
 void launch_ndt_solve(hipStream_t s, const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c, const double* partials, int max_blocks,
                       int B, int* done_counter) {
-  hipLaunchKernelGGL(k_ndt_solve, dim3(B), dim3(64), 0, s, descs, states, angles, c, partials, max_blocks, done_counter);
+  hipLaunchKernelGGL(k_ndt_solve, dim3(B), dim3(kBlock), 0, s, descs, states, angles, c, partials, max_blocks, done_counter);
 }
 
 __global__ void k_ndt_results(const CloudDesc* descs, const NdtState* states, DevResult* out, int B) {
@@ -697,15 +711,14 @@ void launch_ndt_debug_state(hipStream_t s, NdtState* st, NdtAngles* ang, const d
 }
 
 // out[k] = sum over tiles of partials[t*kAcc + k], in tile order (what k_gicp_solve / k_ndt_solve do first)
-__global__ __launch_bounds__(64) void k_reduce_partials(const double* __restrict__ partials, int ntiles, double* out) {
-  if (threadIdx.x < kAcc) {
-    double s = 0;
-    for (int t = 0; t < ntiles; t++) s += partials[(size_t)t * kAcc + threadIdx.x];
-    out[threadIdx.x] = s;
-  }
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ partials, int ntiles, double* out) {
+  __shared__ double acc[kAcc];
+  __shared__ double scratch[9 * kAcc];
+  reduce_tiles(partials, ntiles, acc, scratch);
+  if (threadIdx.x < kAcc) out[threadIdx.x] = acc[threadIdx.x];
 }
 void launch_reduce_partials(hipStream_t s, const double* partials, int ntiles, double* out) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, s, partials, ntiles, out);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, s, partials, ntiles, out);
 }
 
 }  // namespace hgs
