@@ -12,6 +12,7 @@
 // no MFMA (the contraction is 6x6), coalesced float4 loads, wave64 shuffle reductions, deterministic two-stage sums.
 #include <hip/hip_runtime.h>
 #include "hgs_device.h"
+#include "hgs_wave_bvh.h"
 
 namespace hgs {
 
@@ -253,13 +254,14 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   const int ntiles = (n + kBlock - 1) / kBlock;
   if ((int)blockIdx.x >= ntiles) return;
   const int i = xcd_tile(blockIdx.x, ntiles) * kBlock + threadIdx.x;
-  if (i >= n) return;
+  const bool active = i < n;
   BvhView tv;
   tv.nodes = d.nodes, tv.pts = d.pts, tv.P = d.P, tv.n = n;
-  const float4 qp = d.pts[i];
+  const float4 qp = active ? d.pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const F3 q = {qp.x, qp.y, qp.z};
   KnnList<KMAX> list;
-  bvh_knn<KMAX>(tv, q, k, list);
+  wave_knn<KMAX>(tv, q, active, k, list);  // the 64 queries of a wave are consecutive points on the Hilbert curve
+  if (!active) return;
   double s1[3] = {0, 0, 0};
   Sym3 s2 = {0, 0, 0, 0, 0, 0};
   int found = 0;
@@ -321,15 +323,15 @@ __global__ __launch_bounds__(kBlock) void k_gicp_linearize(const CloudDesc* desc
 #pragma unroll
   for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
   const Pose T = states[b].x0;
-  if (i < n) {
-    float Tf[12];
-    pose_to_float(T, Tf);
-    const float4 a = d.pts[i];
-    const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
-    float d2;
-    int orig;
-    const BvhView tv = view_of(tgt);
-    int j = bvh_nn1(tv, q, c.search_bound2, &d2, &orig);
+  const bool active = i < n;
+  float Tf[12];
+  pose_to_float(T, Tf);
+  const float4 a = active ? d.pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
+  float d2;
+  int j, orig;
+  wave_nn1(view_of(tgt), q, active, c.search_bound2, d2, j, orig);
+  if (active) {
     if (j >= 0 && !((double)d2 < c.max_corr2)) j = -1;
     d.corr[i] = j;
     if (j >= 0) {
@@ -439,19 +441,20 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const CloudDesc* descs, Targ
   const int i = tile * kBlock + threadIdx.x;
   __shared__ double lds[4 * 2];
   double acc[2] = {0.0, 0.0};
-  if (i < n) {
+  {
+    const bool active = i < n;
     float Tf[12];
     const float* Tc = poses[b].T;
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int cc = 0; cc < 4; cc++) Tf[r * 4 + cc] = Tc[cc * 4 + r];
-    const float4 a = d.pts[i];
+    const float4 a = active ? d.pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
     float d2;
-    int orig;
-    const int j = bvh_nn1(view_of(tgt), q, FLT_MAX, &d2, &orig);
-    if (j >= 0 && (double)d2 <= max_range) acc[0] = (double)d2, acc[1] = 1.0;
+    int j, orig;
+    wave_nn1(view_of(tgt), q, active, FLT_MAX, d2, j, orig);
+    if (active && j >= 0 && (double)d2 <= max_range) acc[0] = (double)d2, acc[1] = 1.0;
   }
   block_reduce_store<2>(acc, partials + ((size_t)b * max_blocks + tile) * 2, lds);
 }

@@ -94,8 +94,33 @@ def cpu_scaling():
         print(f"cpu oracle GICP 120k threads={nt}: set_source {t1 - t0:.3f}s align {t2 - t1:.3f}s (it {r.iterations}) fitness {t3 - t2:.3f}s")
 
 
+def ndt_trace():
+    """Device-side per-iteration trace (HGS_TRACE=1) next to the oracle's, for the VLP-16 case whose iteration diverges."""
+    os.environ["HGS_TRACE"] = "1"
+    tgt, src, T = synth.make_pair("VLP-16", 2, downsample=0.1)
+    wild = T @ synth.pose_matrix([0.05, 0.02, 0.0], [0.0, 0.0, 0.004])
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution, p.max_iterations = 1.0, 3
+    e, o = hip(p), O.OracleRegistration(p)
+    for r in (e, o):
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+    ro = o.align(wild)
+    np.set_printoptions(precision=9, suppress=True, linewidth=200)
+    print("oracle trace (p, score, step):")
+    print(o.trace())
+    sys.stdout.flush()
+    re = e.align(wild)
+    e.synchronize()
+    print("hip iterations", re.iterations, "oracle", ro.iterations, "diff", synth.pose_error(re.matrix(), ro.matrix()))
+    e.close()
+    del os.environ["HGS_TRACE"]
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ndt", "stages", "cpu"]
+    if "trace" in which:
+        ndt_trace()
     if "ndt" in which:
         ndt_parity()
     if "stages" in which:
