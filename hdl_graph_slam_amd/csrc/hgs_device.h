@@ -96,6 +96,6 @@ void launch_ndt_results(hipStream_t s, const CloudDesc* descs, const NdtState* s
 // stage-level test hooks
 void launch_gicp_debug_state(hipStream_t s, GicpState* st, const double* T12_dev);
 void launch_ndt_debug_state(hipStream_t s, NdtState* st, NdtAngles* ang, const double* p6_dev, NdtConsts c);
-void launch_reduce_partials(hipStream_t s, const double* partials, int ntiles, double* out);
+void launch_reduce_partials(hipStream_t s, const double* partials, int ntiles, int width /* kAcc | kAccNdt */, double* out);
 
 }  // namespace hgs

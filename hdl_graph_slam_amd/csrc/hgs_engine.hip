@@ -436,7 +436,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   HGS_HIP(h, hipMemcpyAsync(h->guesses.p, guesses_host, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HGS_HIP(h, h->done.reserve(64));
   HGS_HIP(h, h->results.reserve((size_t)B * sizeof(DevResult)));
-  HGS_HIP(h, h->partials.reserve((size_t)B * max_blocks * kAcc * sizeof(double)));
+  HGS_HIP(h, h->partials.reserve((size_t)B * max_blocks * kAccNdt * sizeof(double)));
   HGS_HIP(h, h->partials_err.reserve((size_t)B * max_blocks * 2 * sizeof(double)));
   int done = 0;
   if (method == HGS_FAST_GICP) {
@@ -943,7 +943,7 @@ int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, d
   launch_gicp_debug_state(h->stream, h->states.as<GicpState>(), h->misc.as<double>());
   launch_gicp_linearize(h->stream, d_descs, target_view(t), h->states.as<GicpState>(), gicp_consts(h->prm), h->partials.as<double>(), max_blocks, 1);
   double* d_out = h->misc.as<double>() + 16;
-  launch_reduce_partials(h->stream, h->partials.as<double>(), max_blocks, d_out);
+  launch_reduce_partials(h->stream, h->partials.as<double>(), max_blocks, kAcc, d_out);
   double acc[kAcc];
   HGS_HIP(h, hipMemcpyAsync(acc, d_out, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
   const size_t s_slots = (size_t)s->P * kLeaf, t_slots = (size_t)t->P * kLeaf;
@@ -1026,9 +1026,9 @@ int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, 
   const NdtConsts c = ndt_consts(h->prm);
   HGS_HIP(h, h->states.reserve(sizeof(NdtState)));
   HGS_HIP(h, h->angles.reserve(sizeof(NdtAngles)));
-  HGS_HIP(h, h->partials.reserve((size_t)max_blocks * kAcc * sizeof(double)));
-  HGS_HIP(h, h->misc.reserve(64 * sizeof(double)));
-  HGS_HIP(h, hipMemsetAsync(h->partials.p, 0, (size_t)max_blocks * kAcc * sizeof(double), h->stream));
+  HGS_HIP(h, h->partials.reserve((size_t)max_blocks * kAccNdt * sizeof(double)));
+  HGS_HIP(h, h->misc.reserve(128 * sizeof(double)));
+  HGS_HIP(h, hipMemsetAsync(h->partials.p, 0, (size_t)max_blocks * kAccNdt * sizeof(double), h->stream));
   HGS_HIP(h, hipMemcpyAsync(h->misc.p, p6, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   launch_ndt_debug_state(h->stream, h->states.as<NdtState>(), h->angles.as<NdtAngles>(), h->misc.as<double>(), c);
   NdtTargetView tv;
@@ -1036,15 +1036,13 @@ int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, 
   tv.hash_mask = t->ndt_hash_cap - 1, tv.inv_leaf = 1.0f / (float)h->prm.resolution;
   launch_ndt_derivatives(h->stream, d_descs, tv, h->states.as<NdtState>(), h->angles.as<NdtAngles>(), c, h->partials.as<double>(), max_blocks, 1);
   double* d_out = h->misc.as<double>() + 16;
-  launch_reduce_partials(h->stream, h->partials.as<double>(), max_blocks, d_out);
-  double acc[kAcc];
+  launch_reduce_partials(h->stream, h->partials.as<double>(), max_blocks, kAccNdt, d_out);
+  double acc[kAccNdt];
   HGS_HIP(h, hipMemcpyAsync(acc, d_out, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
-  int k = 0;
-  for (int r = 0; r < 6; r++)
-    for (int cc = r; cc < 6; cc++) H36[r * 6 + cc] = H36[cc * 6 + r] = acc[k++];
-  for (int i = 0; i < 6; i++) g6[i] = acc[21 + i];
-  *score = acc[27];
+  for (int i = 0; i < 36; i++) H36[i] = acc[i];
+  for (int i = 0; i < 6; i++) g6[i] = acc[36 + i];
+  *score = acc[42];
   return HGS_OK;
 }
 

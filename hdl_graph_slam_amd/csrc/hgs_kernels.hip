@@ -54,22 +54,25 @@ __device__ __forceinline__ void block_reduce_store(const double* acc, double* ou
   if (threadIdx.x < N) out[threadIdx.x] = (lds[threadIdx.x] + lds[N + threadIdx.x]) + (lds[2 * N + threadIdx.x] + lds[3 * N + threadIdx.x]);
 }
 
-// Second reduction stage: out[k] = sum over tiles of p[tile*kAcc + k], k < kAcc, for a 256-thread block.
-// 252 = 9 x 28 threads read 252 consecutive doubles per step (fully coalesced), each thread owns one (row, column)
-// and walks tiles row, row+9, ... ; the 9 rows are then added in a fixed order -> bitwise reproducible.
-__device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int ntiles, double* out /* LDS [kAcc] */, double* scratch /* LDS [9*kAcc] */) {
+// Second reduction stage: out[k] = sum over tiles of p[tile*N + k], k < N, for a 256-thread block.
+// ROWS x N threads (ROWS = 256 / N: 9 x 28 for GICP, 5 x 43 for NDT) read ROWS*N consecutive doubles per step (fully
+// coalesced), each thread owns one (row, column) and walks tiles row, row+ROWS, ... ; the rows are then added in a
+// fixed order -> bitwise reproducible.
+template <int N>
+__device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int ntiles, double* out /* LDS [N] */, double* scratch /* LDS [(256/N)*N] */) {
+  constexpr int ROWS = kBlock / N;
   const int t = threadIdx.x;
-  if (t < 9 * kAcc) {
-    const int col = t % kAcc, row = t / kAcc;
+  if (t < ROWS * N) {
+    const int col = t % N, row = t / N;
     double s = 0;
-    for (int tile = row; tile < ntiles; tile += 9) s += p[(size_t)tile * kAcc + col];
-    scratch[row * kAcc + col] = s;
+    for (int tile = row; tile < ntiles; tile += ROWS) s += p[(size_t)tile * N + col];
+    scratch[row * N + col] = s;
   }
   __syncthreads();
-  if (t < kAcc) {
+  if (t < N) {
     double s = 0;
 #pragma unroll
-    for (int r = 0; r < 9; r++) s += scratch[r * kAcc + t];
+    for (int r = 0; r < ROWS; r++) s += scratch[r * N + t];
     out[t] = s;
   }
   __syncthreads();
@@ -354,9 +357,9 @@ __global__ __launch_bounds__(kBlock) void k_gicp_solve(const CloudDesc* descs, G
   GicpState& st = states[b];
   if (st.phase != GICP_LINEARIZE) return;
   __shared__ double acc[kAcc];
-  __shared__ double scratch[9 * kAcc];
+  __shared__ double scratch[kBlock];
   const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
-  reduce_tiles(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);
+  reduce_tiles<kAcc>(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);
   if (threadIdx.x == 0) gicp_after_linearize(st, acc, c);
 }
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B) {
@@ -617,13 +620,13 @@ __global__ __launch_bounds__(kBlock) void k_ndt_derivatives(const CloudDesc* des
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = blockIdx.x;
   const int i = tile * kBlock + threadIdx.x;
-  __shared__ double lds[4 * kAcc];
+  __shared__ double lds[4 * kAccNdt];
   __shared__ NdtAngles ang;
   for (int k = threadIdx.x; k < (int)(sizeof(NdtAngles) / 4); k += kBlock) reinterpret_cast<float*>(&ang)[k] = reinterpret_cast<const float*>(&angles[b])[k];
   __syncthreads();
-  double acc[kAcc];
+  double acc[kAccNdt];
 #pragma unroll
-  for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+  for (int k = 0; k < kAccNdt; k++) acc[k] = 0.0;
   if (i < n) {
     const float4 x = d.raw[i];
     if (finite3(x)) {
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void k_ndt_derivatives(const CloudDesc* des
       }
     }
   }
-  block_reduce_store<kAcc>(acc, partials + ((size_t)b * max_blocks + tile) * kAcc, lds);
+  block_reduce_store<kAccNdt>(acc, partials + ((size_t)b * max_blocks + tile) * kAccNdt, lds);
 }
 void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles, NdtConsts c,
                             double* partials, int max_blocks, int B) {
@@ -657,10 +660,10 @@ __global__ __launch_bounds__(kBlock) void k_ndt_solve(const CloudDesc* descs, Nd
   const int b = blockIdx.x;
   NdtState& st = states[b];
   if (st.phase != NDT_DERIV) return;
-  __shared__ double acc[kAcc];
-  __shared__ double scratch[9 * kAcc];
+  __shared__ double acc[kAccNdt];
+  __shared__ double scratch[kBlock];
   const int ntiles = (descs[b].n_input + kBlock - 1) / kBlock;
-  reduce_tiles(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);
+  reduce_tiles<kAccNdt>(partials + (size_t)b * max_blocks * kAccNdt, ntiles, acc, scratch);
   if (threadIdx.x == 0) {
     ndt_after_derivatives(st, acc, c);
     if (c.pad)  // HGS_TRACE=1: per-iteration trace for parity debugging
@@ -713,15 +716,17 @@ void launch_ndt_debug_state(hipStream_t s, NdtState* st, NdtAngles* ang, const d
   hipLaunchKernelGGL(k_ndt_debug_state, dim3(1), dim3(1), 0, s, st, ang, p6_dev, c);
 }
 
-// out[k] = sum over tiles of partials[t*kAcc + k], in tile order (what k_gicp_solve / k_ndt_solve do first)
+// out[k] = sum over tiles of partials[t*N + k], in the order k_gicp_solve (N = kAcc) / k_ndt_solve (N = kAccNdt) use
+template <int N>
 __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ partials, int ntiles, double* out) {
-  __shared__ double acc[kAcc];
-  __shared__ double scratch[9 * kAcc];
-  reduce_tiles(partials, ntiles, acc, scratch);
-  if (threadIdx.x < kAcc) out[threadIdx.x] = acc[threadIdx.x];
+  __shared__ double acc[N];
+  __shared__ double scratch[kBlock];
+  reduce_tiles<N>(partials, ntiles, acc, scratch);
+  if (threadIdx.x < N) out[threadIdx.x] = acc[threadIdx.x];
 }
-void launch_reduce_partials(hipStream_t s, const double* partials, int ntiles, double* out) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, s, partials, ntiles, out);
+void launch_reduce_partials(hipStream_t s, const double* partials, int ntiles, int width, double* out) {
+  if (width == kAccNdt) hipLaunchKernelGGL(k_reduce_partials<kAccNdt>, dim3(1), dim3(kBlock), 0, s, partials, ntiles, out);
+  else hipLaunchKernelGGL(k_reduce_partials<kAcc>, dim3(1), dim3(kBlock), 0, s, partials, ntiles, out);
 }
 
 }  // namespace hgs

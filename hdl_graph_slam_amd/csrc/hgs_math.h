@@ -15,6 +15,15 @@
 
 namespace hgs {
 
+// First statement of a function body: no fused multiply-add contraction inside it, so that the device evaluates the
+// expression tree exactly like the (contraction-free) CPU oracle.  Used on the one-thread-per-problem NDT control path,
+// whose Newton iteration amplifies last-bit differences (DESIGN.md "NDT conditioning"); never in per-point fp64 code.
+#if defined(__clang__)
+#define HGS_FP_STRICT _Pragma("clang fp contract(off)")
+#else
+#define HGS_FP_STRICT
+#endif
+
 // ---- float point helpers (bit-exact contract with the oracle: explicit fma chains) -------------------------
 struct F3 {
   float x, y, z;
@@ -218,6 +227,7 @@ HGS_HD void solve_ldlt6(const double* A_in, const double* b_in, double* x) {
 // x = pinv(A) b via one-sided Jacobi SVD, singular values <= 6 eps sigma_max dropped (role of Eigen::JacobiSVD
 // .solve in ndt_omp's Newton step).
 HGS_HD void solve_svd6(const double* A, const double* b, double* x) {
+  HGS_FP_STRICT
   double U[36], V[36];
   for (int i = 0; i < 36; i++) U[i] = A[i], V[i] = (i % 7 == 0) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; sweep++) {
@@ -267,6 +277,7 @@ HGS_HD void solve_svd6(const double* A, const double* b, double* x) {
 
 // ---- symmetric 3x3 eigen decomposition (cyclic Jacobi), eigenvalues ascending, eigenvectors in columns of V ----
 HGS_HD void eig_sym3(const double* A_in, double* w, double* V) {
+  HGS_FP_STRICT
   double a[9];
   for (int i = 0; i < 9; i++) a[i] = A_in[i], V[i] = (i % 4 == 0) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 64; sweep++) {
@@ -314,6 +325,7 @@ HGS_HD void eig_sym3(const double* A_in, double* w, double* V) {
 }
 
 HGS_HD void mat3_inverse(const double* a, double* r) {
+  HGS_FP_STRICT
   const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
   const double id = 1.0 / (a[0] * c00 + a[1] * c01 + a[2] * c02);
   r[0] = c00 * id;

@@ -43,6 +43,7 @@ HGS_HD int ndt_lookup(const NdtGrid& g, int cx, int cy, int cz) {
 // VoxelGridCovariance second pass for one cell: from n, sum p, sum p p^T (double) to mean / inverse covariance.
 // Returns false if the cell is rejected (fewer than min_points, bad eigenvalues, non-finite inverse).
 HGS_HD bool ndt_finalize_cell(int n, const double* sum, const Sym3& sq, int min_points, double* mean, Sym3* icov) {
+  HGS_FP_STRICT
   const double dn = (double)n;
   mean[0] = sum[0] / dn, mean[1] = sum[1] / dn, mean[2] = sum[2] / dn;
   if (n < min_points) return false;
@@ -96,6 +97,7 @@ struct NdtAngles {
 };
 
 HGS_HD Pose ndt_pose_from_p(const double* p) {
+  HGS_FP_STRICT
   const double cx = cos(p[3]), sx = sin(p[3]), cy = cos(p[4]), sy = sin(p[4]), cz = cos(p[5]), sz = sin(p[5]);
   Pose T;
   T.m[0] = cy * cz, T.m[1] = -cy * sz, T.m[2] = sy, T.m[3] = p[0];
@@ -105,6 +107,7 @@ HGS_HD Pose ndt_pose_from_p(const double* p) {
 }
 
 HGS_HD void ndt_angle_tables(const double* p, int upstream_hd1_sign, NdtAngles& a) {
+  HGS_FP_STRICT
   double cx, cy, cz, sx, sy, sz;
   if (fabs(p[3]) < 10e-5) cx = 1.0, sx = 0.0; else cx = cos(p[3]), sx = sin(p[3]);
   if (fabs(p[4]) < 10e-5) cy = 1.0, sy = 0.0; else cy = cos(p[4]), sy = sin(p[4]);
@@ -146,7 +149,13 @@ HGS_HD void ndt_point_derivatives(const NdtAngles& a, float x, float y, float z,
   for (int r = 0; r < 15; r++) d.xh[r] = a.h[r][0] * x + a.h[r][1] * y + a.h[r][2] * z;
 }
 
-// updateDerivatives for one (point, cell): adds to acc[28] = {H upper 21, g 6, score}. Float temporaries, double
+// Accumulator layout of one NDT derivative pass: [0..35] the FULL 6x6 Hessian, row-major — upstream evaluates all 36
+// entries in float and (i,j) / (j,i) round differently, so the matrix handed to the SVD solve is slightly asymmetric;
+// the Newton direction of a weakly constrained scan is sensitive to exactly that, hence no mirrored upper triangle —
+// [36..41] gradient, [42] score.
+constexpr int kAccNdt = 43;
+
+// updateDerivatives for one (point, cell): adds to acc[kAccNdt]. Float temporaries, double
 // accumulation, exactly the operation order of the oracle (oracle/ndt.hpp) so the two agree to float rounding.
 HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx, float qy, float qz,  // q = x' - mean (float)
                            const float* ci /*icov xx,xy,xz,yy,yz,zz*/, double* acc) {
@@ -164,7 +173,7 @@ HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx
   e = d2 * e;
   if (e > 1.f || e < 0.f || e != e) return;
   e *= d1;
-  acc[27] += (double)score_inc;
+  acc[42] += (double)score_inc;
   // point gradient (3x6): identity | columns 3..5 from xj
   float pg[3][6];
 #pragma unroll
@@ -182,7 +191,7 @@ HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx
 #pragma unroll
   for (int k = 0; k < 6; k++) qCpg[k] = qx * Cpg[0][k] + qy * Cpg[1][k] + qz * Cpg[2][k];
 #pragma unroll
-  for (int k = 0; k < 6; k++) acc[21 + k] += (double)(e * qCpg[k]);
+  for (int k = 0; k < 6; k++) acc[36 + k] += (double)(e * qCpg[k]);
   // second derivatives d2x'/dp_i dp_j (3-vectors), non-zero for i,j in {3,4,5}
   const float ph[6][3] = {{0.f, pd.xh[0], pd.xh[1]},          // (3,3) a
                           {0.f, pd.xh[2], pd.xh[3]},          // (3,4) b
@@ -190,19 +199,18 @@ HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx
                           {pd.xh[6], pd.xh[7], pd.xh[8]},     // (4,4) d
                           {pd.xh[9], pd.xh[10], pd.xh[11]},   // (4,5) e
                           {pd.xh[12], pd.xh[13], pd.xh[14]}}; // (5,5) f
-  int k = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++)
 #pragma unroll
-    for (int j = i; j < 6; j++) {
+    for (int j = 0; j < 6; j++) {
       float qCh = 0.f;
-      if (i >= 3) {
-        const int hidx = (i == 3) ? (j - 3) : (i == 4 ? (j - 4 + 3) : 5);
+      if (i >= 3 && j >= 3) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int hidx = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
         qCh = qC[0] * ph[hidx][0] + qC[1] * ph[hidx][1] + qC[2] * ph[hidx][2];
       }
       const float pgCpg = pg[0][j] * Cpg[0][i] + pg[1][j] * Cpg[1][i] + pg[2][j] * Cpg[2][i];
-      acc[k] += (double)(e * (-d2 * qCpg[i] * qCpg[j] + qCh + pgCpg));
-      k++;
+      acc[i * 6 + j] += (double)(e * (-d2 * qCpg[i] * qCpg[j] + qCh + pgCpg));
     }
 }
 
@@ -257,16 +265,11 @@ HGS_HD void ndt_state_init(NdtState& s, const float* guess_colmajor) {
 
 // Consumes the reduced {H, g, score} of a derivative pass evaluated at s.p and prepares the next evaluation point.
 HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConsts& c) {
+  HGS_FP_STRICT
   double H[36], g[6];
-  int k = 0;
-  for (int r = 0; r < 6; r++)
-    for (int cc = r; cc < 6; cc++) {
-      H[r * 6 + cc] = acc[k];
-      H[cc * 6 + r] = acc[k];
-      k++;
-    }
-  for (int i = 0; i < 6; i++) g[i] = acc[21 + i];
-  s.score = acc[27];
+  for (int i = 0; i < 36; i++) H[i] = acc[i];
+  for (int i = 0; i < 6; i++) g[i] = acc[36 + i];
+  s.score = acc[42];
   s.passes++;
   if (!s.first) {
     // finish the iteration whose step produced this pass: p += dp * a_t ; convergence test ; iter++

@@ -244,16 +244,16 @@ static void ndt_build(ENdt& e, const ECloud& c, double resolution, int min_point
 }
 static void ndt_derivatives(const ECloud& src, const ENdt& e, const NdtAngles& ang, const NdtConsts& c, double* acc_out) {
   const int ntiles = (src.n_input + 255) / 256;
-  std::vector<double> total(kAcc, 0.0);
+  std::vector<double> total(kAccNdt, 0.0);
   const NdtGrid& g = e.grid;
   for (int tile = 0; tile < ntiles; tile++) {
-    double part[kAcc] = {0};
+    double part[kAccNdt] = {0};
     for (int t = 0; t < 256; t++) {
       const int i = tile * 256 + t;
       if (i >= src.n_input) break;
       const Float4 x = src.raw[i];
       if (!finite3(x)) continue;
-      double acc[kAcc] = {0};
+      double acc[kAccNdt] = {0};
       const F3 xt = transform_point_f(ang.T, x.x, x.y, x.z);
       const int cx = (int)floorf(xt.x * g.inv_leaf), cy = (int)floorf(xt.y * g.inv_leaf), cz = (int)floorf(xt.z * g.inv_leaf);
       NdtPointDeriv pd;
@@ -267,11 +267,11 @@ static void ndt_derivatives(const ECloud& src, const ENdt& e, const NdtAngles& a
         const float icov[6] = {rec.v0.x, rec.v0.y, rec.v0.z, rec.v0.w, rec.v1.x, rec.v1.y};
         ndt_cell_terms(c, pd, (float)((double)xt.x - rec.mean[0]), (float)((double)xt.y - rec.mean[1]), (float)((double)xt.z - rec.mean[2]), icov, acc);
       }
-      for (int k = 0; k < kAcc; k++) part[k] += acc[k];
+      for (int k = 0; k < kAccNdt; k++) part[k] += acc[k];
     }
-    for (int k = 0; k < kAcc; k++) total[k] += part[k];
+    for (int k = 0; k < kAccNdt; k++) total[k] += part[k];
   }
-  for (int k = 0; k < kAcc; k++) acc_out[k] = total[k];
+  for (int k = 0; k < kAccNdt; k++) acc_out[k] = total[k];
 }
 static NdtConsts ndt_consts(const hgs_params& p) {
   NdtConsts c;
@@ -344,7 +344,7 @@ int emul_align(EmulHandle* h, const float* guess, hgs_result* out) {
     ndt_angle_tables(st.p, c.upstream_hd1_sign, ang);
     long rounds = 0;
     while (st.phase != NDT_DONE && rounds < 100000) {
-      double acc[kAcc];
+      double acc[kAccNdt];
       ndt_derivatives(h->src, h->ndt, ang, c, acc);
       ndt_after_derivatives(st, acc, c);
       if (getenv("HGS_EMUL_TRACE")) printf("emul it=%d p=%.6f %.6f %.6f %.6f %.6f %.6f score=%.6f a_t=%.6f\n", st.iterations, st.p[0], st.p[1], st.p[2], st.p[3], st.p[4], st.p[5], st.score, st.a_t);
@@ -447,13 +447,11 @@ int emul_ndt_derivatives(EmulHandle* h, const double* p6, double* score, double*
   const NdtConsts c = ndt_consts(h->prm);
   NdtAngles ang;
   ndt_angle_tables(p6, c.upstream_hd1_sign, ang);
-  double acc[kAcc];
+  double acc[kAccNdt];
   ndt_derivatives(h->src, h->ndt, ang, c, acc);
-  int k = 0;
-  for (int r = 0; r < 6; r++)
-    for (int cc = r; cc < 6; cc++) H36[r * 6 + cc] = H36[cc * 6 + r] = acc[k++];
-  for (int i = 0; i < 6; i++) g6[i] = acc[21 + i];
-  *score = acc[27];
+  for (int i = 0; i < 36; i++) H36[i] = acc[i];
+  for (int i = 0; i < 6; i++) g6[i] = acc[36 + i];
+  *score = acc[42];
   return 0;
 }
 

@@ -83,7 +83,8 @@ def check_ndt_cells(engine, oracle):
     assert len(set(idx.tolist())) == len(idx)
     assert np.array_equal(ne, no[idx])
     assert np.abs(me - mo[idx]).max() < 1e-9
-    assert (np.abs(ce - co[idx]).max(axis=1) / np.abs(co[idx]).max(axis=1)).max() < 2e-6
+    # inverse covariances are stored in float; the double pipeline behind them is contraction-free on both sides
+    assert (np.abs(ce - co[idx]).max(axis=1) / np.abs(co[idx]).max(axis=1)).max() < 1.5e-7
 
 
 def check_ndt_derivatives(engine, oracle, p6, rel=2e-5):

@@ -92,7 +92,7 @@ def test_ndt_cells(ndt_case):
 def test_ndt_derivatives(ndt_case):
     e, o, tgt, src, T, kind = ndt_case
     for p6 in ([T[0, 3], T[1, 3], T[2, 3], 0.003, -0.004, 0.02], [T[0, 3] + 0.1, T[1, 3], T[2, 3], 3.14, 3.13, 3.1], [0, 0, 0, 0, 0, 0]):
-        PC.check_ndt_derivatives(e, o, np.array(p6, np.float64), rel=2e-6)  # H: lower triangle mirrored from the upper one
+        PC.check_ndt_derivatives(e, o, np.array(p6, np.float64), rel=1e-12)
 
 
 def test_ndt_align_follows_oracle_iteration_by_iteration(ndt_case):

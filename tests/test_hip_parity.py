@@ -125,20 +125,24 @@ def test_ndt_cells(ndt_case):
 def test_ndt_derivatives(ndt_case):
     e, o, tgt, src, T, kind, p = ndt_case
     for p6 in ([T[0, 3], T[1, 3], T[2, 3], 0.003, -0.004, 0.02], [T[0, 3] + 0.1, T[1, 3], T[2, 3], 3.14, 3.13, 3.1], [0, 0, 0, 0, 0, 0]):
-        PC.check_ndt_derivatives(e, o, np.array(p6, np.float64), rel=2e-5)
+        PC.check_ndt_derivatives(e, o, np.array(p6, np.float64), rel=1e-10)
 
 
 def test_ndt_align(ndt_case):
-    """See tests/test_device_logic_host.py: ndt_omp's iteration is chaotic for some guesses, so parity is asserted per pass,
-    after truncated iteration counts, and end-to-end wherever the oracle settles within 8 iterations."""
+    """ndt_omp's Newton iteration (normalised direction, step clamped to [eps/2, 0.1], no line search) amplifies a
+    perturbation of its state by up to ~1e3 per iteration on weakly constrained scans (DESIGN.md "NDT conditioning"), so
+    a last-bit difference in a double sum decides the trajectory after ~5 iterations.  Parity is therefore asserted
+    (i) per derivative pass at 1e-10 (test_ndt_derivatives), (ii) after truncated runs from a deliberately bad guess
+    (2 and 3 derivative passes), and (iii) end-to-end at the north-star tolerance wherever the oracle settles within 8
+    iterations, i.e. wherever the iteration is contractive."""
     e, o, tgt, src, T, kind, p = ndt_case
     wild = T @ synth.pose_matrix([0.05, 0.02, 0.0], [0.0, 0.0, 0.004])
-    for max_it in (0, 3):
+    for max_it in (0, 1):
         p2 = O.default_params(O.HGS_NDT_OMP)
         p2.resolution, p2.neighbor_search, p2.max_iterations = p.resolution, p.neighbor_search, max_it
         e2, o2 = _hip(p2), O.OracleRegistration(p2)
         PC.load_pair(e2, o2, tgt, src)
-        PC.check_align(e2, o2, wild, tol_m=1e-4, tol_rad=1e-4)
+        PC.check_align(e2, o2, wild, tol_m=1e-6, tol_rad=1e-6)
         e2.close()
     settled = 0
     for off in ([0.02, 0.01, 0.0, 0.002], [0.1, -0.05, 0.0, 0.01], [0.3, 0.1, 0.0, 0.02], [0.1, 0.0, 0.0, 0.01]):
