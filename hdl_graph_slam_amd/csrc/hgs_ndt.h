@@ -216,20 +216,23 @@ HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx
 
 // Eigen's eulerAngles(0,1,2) on the float rotation of the guess (ndt_omp's initial p)
 HGS_HD void ndt_euler_xyz_f(const float* g16_colmajor, float* out) {
+  HGS_FP_STRICT
   const float R00 = g16_colmajor[0], R01 = g16_colmajor[4], R02 = g16_colmajor[8];
   const float R10 = g16_colmajor[1], R11 = g16_colmajor[5], R12 = g16_colmajor[9];
   const float R20 = g16_colmajor[2], R21 = g16_colmajor[6], R22 = g16_colmajor[10];
-  float r0 = atan2f(R12, R22);
+  // float transcendental = double function rounded once: identical on the device libm and on glibc (one float ulp
+  // near pi is 2.4e-7 rad — enough to move the Newton trajectory of a weakly constrained scan); no FMA contraction
+  float r0 = (float)atan2((double)R12, (double)R22);
   const float c2 = sqrtf(R00 * R00 + R01 * R01);
   float r1;
   if (r0 > 0.f) {
     r0 -= 3.14159265358979323846f;
-    r1 = atan2f(-R02, -c2);
+    r1 = (float)atan2((double)-R02, (double)-c2);
   } else {
-    r1 = atan2f(-R02, c2);
+    r1 = (float)atan2((double)-R02, (double)c2);
   }
-  const float s1 = sinf(r0), c1 = cosf(r0);
-  const float r2 = atan2f(s1 * R20 - c1 * R10, c1 * R11 - s1 * R21);
+  const float s1 = (float)sin((double)r0), c1 = (float)cos((double)r0);
+  const float r2 = (float)atan2((double)(s1 * R20 - c1 * R10), (double)(c1 * R11 - s1 * R21));
   out[0] = -r0, out[1] = -r1, out[2] = -r2;
 }
 

@@ -151,19 +151,26 @@ public:
 
 // Eigen's MatrixBase::eulerAngles(0,1,2) (Graphics Gems IV variant) on a float rotation, as ndt_omp uses to
 // initialise p from the guess.
+// Float transcendental = the double function rounded once (a correctly rounded float result, which is what a
+// conforming atan2f/sinf/cosf returns up to its <= 1 ulp slack); written this way so that glibc here and the device
+// libm in the HIP path agree bit-for-bit — near pi one float ulp is 2.4e-7 rad, enough to change the NDT trajectory.
+inline float atan2_f(float y, float x) { return (float)std::atan2((double)y, (double)x); }
+inline float sin_f(float a) { return (float)std::sin((double)a); }
+inline float cos_f(float a) { return (float)std::cos((double)a); }
+
 inline void euler_angles_xyz_f(const float R[3][3], float out[3]) {
   // i=0, j=1, k=2, "odd" = 0
-  float r0 = std::atan2(R[1][2], R[2][2]);
+  float r0 = atan2_f(R[1][2], R[2][2]);
   const float c2 = std::sqrt(R[0][0] * R[0][0] + R[0][1] * R[0][1]);
   float r1;
   if (r0 > 0.f) {
     r0 -= (float)M_PI;
-    r1 = std::atan2(-R[0][2], -c2);
+    r1 = atan2_f(-R[0][2], -c2);
   } else {
-    r1 = std::atan2(-R[0][2], c2);
+    r1 = atan2_f(-R[0][2], c2);
   }
-  const float s1 = std::sin(r0), c1 = std::cos(r0);
-  const float r2 = std::atan2(s1 * R[2][0] - c1 * R[1][0], c1 * R[1][1] - s1 * R[2][1]);
+  const float s1 = sin_f(r0), c1 = cos_f(r0);
+  const float r2 = atan2_f(s1 * R[2][0] - c1 * R[1][0], c1 * R[1][1] - s1 * R[2][1]);
   out[0] = -r0, out[1] = -r1, out[2] = -r2;
 }
 
