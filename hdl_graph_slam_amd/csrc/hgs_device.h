@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "hgs_gicp.h"
 #include "hgs_ndt.h"
+#include "hgs_vgicp.h"
 
 namespace hgs {
 
@@ -14,7 +15,11 @@ struct CloudMeta {
   unsigned bbmax[3];
   int ndt_min_b[3], ndt_max_b[3], ndt_div_mul[3];
   int ndt_error;         // 1: voxel grid larger than INT_MAX cells (upstream aborts)
-  int pad[3];
+  // VGICP Gaussian voxel map of this cloud as a target (hgs_vgicp.h): same roles as the ndt_* fields
+  int vg_ncells;
+  int vg_min_b[3], vg_max_b[3], vg_div_mul[3];
+  int vg_error;
+  int pad[1];
 };
 
 // Read-only description of one cloud resident in HBM.
@@ -92,6 +97,15 @@ void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView
 void launch_ndt_solve(hipStream_t s, const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c, const double* partials, int max_blocks,
                       int B, int* done_counter);
 void launch_ndt_results(hipStream_t s, const CloudDesc* descs, const NdtState* states, DevResult* out, int B);
+
+void launch_vgicp_grid_params(hipStream_t s, CloudDesc desc, double resolution);
+void launch_vgicp_cell_keys(hipStream_t s, CloudDesc desc, double resolution, unsigned long long* keys, unsigned* vals);
+void launch_vgicp_build_cells(hipStream_t s, CloudDesc desc, const unsigned long long* sorted_keys, const unsigned* sorted_vals, int* hash_keys,
+                              int* hash_vals, int hash_mask, NdtCellRec* cells);
+void launch_vgicp_linearize(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const GicpState* states, VgicpConsts c, double* partials,
+                            int max_blocks, int B);
+void launch_vgicp_error(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const GicpState* states, VgicpConsts c, double* partials_err,
+                        int max_blocks, int B);
 
 // stage-level test hooks
 void launch_gicp_debug_state(hipStream_t s, GicpState* st, const double* T12_dev);

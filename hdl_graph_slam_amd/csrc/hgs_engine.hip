@@ -103,6 +103,15 @@ struct hgs_cloud {
   int* ndt_hash_vals = nullptr;
   NdtCellRec* ndt_cells = nullptr;
   int ndt_hash_cap = 0;
+  // VGICP Gaussian voxel map (target role)
+  bool has_vg = false;
+  double vg_resolution = 0;
+  int vg_cov_k = 0;
+  void* vg_block = nullptr;
+  int* vg_hash_keys = nullptr;
+  int* vg_hash_vals = nullptr;
+  NdtCellRec* vg_cells = nullptr;
+  int vg_hash_cap = 0;
 };
 
 struct ProfEvent {
@@ -223,6 +232,7 @@ void cloud_free(hgs_cloud* c) {
   if (!c) return;
   if (c->block) (void)hipFree(c->block);
   if (c->ndt_block) (void)hipFree(c->ndt_block);
+  if (c->vg_block) (void)hipFree(c->vg_block);
   delete c;
 }
 
@@ -366,6 +376,74 @@ int ensure_ndt_target(hgs_handle* h, hgs_cloud* c) {
   return HGS_OK;
 }
 
+// FastVGICP's GaussianVoxelMap of the target (needs the target's kNN covariances first).  Upstream rebuilds it at
+// the start of every align(); the result only depends on (target, resolution, k), so it is cached on the cloud.
+int ensure_vgicp_target(hgs_handle* h, hgs_cloud* c) {
+  const double res = h->prm.resolution;
+  const int k = h->prm.correspondence_randomness;
+  if (c->has_vg && c->vg_resolution == res && c->vg_cov_k == k) return HGS_OK;
+  StageTimer tm(h, HGS_STAGE_VOXELIZE);
+  const size_t n = c->n_input;
+  const int max_cells = (int)n + 1;
+  const int cap = next_pow2(std::max<int>(64, 2 * max_cells));
+  if (!c->vg_block || c->vg_hash_cap != cap) {
+    if (c->vg_block) (void)hipFree(c->vg_block);
+    c->vg_block = nullptr;
+    const size_t o_keys = 0, o_vals = align_up((size_t)cap * 4, 256), o_cells = o_vals + align_up((size_t)cap * 4, 256);
+    const size_t bytes = o_cells + (size_t)max_cells * sizeof(NdtCellRec);
+    HGS_HIP(h, hipMalloc(&c->vg_block, bytes));
+    c->vg_hash_keys = (int*)((char*)c->vg_block + o_keys);
+    c->vg_hash_vals = (int*)((char*)c->vg_block + o_vals);
+    c->vg_cells = (NdtCellRec*)((char*)c->vg_block + o_cells);
+    c->vg_hash_cap = cap;
+  }
+  HGS_HIP(h, hipMemsetAsync(c->vg_hash_keys, 0xff, (size_t)cap * 4, h->stream));
+  launch_vgicp_grid_params(h->stream, c->desc, res);
+  if (n > 0) {
+    for (int i = 0; i < 2; i++) {
+      HGS_HIP(h, h->sort_keys[i].reserve(n * sizeof(uint64_t)));
+      HGS_HIP(h, h->sort_vals[i].reserve(n * sizeof(uint32_t)));
+    }
+    launch_vgicp_cell_keys(h->stream, c->desc, res, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
+    size_t tmp_bytes = 0;
+    int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                    h->sort_vals[1].as<uint32_t>(), n, 0, 32, h->stream);
+    if (rc != 0) {
+      h->err = "rocprim radix_sort_pairs (size query) failed";
+      return HGS_ERR_HIP;
+    }
+    HGS_HIP(h, h->sort_tmp.reserve(tmp_bytes));
+    rc = hgs_sort_pairs_u64_u32(h->sort_tmp.p, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                h->sort_vals[1].as<uint32_t>(), n, 0, 32, h->stream);
+    if (rc != 0) {
+      h->err = "rocprim radix_sort_pairs failed";
+      return HGS_ERR_HIP;
+    }
+    launch_vgicp_build_cells(h->stream, c->desc, h->sort_keys[1].as<unsigned long long>(), h->sort_vals[1].as<unsigned>(), c->vg_hash_keys,
+                             c->vg_hash_vals, cap - 1, c->vg_cells);
+  }
+  HGS_HIP(h, hipGetLastError());
+  c->has_vg = true;
+  c->vg_resolution = res;
+  c->vg_cov_k = k;
+  return HGS_OK;
+}
+
+NdtTargetView vgicp_target_view(const hgs_cloud* t) {
+  NdtTargetView tv;
+  tv.hash_keys = t->vg_hash_keys, tv.hash_vals = t->vg_hash_vals, tv.cells = t->vg_cells, tv.meta = t->desc.meta;
+  tv.hash_mask = t->vg_hash_cap - 1, tv.inv_leaf = 0.f;
+  return tv;
+}
+
+VgicpConsts vgicp_consts(const hgs_params& p) {
+  VgicpConsts c;
+  c.resolution = p.resolution;
+  c.search = p.neighbor_search == HGS_DIRECT27 ? 3 : (p.neighbor_search == HGS_DIRECT7 ? 2 : 1);
+  c.pad = 0;
+  return c;
+}
+
 TargetView target_view(const hgs_cloud* c) {
   TargetView t;
   t.nodes = c->desc.nodes, t.pts = c->desc.pts, t.cov = c->desc.cov, t.meta = c->desc.meta, t.P = c->P, t.pad = 0;
@@ -416,14 +494,11 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   const int B = (int)sources.size();
   hgs_cloud* tgt = h->target;
   const int method = h->prm.method;
-  if (method == HGS_FAST_VGICP) {
-    h->err = "FAST_VGICP is not implemented on the device yet";
-    return HGS_ERR_UNSUPPORTED;
-  }
   std::vector<hgs_cloud*> all(sources);
-  if (method == HGS_FAST_GICP) {
+  if (method == HGS_FAST_GICP || method == HGS_FAST_VGICP) {
     all.push_back(tgt);
     HGS_TRY(ensure_cov(h, all, h->prm.correspondence_randomness));
+    if (method == HGS_FAST_VGICP) HGS_TRY(ensure_vgicp_target(h, tgt));
   } else {
     HGS_TRY(ensure_ndt_target(h, tgt));
   }
@@ -439,19 +514,23 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   HGS_HIP(h, h->partials.reserve((size_t)B * max_blocks * kAccNdt * sizeof(double)));
   HGS_HIP(h, h->partials_err.reserve((size_t)B * max_blocks * 2 * sizeof(double)));
   int done = 0;
-  if (method == HGS_FAST_GICP) {
+  if (method == HGS_FAST_GICP || method == HGS_FAST_VGICP) {
+    const bool voxel = method == HGS_FAST_VGICP;
     const GicpConsts c = gicp_consts(h->prm);
+    const VgicpConsts vc = vgicp_consts(h->prm);
     HGS_HIP(h, h->states.reserve((size_t)B * sizeof(GicpState)));
     GicpState* st = h->states.as<GicpState>();
     launch_gicp_init(h->stream, st, h->guesses.as<float>(), B, h->done.as<int>());
     const TargetView tv = target_view(tgt);
+    const NdtTargetView vtv = voxel ? vgicp_target_view(tgt) : NdtTargetView{};
     const long max_rounds = (long)std::max(1, c.max_iterations) * std::max(1, c.lm_max_iterations) + 2;
     long round = 0;
     int next_check = 3;
     while (round < max_rounds) {
       {
         StageTimer tm(h, HGS_STAGE_LINEARIZE);
-        launch_gicp_linearize(h->stream, d_descs, tv, st, c, h->partials.as<double>(), max_blocks, B);
+        if (voxel) launch_vgicp_linearize(h->stream, d_descs, vtv, st, vc, h->partials.as<double>(), max_blocks, B);
+        else launch_gicp_linearize(h->stream, d_descs, tv, st, c, h->partials.as<double>(), max_blocks, B);
       }
       {
         StageTimer tm(h, HGS_STAGE_SOLVE);
@@ -459,7 +538,8 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       }
       {
         StageTimer tm(h, HGS_STAGE_ERROR);
-        launch_gicp_error(h->stream, d_descs, tv, st, h->partials_err.as<double>(), max_blocks, B);
+        if (voxel) launch_vgicp_error(h->stream, d_descs, vtv, st, vc, h->partials_err.as<double>(), max_blocks, B);
+        else launch_gicp_error(h->stream, d_descs, tv, st, h->partials_err.as<double>(), max_blocks, B);
       }
       {
         StageTimer tm(h, HGS_STAGE_SOLVE);
@@ -695,7 +775,7 @@ size_t hgs_cloud_size(const hgs_cloud* c) { return c ? c->n_input : 0; }
 
 int hgs_cloud_invalidate(hgs_cloud* c) {
   if (!c) return HGS_ERR_INVALID_ARGUMENT;
-  c->has_index = false, c->has_cov = false, c->has_ndt = false;
+  c->has_index = false, c->has_cov = false, c->has_ndt = false, c->has_vg = false;
   return HGS_OK;
 }
 
@@ -924,13 +1004,15 @@ int hgs_debug_target_covariances(hgs_handle* h, float* out6) {
 
 int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, double* b6, double* err, int32_t* corr) {
   if (!h || !T12 || !H36 || !b6 || !err) return HGS_ERR_INVALID_ARGUMENT;
-  if (h->prm.method != HGS_FAST_GICP) return HGS_ERR_UNSUPPORTED;
+  if (h->prm.method != HGS_FAST_GICP && h->prm.method != HGS_FAST_VGICP) return HGS_ERR_UNSUPPORTED;
   if (!h->target) return HGS_ERR_NO_TARGET;
   if (!h->source) return HGS_ERR_NO_SOURCE;
   HGS_TRY(set_device(h));
   hgs_cloud *s = h->source, *t = h->target;
+  const bool voxel = h->prm.method == HGS_FAST_VGICP;
   std::vector<hgs_cloud*> all{s, t};
   HGS_TRY(ensure_cov(h, all, h->prm.correspondence_randomness));
+  if (voxel) HGS_TRY(ensure_vgicp_target(h, t));
   const int max_blocks = std::max(1, ((int)s->n_input + kBlock - 1) / kBlock);
   std::vector<hgs_cloud*> src{s};
   const CloudDesc* d_descs = nullptr;
@@ -941,7 +1023,8 @@ int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, d
   HGS_HIP(h, hipMemsetAsync(h->partials.p, 0, (size_t)max_blocks * kAcc * sizeof(double), h->stream));
   HGS_HIP(h, hipMemcpyAsync(h->misc.p, T12, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   launch_gicp_debug_state(h->stream, h->states.as<GicpState>(), h->misc.as<double>());
-  launch_gicp_linearize(h->stream, d_descs, target_view(t), h->states.as<GicpState>(), gicp_consts(h->prm), h->partials.as<double>(), max_blocks, 1);
+  if (voxel) launch_vgicp_linearize(h->stream, d_descs, vgicp_target_view(t), h->states.as<GicpState>(), vgicp_consts(h->prm), h->partials.as<double>(), max_blocks, 1);
+  else launch_gicp_linearize(h->stream, d_descs, target_view(t), h->states.as<GicpState>(), gicp_consts(h->prm), h->partials.as<double>(), max_blocks, 1);
   double* d_out = h->misc.as<double>() + 16;
   launch_reduce_partials(h->stream, h->partials.as<double>(), max_blocks, kAcc, d_out);
   double acc[kAcc];
@@ -964,12 +1047,13 @@ int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, d
   for (int i = 0; i < 6; i++) b6[i] = acc[21 + i];
   *err = acc[27];
   if (corr) {
-    for (size_t i = 0; i < s->n_input; i++) corr[i] = -1;
+    for (size_t i = 0; i < s->n_input; i++) corr[i] = voxel ? 0 : -1;
     for (int i = 0; i < s_nvalid; i++) {
       int so, to = -1;
       std::memcpy(&so, &spts[i].w, 4);
       const int j = dcorr[i];
-      if (j >= 0 && (size_t)j < t_slots) std::memcpy(&to, &tpts[j].w, 4);
+      if (voxel) to = j;  // VGICP: number of voxel correspondences of that source point
+      else if (j >= 0 && (size_t)j < t_slots) std::memcpy(&to, &tpts[j].w, 4);
       if (so >= 0 && (size_t)so < s->n_input) corr[so] = to;
     }
   }

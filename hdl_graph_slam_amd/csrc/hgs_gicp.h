@@ -50,11 +50,11 @@ HGS_HD Sym3 gicp_mahalanobis(const double* R /*3x3 row-major*/, const Sym3& ca, 
 
 // residual e = b - T a, returns e^T M e; optionally adds J^T M J, J^T M e (J = [skew(Ta) | -I]) to acc[28]
 template <bool WITH_JACOBIAN>
-HGS_HD double gicp_point_terms(const Pose& T, const Sym3& M, float ax, float ay, float az, float bx, float by, float bz, double* acc) {
+HGS_HD double gicp_point_terms(const Pose& T, const Sym3& M, float ax, float ay, float az, double bx, double by, double bz, double* acc) {
   const double x = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];
   const double y = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
   const double z = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
-  const double ex = (double)bx - x, ey = (double)by - y, ez = (double)bz - z;
+  const double ex = bx - x, ey = by - y, ez = bz - z;
   const double mex = M.xx * ex + M.xy * ey + M.xz * ez;
   const double mey = M.xy * ex + M.yy * ey + M.yz * ez;
   const double mez = M.xz * ex + M.yz * ey + M.zz * ez;

@@ -694,6 +694,153 @@ void launch_ndt_results(hipStream_t s, const CloudDesc* descs, const NdtState* s
   hipLaunchKernelGGL(k_ndt_results, dim3((B + 63) / 64), dim3(64), 0, s, descs, states, out, B);
 }
 
+// ------------------------------------------------------------------------------------------------ VGICP (fast_gicp::FastVGICP)
+// Target voxelisation (GaussianVoxelMap, ADDITIVE): voxel = {n, mean of the points, mean of their GICP covariances}.
+// Same sort-by-cell + segment-head machinery as the NDT target; the points are taken in Hilbert order because the
+// covariances live there (the per-voxel sums are re-associated relative to upstream's input order, nothing else).
+__global__ void k_vgicp_grid_params(CloudDesc d, double resolution) {
+  CloudMeta* m = d.meta;
+  m->vg_ncells = 0;
+  m->vg_error = 0;
+  if (m->nvalid <= 0) {
+    for (int k = 0; k < 3; k++) m->vg_min_b[k] = 0, m->vg_max_b[k] = -1, m->vg_div_mul[k] = 0;
+    return;
+  }
+  long long div[3];
+  for (int k = 0; k < 3; k++) {
+    m->vg_min_b[k] = vgicp_coord((double)ord2f(m->bbmin[k]), resolution);
+    m->vg_max_b[k] = vgicp_coord((double)ord2f(m->bbmax[k]), resolution);
+    div[k] = (long long)m->vg_max_b[k] - m->vg_min_b[k] + 1;
+  }
+  if (div[0] * div[1] * div[2] > 2147483647LL) m->vg_error = 1;
+  m->vg_div_mul[0] = 1, m->vg_div_mul[1] = (int)div[0], m->vg_div_mul[2] = (int)(div[0] * div[1]);
+}
+void launch_vgicp_grid_params(hipStream_t s, CloudDesc desc, double resolution) {
+  hipLaunchKernelGGL(k_vgicp_grid_params, dim3(1), dim3(1), 0, s, desc, resolution);
+}
+
+__global__ __launch_bounds__(kBlock) void k_vgicp_cell_keys(CloudDesc d, double resolution, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= d.n_input) return;
+  unsigned long long key = 0xffffffffull;
+  const CloudMeta* m = d.meta;
+  if (i < m->nvalid && !m->vg_error) {
+    const float4 p = d.pts[i];
+    const int cx = vgicp_coord((double)p.x, resolution) - m->vg_min_b[0];
+    const int cy = vgicp_coord((double)p.y, resolution) - m->vg_min_b[1];
+    const int cz = vgicp_coord((double)p.z, resolution) - m->vg_min_b[2];
+    key = (unsigned long long)(unsigned)(cx * m->vg_div_mul[0] + cy * m->vg_div_mul[1] + cz * m->vg_div_mul[2]);
+  }
+  keys[i] = key;
+  vals[i] = (unsigned)i;
+}
+void launch_vgicp_cell_keys(hipStream_t s, CloudDesc desc, double resolution, unsigned long long* keys, unsigned* vals) {
+  if (desc.n_input <= 0) return;
+  hipLaunchKernelGGL(k_vgicp_cell_keys, dim3((desc.n_input + kBlock - 1) / kBlock), dim3(kBlock), 0, s, desc, resolution, keys, vals);
+}
+
+__global__ __launch_bounds__(kBlock) void k_vgicp_build_cells(CloudDesc d, const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                              int* hash_keys, int* hash_vals, int hash_mask, NdtCellRec* cells) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= d.n_input) return;
+  const unsigned long long key = keys[i];
+  if (key == 0xffffffffull) return;
+  if (i > 0 && keys[i - 1] == key) return;
+  double sum[3] = {0, 0, 0};
+  Sym3 sc = {0, 0, 0, 0, 0, 0};
+  int n = 0;
+  for (int j = i; j < d.n_input && keys[j] == key; j++) {
+    const int pi = (int)vals[j];
+    const float4 p = d.pts[pi];
+    const float4 c0 = d.cov[2 * pi], c1 = d.cov[2 * pi + 1];
+    sum[0] += (double)p.x, sum[1] += (double)p.y, sum[2] += (double)p.z;
+    sc.xx += (double)c0.x, sc.xy += (double)c0.y, sc.xz += (double)c0.z, sc.yy += (double)c0.w, sc.yz += (double)c1.x, sc.zz += (double)c1.y;
+    n++;
+  }
+  NdtCellRec rec;
+  vgicp_finalize_voxel(n, sum, sc, (int)key, &rec);
+  const int slot_c = atomicAdd(&d.meta->vg_ncells, 1);
+  cells[slot_c] = rec;
+  unsigned slot = (ndt_hash((int)key) >> 7) & (unsigned)hash_mask;
+  for (;;) {
+    const int prev = atomicCAS(&hash_keys[slot], -1, (int)key);
+    if (prev == -1) {
+      hash_vals[slot] = slot_c;
+      break;
+    }
+    slot = (slot + 1) & (unsigned)hash_mask;
+  }
+}
+void launch_vgicp_build_cells(hipStream_t s, CloudDesc desc, const unsigned long long* sorted_keys, const unsigned* sorted_vals, int* hash_keys,
+                              int* hash_vals, int hash_mask, NdtCellRec* cells) {
+  if (desc.n_input <= 0) return;
+  hipLaunchKernelGGL(k_vgicp_build_cells, dim3((desc.n_input + kBlock - 1) / kBlock), dim3(kBlock), 0, s, desc, sorted_keys, sorted_vals, hash_keys,
+                     hash_vals, hash_mask, cells);
+}
+
+__device__ __forceinline__ NdtGrid vgicp_grid_of(const NdtTargetView& tgt) {
+  NdtGrid g;
+  g.hash_keys = tgt.hash_keys, g.hash_vals = tgt.hash_vals, g.cells = tgt.cells, g.hash_mask = tgt.hash_mask, g.inv_leaf = 0.f;
+  for (int k = 0; k < 3; k++) g.min_b[k] = tgt.meta->vg_min_b[k], g.max_b[k] = tgt.meta->vg_max_b[k], g.div_mul[k] = tgt.meta->vg_div_mul[k];
+  return g;
+}
+
+// update_correspondences + linearize of FastVGICP fused.  Algorithmic bytes per source point (DIRECT1):
+// 16 (a_i) + 24 (C_A) + 40 (voxel: mean 12, cov 24, n 4) = 80; the voxel table of a LiDAR scan is L2-resident.
+__global__ __launch_bounds__(kBlock) void k_vgicp_linearize(const CloudDesc* descs, NdtTargetView tgt, const GicpState* states, VgicpConsts c,
+                                                            double* __restrict__ partials, int max_blocks) {
+  const int b = blockIdx.y;
+  if (states[b].phase != GICP_LINEARIZE) return;
+  const CloudDesc d = descs[b];
+  const int n = d.meta->nvalid;
+  const int ntiles = (n + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int i = tile * kBlock + threadIdx.x;
+  __shared__ double lds[4 * kAcc];
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+  if (i < n) {
+    const Pose T = states[b].x0;
+    const NdtGrid g = vgicp_grid_of(tgt);
+    const float4 a = d.pts[i];
+    int hits;
+    acc[27] = vgicp_point_terms<true>(g, c, T, T, load_cov(d.cov, i), a.x, a.y, a.z, acc, &hits);
+    d.corr[i] = hits;
+  }
+  block_reduce_store<kAcc>(acc, partials + ((size_t)b * max_blocks + tile) * kAcc, lds);
+}
+void launch_vgicp_linearize(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const GicpState* states, VgicpConsts c, double* partials,
+                            int max_blocks, int B) {
+  hipLaunchKernelGGL(k_vgicp_linearize, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks);
+}
+
+// compute_error(xi): voxels and Mahalanobis matrices of the linearisation pose x0, residuals at the LM trial pose xi.
+__global__ __launch_bounds__(kBlock) void k_vgicp_error(const CloudDesc* descs, NdtTargetView tgt, const GicpState* states, VgicpConsts c,
+                                                        double* __restrict__ partials_err, int max_blocks) {
+  const int b = blockIdx.y;
+  if (states[b].phase != GICP_TRY) return;
+  const CloudDesc d = descs[b];
+  const int n = d.meta->nvalid;
+  const int ntiles = (n + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int i = tile * kBlock + threadIdx.x;
+  __shared__ double lds[4];
+  double err = 0.0;
+  if (i < n && d.corr[i] > 0) {
+    const NdtGrid g = vgicp_grid_of(tgt);
+    const float4 a = d.pts[i];
+    err = vgicp_point_terms<false>(g, c, states[b].x0, states[b].xi, load_cov(d.cov, i), a.x, a.y, a.z, nullptr, nullptr);
+  }
+  block_reduce_store<1>(&err, partials_err + (size_t)b * max_blocks + tile, lds);
+}
+void launch_vgicp_error(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const GicpState* states, VgicpConsts c, double* partials_err,
+                        int max_blocks, int B) {
+  hipLaunchKernelGGL(k_vgicp_error, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, c, partials_err, max_blocks);
+}
+
 }  // namespace hgs
 
 // ------------------------------------------------------------------------------------------------ stage-level test hooks

@@ -73,6 +73,31 @@ def test_gicp_lm_rejection_path(gicp_case):
     assert ro.lm_tries >= ro.iterations
 
 
+@pytest.fixture(scope="module", params=[("hdl32", 1.0, O.HGS_DIRECT1), ("vlp16", 0.5, O.HGS_DIRECT7), ("dense", 1.0, O.HGS_DIRECT27)])
+def vgicp_case(request):
+    kind, res, search = request.param
+    tgt, src, T = _pair(kind)
+    p = O.default_params(O.HGS_FAST_VGICP)
+    p.resolution, p.neighbor_search = res, search
+    e, o = emul.EmulRegistration(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    return e, o, tgt, src, T
+
+
+def test_vgicp_linearize(vgicp_case):
+    """Voxel lookups (number of voxel correspondences per source point) bit-exact; H, b, error to float-covariance accuracy."""
+    e, o, tgt, src, T = vgicp_case
+    PC.check_gicp_linearize(e, o, T.astype(np.float32).astype(np.float64))
+    PC.check_gicp_linearize(e, o, np.eye(4))
+
+
+@pytest.mark.parametrize("guess_kind", ["identity", "near"])
+def test_vgicp_align(vgicp_case, guess_kind):
+    e, o, tgt, src, T = vgicp_case
+    guess = np.eye(4) if guess_kind == "identity" else T @ synth.pose_matrix([0.2, -0.1, 0.02], [0.002, -0.003, 0.015])
+    PC.check_align(e, o, guess, tol_m=1e-5, tol_rad=2e-5)
+
+
 @pytest.fixture(scope="module", params=[("hdl32", 1.0, O.HGS_DIRECT7), ("hdl32", 0.5, O.HGS_DIRECT1), ("vlp16", 1.0, O.HGS_DIRECT7)])
 def ndt_case(request):
     kind, res, search = request.param

@@ -105,6 +105,36 @@ def test_gicp_point_order_invariance(gicp_case):
     assert dt < 1e-5 and dr < 1e-5
 
 
+@pytest.fixture(scope="module", params=[("hdl32", 1.0, O.HGS_DIRECT1), ("vlp16", 0.5, O.HGS_DIRECT7), ("dense", 1.0, O.HGS_DIRECT27), ("hdl32_raw", 1.0, O.HGS_DIRECT1)])
+def vgicp_case(request):
+    kind, res, search = request.param
+    tgt, src, T = _pair(kind)
+    p = O.default_params(O.HGS_FAST_VGICP)
+    p.resolution, p.neighbor_search = res, search
+    e, o = _hip(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    yield e, o, tgt, src, T
+    e.close()
+
+
+def test_vgicp_linearize(vgicp_case):
+    """FastVGICP (registrations.cpp:48-56): voxel lookups bit-exact (count of voxel correspondences per source point),
+    H / b / error to the accuracy of the float-stored covariances."""
+    e, o, tgt, src, T = vgicp_case
+    PC.check_gicp_linearize(e, o, T.astype(np.float32).astype(np.float64))
+    PC.check_gicp_linearize(e, o, np.eye(4))
+
+
+@pytest.mark.parametrize("guess_kind", ["identity", "near"])
+def test_vgicp_align(vgicp_case, guess_kind):
+    e, o, tgt, src, T = vgicp_case
+    guess = np.eye(4) if guess_kind == "identity" else T @ synth.pose_matrix([0.2, -0.1, 0.02], [0.002, -0.003, 0.015])
+    re, ro = PC.check_align(e, o, guess, tol_m=1e-5, tol_rad=1e-5)
+    PC.check_fitness(e, o, ro.matrix())
+    a = e.align(guess)
+    assert bytes(a.final_transformation) == bytes(re.final_transformation)   # run-to-run determinism
+
+
 @pytest.fixture(scope="module", params=[("hdl32", 1.0, O.HGS_DIRECT7), ("hdl32", 0.5, O.HGS_DIRECT1), ("vlp16", 1.0, O.HGS_DIRECT7), ("hdl32_raw", 1.0, O.HGS_DIRECT7)])
 def ndt_case(request):
     kind, res, search = request.param
