@@ -8,10 +8,14 @@
 //
 // Layout in HBM (per cloud):
 //   pts   : float4[P*LEAF]   sorted along a 48-bit Hilbert curve; .w = original index (int bits); padding = +inf
-//   nodes : float4[4*P]      node n (1 <= n < 2P) has AABB {nodes[2n] = min.xyz, nodes[2n+1] = max.xyz};
-//                            children of n are 2n, 2n+1, so both child boxes are one aligned 64-byte read at 4n.
-//                            Leaves are nodes P..2P-1; leaf l owns pts[l*LEAF .. l*LEAF+LEAF).  Empty nodes have
-//                            min = +inf, max = -inf (box distance = +inf, never visited).
+//   lpts  : float[P*32]      the same points leaf by leaf in SoA form {x[8], y[8], z[8], w[8]} (128 bytes per leaf):
+//                            what the wave-cooperative walk reads (scalar loads, adjacent lanes of packed-fp32 math)
+//   nodes : float[(P/2)*32]  heap-ordered tree, node n (1 <= n < 2P), children 2n, 2n+1, leaves P..2P-1 (leaf l owns
+//                            pts[l*LEAF .. l*LEAF+LEAF)).  Boxes are stored in GROUPS of four siblings-of-siblings:
+//                            group G holds nodes 4G..4G+3 — exactly the four grandchildren of node G — as one aligned
+//                            128-byte record {mnx[4], mny[4], mnz[4], mxx[4], mxy[4], mxz[4], pad[8]}, so a 4-ary
+//                            step of the walk is one load and its box arithmetic pairs up for v_pk_*_f32.
+//                            Empty nodes have min = +inf, max = -inf (box distance = +inf, never visited).
 #pragma once
 #include "hgs_math.h"
 
@@ -28,11 +32,29 @@ struct alignas(16) Float4 {
 #endif
 
 struct BvhView {
-  const Float4* nodes;
+  const Float4* nodes;  // grouped boxes, 8 Float4 per group
   const Float4* pts;
+  const Float4* lpts;   // SoA leaves, 8 Float4 per leaf (may be null where only the per-lane search is used)
   int P;       // number of leaves (power of two)
   int n;       // number of valid (finite) points
 };
+
+// box of node n inside the grouped layout
+HGS_HD void bvh_load_box(const Float4* nodes, uint32_t n, float* mn, float* mx) {
+  const float* g = reinterpret_cast<const float*>(nodes) + 32 * (size_t)(n >> 2) + (n & 3u);
+  mn[0] = g[0], mn[1] = g[4], mn[2] = g[8];
+  mx[0] = g[12], mx[1] = g[16], mx[2] = g[20];
+}
+HGS_HD void bvh_store_box(Float4* nodes, uint32_t n, const float* mn, const float* mx) {
+  float* g = reinterpret_cast<float*>(nodes) + 32 * (size_t)(n >> 2) + (n & 3u);
+  g[0] = mn[0], g[4] = mn[1], g[8] = mn[2];
+  g[12] = mx[0], g[16] = mx[1], g[20] = mx[2];
+}
+HGS_HD float bvh_box_dist2(const Float4* nodes, uint32_t n, const F3& q) {
+  float mn[3], mx[3];
+  bvh_load_box(nodes, n, mn, mx);
+  return box_dist2f(q, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]);
+}
 
 HGS_HD int float_as_int_hd(float f) {
   union {
@@ -74,10 +96,8 @@ HGS_HD int bvh_nn1(const BvhView& t, const F3& q, float bound2, float* out_d2, i
   for (;;) {
     bool pruned = false;
     while ((int)node < t.P) {
-      const Float4 a0 = t.nodes[4 * node + 0], a1 = t.nodes[4 * node + 1];
-      const Float4 b0 = t.nodes[4 * node + 2], b1 = t.nodes[4 * node + 3];
-      const float d0 = box_dist2f(q, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z);
-      const float d1 = box_dist2f(q, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
+      const float d0 = bvh_box_dist2(t.nodes, 2 * node, q);
+      const float d1 = bvh_box_dist2(t.nodes, 2 * node + 1, q);
       const int near = d1 < d0 ? 1 : 0;
       const float dn = near ? d1 : d0, df = near ? d0 : d1;
       if (!(dn <= best)) {
@@ -113,8 +133,7 @@ HGS_HD int bvh_nn1(const BvhView& t, const F3& q, float bound2, float* out_d2, i
       pending ^= 1u << lvl;
       node = (node >> (depth - lvl)) ^ 1u;
       depth = lvl;
-      const Float4 m0 = t.nodes[2 * node], m1 = t.nodes[2 * node + 1];
-      if (box_dist2f(q, m0.x, m0.y, m0.z, m1.x, m1.y, m1.z) <= best) break;
+      if (bvh_box_dist2(t.nodes, node, q) <= best) break;
     }
   }
 }
@@ -133,18 +152,24 @@ struct KnnList {
     }
   }
   HGS_HD float worst() const { return d[KMAX - 1]; }
+  // Sorted insertion without a carried element: with d ascending, the new d[i] is the median of (d[i-1], d[i], dist)
+  // — one v_med3_f32 per slot — and pos[i] follows the two comparison masks.  Equal distances keep arrival order.
   HGS_HD void insert(float dist, int p) {
     // caller guarantees dist < worst()
-    d[KMAX - 1] = dist;
-    pos[KMAX - 1] = p;
+    bool c_hi = dist < d[KMAX - 1];
 #pragma unroll
     for (int i = KMAX - 1; i > 0; i--) {
-      const bool sw = d[i] < d[i - 1];
-      const float dl = sw ? d[i] : d[i - 1], dh = sw ? d[i - 1] : d[i];
-      const int pl = sw ? pos[i] : pos[i - 1], ph = sw ? pos[i - 1] : pos[i];
-      d[i - 1] = dl, d[i] = dh;
-      pos[i - 1] = pl, pos[i] = ph;
+      const bool c_lo = dist < d[i - 1];
+      pos[i] = c_lo ? pos[i - 1] : (c_hi ? p : pos[i]);
+#if defined(__HIP_DEVICE_COMPILE__)
+      d[i] = __builtin_amdgcn_fmed3f(d[i - 1], d[i], dist);
+#else
+      d[i] = fmaxf(d[i - 1], fminf(d[i], dist));
+#endif
+      c_hi = c_lo;
     }
+    pos[0] = c_hi ? p : pos[0];
+    d[0] = fminf(d[0], dist);
   }
 };
 
@@ -157,10 +182,8 @@ HGS_HD void bvh_knn(const BvhView& t, const F3& q, int k, KnnList<KMAX>& list) {
   for (;;) {
     bool pruned = false;
     while ((int)node < t.P) {
-      const Float4 a0 = t.nodes[4 * node + 0], a1 = t.nodes[4 * node + 1];
-      const Float4 b0 = t.nodes[4 * node + 2], b1 = t.nodes[4 * node + 3];
-      const float d0 = box_dist2f(q, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z);
-      const float d1 = box_dist2f(q, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
+      const float d0 = bvh_box_dist2(t.nodes, 2 * node, q);
+      const float d1 = bvh_box_dist2(t.nodes, 2 * node + 1, q);
       const int near = d1 < d0 ? 1 : 0;
       const float dn = near ? d1 : d0, df = near ? d0 : d1;
       if (!(dn < list.worst())) {
@@ -186,8 +209,7 @@ HGS_HD void bvh_knn(const BvhView& t, const F3& q, int k, KnnList<KMAX>& list) {
       pending ^= 1u << lvl;
       node = (node >> (depth - lvl)) ^ 1u;
       depth = lvl;
-      const Float4 m0 = t.nodes[2 * node], m1 = t.nodes[2 * node + 1];
-      if (box_dist2f(q, m0.x, m0.y, m0.z, m1.x, m1.y, m1.z) < list.worst()) break;
+      if (bvh_box_dist2(t.nodes, node, q) < list.worst()) break;
     }
   }
 }

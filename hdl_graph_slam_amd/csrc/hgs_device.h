@@ -26,7 +26,8 @@ struct CloudMeta {
 struct CloudDesc {
   const float4* raw;  // [n_input]  original order, .w = original index (int bits)
   float4* pts;        // [P*kLeaf]  Hilbert order, .w = original index, padding = +inf
-  float4* nodes;      // [4*P]      implicit tree AABBs
+  float4* lpts;       // [P*kLeaf]  the same points as SoA leaves {x[8],y[8],z[8],w[8]} (hgs_bvh.h)
+  float4* nodes;      // [4*P+8]    implicit tree AABBs, grouped 4 nodes per 128-byte record (hgs_bvh.h)
   float4* cov;        // [2*P*kLeaf] GICP covariance of sorted point i: {xx,xy,xz,yy},{yz,zz,0,0}
   int* corr;          // [P*kLeaf]  scratch: correspondence (sorted target position or -1) when used as a source
   CloudMeta* meta;
@@ -39,6 +40,7 @@ struct CloudDesc {
 struct TargetView {
   const float4* nodes;
   const float4* pts;
+  const float4* lpts;
   const float4* cov;
   const CloudMeta* meta;
   int P;
@@ -65,6 +67,8 @@ struct DevResult {
 };
 
 constexpr int kBlock = 256;
+constexpr int kNW = 1;                    // packets of 64 queries a wave walks in lock-step in the 1-NN kernels (hgs_wave_bvh.h)
+constexpr int kTileNN = kBlock * kNW;     // source points per block of k_gicp_linearize / k_fitness
 
 // ---- launchers (hgs_kernels.hip) --------------------------------------------------------------------------
 void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw);
@@ -77,12 +81,14 @@ void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n
 
 void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, int* done_counter);
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B);
-void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B);
+void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
+                       int tile_points /* kTileNN after k_gicp_linearize, kBlock after k_vgicp_linearize */);
 void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B);
 void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B, int* done_counter);
 void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out, int B);
 
-void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks, int B);
+void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks, int B,
+                    int use_seed);
 void launch_fitness_final(hipStream_t s, const CloudDesc* descs, const double* partials, int max_blocks, DevResult* out, int B);
 void launch_nn_query(hipStream_t s, TargetView tgt, const float4* q, int nq, int* idx, float* d2);
 void launch_transform(hipStream_t s, const float4* raw, int n, const float* T16_colmajor_dev, float4* out);

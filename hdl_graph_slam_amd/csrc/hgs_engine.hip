@@ -200,8 +200,10 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   off = align_up(off + std::max<size_t>(n, 1) * sizeof(float4), 256);
   const size_t o_pts = off;
   off = align_up(off + slots * sizeof(float4), 256);
+  const size_t o_lpts = off;
+  off = align_up(off + slots * sizeof(float4), 256);
   const size_t o_nodes = off;
-  off = align_up(off + (size_t)4 * c->P * sizeof(float4), 256);
+  off = align_up(off + ((size_t)4 * c->P + 8) * sizeof(float4), 256);  // + one 128-byte group: the 4-ary walk reads whole groups
   const size_t o_cov = off;
   off = align_up(off + 2 * slots * sizeof(float4), 256);
   const size_t o_corr = off;
@@ -217,6 +219,7 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   c->desc.meta = (CloudMeta*)(base + o_meta);
   c->desc.raw = (const float4*)(base + o_raw);
   c->desc.pts = (float4*)(base + o_pts);
+  c->desc.lpts = (float4*)(base + o_lpts);
   c->desc.nodes = (float4*)(base + o_nodes);
   c->desc.cov = (float4*)(base + o_cov);
   c->desc.corr = (int*)(base + o_corr);
@@ -224,6 +227,7 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   c->desc.P = c->P;
   c->desc.sort_off = 0;
   c->desc.pad = 0;
+  (void)hipMemsetAsync(c->desc.corr, 0xff, slots * sizeof(int), h->stream);  // no correspondences yet (-1)
   *out = c;
   return HGS_OK;
 }
@@ -446,7 +450,7 @@ VgicpConsts vgicp_consts(const hgs_params& p) {
 
 TargetView target_view(const hgs_cloud* c) {
   TargetView t;
-  t.nodes = c->desc.nodes, t.pts = c->desc.pts, t.cov = c->desc.cov, t.meta = c->desc.meta, t.P = c->P, t.pad = 0;
+  t.nodes = c->desc.nodes, t.pts = c->desc.pts, t.lpts = c->desc.lpts, t.cov = c->desc.cov, t.meta = c->desc.meta, t.P = c->P, t.pad = 0;
   return t;
 }
 
@@ -534,7 +538,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       }
       {
         StageTimer tm(h, HGS_STAGE_SOLVE);
-        launch_gicp_solve(h->stream, d_descs, st, c, h->partials.as<double>(), max_blocks, B);
+        launch_gicp_solve(h->stream, d_descs, st, c, h->partials.as<double>(), max_blocks, B, voxel ? kBlock : kTileNN);
       }
       {
         StageTimer tm(h, HGS_STAGE_ERROR);
@@ -601,7 +605,8 @@ int run_fitness(hgs_handle* h, const std::vector<hgs_cloud*>& sources, double ma
   HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
   HGS_HIP(h, h->partials_err.reserve((size_t)B * max_blocks * 2 * sizeof(double)));
   StageTimer tm(h, HGS_STAGE_FITNESS);
-  launch_fitness(h->stream, d_descs, target_view(h->target), h->results.as<DevResult>(), max_range, h->partials_err.as<double>(), max_blocks, B);
+  launch_fitness(h->stream, d_descs, target_view(h->target), h->results.as<DevResult>(), max_range, h->partials_err.as<double>(), max_blocks, B,
+                 h->prm.method == HGS_FAST_GICP ? 1 : 0);
   launch_fitness_final(h->stream, d_descs, h->partials_err.as<double>(), max_blocks, h->results.as<DevResult>(), B);
   HGS_HIP(h, hipGetLastError());
   return HGS_OK;

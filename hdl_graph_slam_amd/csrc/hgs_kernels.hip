@@ -80,7 +80,7 @@ __device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int n
 
 __device__ __forceinline__ BvhView view_of(const TargetView& t) {
   BvhView v;
-  v.nodes = t.nodes, v.pts = t.pts, v.P = t.P, v.n = t.meta->nvalid;
+  v.nodes = t.nodes, v.pts = t.pts, v.lpts = t.lpts, v.P = t.P, v.n = t.meta->nvalid;
   return v;
 }
 
@@ -175,13 +175,24 @@ __global__ __launch_bounds__(kBlock) void k_gather_sorted(const CloudDesc* descs
   float4 p = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(-1));
   if (i < d.meta->nvalid) p = d.raw[sorted_vals[d.sort_off + i]];
   d.pts[i] = p;
+  float* leaf = reinterpret_cast<float*>(d.lpts) + 32 * (size_t)(i >> 3) + (i & 7);  // SoA copy for the wave walk
+  leaf[0] = p.x, leaf[8] = p.y, leaf[16] = p.z, leaf[24] = p.w;
 }
 void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int max_slots, const unsigned* sorted_vals) {
   if (max_slots <= 0) return;
   hipLaunchKernelGGL(k_gather_sorted, dim3((max_slots + kBlock - 1) / kBlock, ncloud), dim3(kBlock), 0, s, descs, sorted_vals);
 }
 
-// Leaves + the 8 tree levels above them: one block owns 256 consecutive leaves, merges in LDS.
+// Slots 0 and 1 of group 0 (node 0 does not exist, node 1 is the root, whose box no search ever tests) hold EMPTY
+// boxes: an odd-height tree starts its 4-ary walk at the virtual node 0, whose group is then {empty, empty, 2, 3}.
+__device__ __forceinline__ void store_walk_sentinels(float4* nodes) {
+  const float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  bvh_store_box(nodes, 0u, mn, mx);
+  bvh_store_box(nodes, 1u, mn, mx);
+}
+
+// Leaves + the 8 tree levels above them: one block owns 256 consecutive leaves, merges in LDS.  Node 0 and the
+// pad floats of the grouped layout are never read as boxes.
 __global__ __launch_bounds__(kBlock) void k_build_bottom(const CloudDesc* descs) {
   const CloudDesc d = descs[blockIdx.y];
   const int P = d.P;
@@ -202,8 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_build_bottom(const CloudDesc* descs)
         mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
       }
     }
-    d.nodes[2 * (P + leaf)] = make_float4(mn[0], mn[1], mn[2], 0.f);
-    d.nodes[2 * (P + leaf) + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+    bvh_store_box(d.nodes, (unsigned)(P + leaf), mn, mx);
   }
   for (int k = 0; k < 3; k++) smn[0][t][k] = mn[k], smx[0][t][k] = mx[k];
   int cur = 0, width = P < kBlock ? P : kBlock, level_nodes = P, first = leaf0;
@@ -220,13 +230,12 @@ __global__ __launch_bounds__(kBlock) void k_build_bottom(const CloudDesc* descs)
         smn[cur ^ 1][t][k] = a[k];
         smx[cur ^ 1][t][k] = b[k];
       }
-      const int id = level_nodes + first + t;
-      d.nodes[2 * id] = make_float4(a[0], a[1], a[2], 0.f);
-      d.nodes[2 * id + 1] = make_float4(b[0], b[1], b[2], 0.f);
+      bvh_store_box(d.nodes, (unsigned)(level_nodes + first + t), a, b);
     }
     cur ^= 1;
     width = nw;
   }
+  if (t == 0 && P <= kBlock) store_walk_sentinels(d.nodes);
 }
 // Remaining top levels (only when P > 256): one block per cloud walks them level by level.
 __global__ __launch_bounds__(kBlock) void k_build_top(const CloudDesc* descs) {
@@ -234,13 +243,17 @@ __global__ __launch_bounds__(kBlock) void k_build_top(const CloudDesc* descs) {
   if (d.P <= kBlock) return;
   for (int level_nodes = (d.P / kBlock) >> 1; level_nodes >= 1; level_nodes >>= 1) {
     for (int t = threadIdx.x; t < level_nodes; t += kBlock) {
-      const int id = level_nodes + t;
-      const float4 a0 = d.nodes[4 * id], a1 = d.nodes[4 * id + 1], b0 = d.nodes[4 * id + 2], b1 = d.nodes[4 * id + 3];
-      d.nodes[2 * id] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0.f);
-      d.nodes[2 * id + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0.f);
+      const unsigned id = (unsigned)(level_nodes + t);
+      float amn[3], amx[3], bmn[3], bmx[3];
+      bvh_load_box(d.nodes, 2 * id, amn, amx);
+      bvh_load_box(d.nodes, 2 * id + 1, bmn, bmx);
+      const float mn[3] = {fminf(amn[0], bmn[0]), fminf(amn[1], bmn[1]), fminf(amn[2], bmn[2])};
+      const float mx[3] = {fmaxf(amx[0], bmx[0]), fmaxf(amx[1], bmx[1]), fmaxf(amx[2], bmx[2])};
+      bvh_store_box(d.nodes, id, mn, mx);
     }
     __syncthreads();
   }
+  if (threadIdx.x == 0) store_walk_sentinels(d.nodes);
 }
 void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int max_P) {
   hipLaunchKernelGGL(k_build_bottom, dim3((max_P + kBlock - 1) / kBlock, ncloud), dim3(kBlock), 0, s, descs);
@@ -248,8 +261,13 @@ void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 }
 
 // ------------------------------------------------------------------------------------------------ GICP covariances
-// One thread per (Hilbert-sorted) point: neighbouring lanes walk nearly the same tree path, so the node reads
-// of a wave coalesce into a handful of L2 lines.  Algorithmic bytes: 16 (query) + k*16 (neighbours) + 24 (cov).
+// calculate_covariances of fast_gicp: one thread per (Hilbert-sorted) point, one packet walk per wave, two passes:
+//   1. the squared distance r2 of the k-th nearest neighbour — a sorted list of k DISTANCES only (one v_med3_f32 per
+//      slot and insertion; keeping the positions sorted alongside costs 4x as many instructions and this kernel is
+//      VALU bound, see profiles/),
+//   2. a second walk bounded by r2 that sums (p - q) and (p - q)(p - q)^T over exactly the k nearest points (those
+//      closer than r2 plus as many at exactly r2 as the list held) — the covariance needs the set, not its order.
+// Algorithmic bytes per point: 16 (query) + k*16 (neighbours) + 24 (cov).
 template <int KMAX>
 __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int k) {
   const CloudDesc d = descs[blockIdx.y];
@@ -259,26 +277,41 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   const int i = xcd_tile(blockIdx.x, ntiles) * kBlock + threadIdx.x;
   const bool active = i < n;
   BvhView tv;
-  tv.nodes = d.nodes, tv.pts = d.pts, tv.P = d.P, tv.n = n;
+  tv.nodes = d.nodes, tv.pts = d.pts, tv.lpts = d.lpts, tv.P = d.P, tv.n = n;
+  const int height = 31 - __clz(tv.P);
   const float4 qp = active ? d.pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const F3 q = {qp.x, qp.y, qp.z};
-  KnnList<KMAX> list;
-  wave_knn<KMAX>(tv, q, active, k, list);  // the 64 queries of a wave are consecutive points on the Hilbert curve
-  if (!active) return;
-  double s1[3] = {0, 0, 0};
-  Sym3 s2 = {0, 0, 0, 0, 0, 0};
-  int found = 0;
+  const int live = k < KMAX ? k : KMAX;
+  __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][32];
+  float* slot = walk_slots[threadIdx.x >> 6];
+  float r2;
+  int ties;
+  {
+    PacketWalk<KnnRadiusLane<KMAX>> w[1];
+    w[0].lane.init(live, active);
+    w[0].start(tv, q, height);
+    wave_walk_multi<KnnRadiusLane<KMAX>, 1>(tv, w, slot);
+    r2 = w[0].lane.worst();
+    int n_lt = 0;
 #pragma unroll
-  for (int j = 0; j < KMAX; j++) {
-    if (list.pos[j] >= 0) {
-      const float4 p = d.pts[list.pos[j]];
-      const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
-      s1[0] += dx, s1[1] += dy, s1[2] += dz;
-      s2.xx += dx * dx, s2.xy += dx * dy, s2.xz += dx * dz, s2.yy += dy * dy, s2.yz += dy * dz, s2.zz += dz * dz;
-      found++;
-    }
+    for (int j = 0; j < KMAX; j++) n_lt += (w[0].lane.d[j] >= 0.f && w[0].lane.d[j] < r2) ? 1 : 0;
+    ties = live - n_lt;
   }
-  const Sym3 c = gicp_regularized_cov(s1, s2, found, k);
+  PacketWalk<KnnGatherLane> g[1];
+  {
+    KnnGatherLane& L = g[0].lane;
+    L.r2 = active ? r2 : -1.f, L.ties_left = ties, L.found = 0;
+    L.s1[0] = L.s1[1] = L.s1[2] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) L.s2[j] = 0.0;
+    L.qx0 = q.x, L.qy0 = q.y, L.qz0 = q.z;
+    g[0].start(tv, q, height);
+  }
+  wave_walk_multi<KnnGatherLane, 1>(tv, g, slot);
+  if (!active) return;
+  const KnnGatherLane& L = g[0].lane;
+  const Sym3 s2 = {L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
+  const Sym3 c = gicp_regularized_cov(L.s1, s2, L.found, k);
   d.cov[2 * i] = make_float4((float)c.xx, (float)c.xy, (float)c.xz, (float)c.yy);
   d.cov[2 * i + 1] = make_float4((float)c.yz, (float)c.zz, 0.f, 0.f);
 }
@@ -317,31 +350,45 @@ __global__ __launch_bounds__(kBlock) void k_gicp_linearize(const CloudDesc* desc
   if (states[b].phase != GICP_LINEARIZE) return;
   const CloudDesc d = descs[b];
   const int n = d.meta->nvalid;
-  const int ntiles = (n + kBlock - 1) / kBlock;
+  const int ntiles = (n + kTileNN - 1) / kTileNN;
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = xcd_tile(blockIdx.x, ntiles);
-  const int i = tile * kBlock + threadIdx.x;
   __shared__ double lds[4 * kAcc];
+  __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][kNW * 32];
   double acc[kAcc];
 #pragma unroll
   for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
   const Pose T = states[b].x0;
-  const bool active = i < n;
   float Tf[12];
   pose_to_float(T, Tf);
-  const float4 a = active ? d.pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
-  float d2;
-  int j, orig;
-  wave_nn1(view_of(tgt), q, active, c.search_bound2, d2, j, orig);
-  if (active) {
-    if (j >= 0 && !((double)d2 < c.max_corr2)) j = -1;
-    d.corr[i] = j;
-    if (j >= 0) {
-      const double R[9] = {T.m[0], T.m[1], T.m[2], T.m[4], T.m[5], T.m[6], T.m[8], T.m[9], T.m[10]};
-      const Sym3 M = gicp_mahalanobis(R, load_cov(d.cov, i), load_cov(tgt.cov, j));
-      const float4 bp = tgt.pts[j];
-      acc[27] = gicp_point_terms<true>(T, M, a.x, a.y, a.z, bp.x, bp.y, bp.z, acc);
+  // every wave walks kNW packets of 64 consecutive source points in lock-step (hgs_wave_bvh.h)
+  int idx[kNW], seed[kNW], j[kNW], orig[kNW];
+  bool active[kNW];
+  float4 a[kNW];
+  F3 q[kNW];
+  float d2[kNW];
+#pragma unroll
+  for (int w = 0; w < kNW; w++) {
+    idx[w] = tile * kTileNN + (int)(threadIdx.x >> 6) * (64 * kNW) + w * 64 + (int)(threadIdx.x & 63);
+    active[w] = idx[w] < n;
+    a[w] = active[w] ? d.pts[idx[w]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    q[w] = transform_point_f(Tf, a[w].x, a[w].y, a[w].z);
+    // seed: the correspondence of the previous linearisation (or of an earlier align; -1 / stale values are harmless)
+    seed[w] = active[w] ? d.corr[idx[w]] : -1;
+  }
+  wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, c.search_bound2, seed, d2, j, orig);
+  const double R[9] = {T.m[0], T.m[1], T.m[2], T.m[4], T.m[5], T.m[6], T.m[8], T.m[9], T.m[10]};
+#pragma unroll
+  for (int w = 0; w < kNW; w++) {
+    if (active[w]) {
+      int jj = j[w];
+      if (jj >= 0 && !((double)d2[w] < c.max_corr2)) jj = -1;
+      d.corr[idx[w]] = jj;
+      if (jj >= 0) {
+        const Sym3 M = gicp_mahalanobis(R, load_cov(d.cov, idx[w]), load_cov(tgt.cov, jj));
+        const float4 bp = tgt.pts[jj];
+        acc[27] += gicp_point_terms<true>(T, M, a[w].x, a[w].y, a[w].z, bp.x, bp.y, bp.z, acc);
+      }
     }
   }
   block_reduce_store<kAcc>(acc, partials + ((size_t)b * max_blocks + tile) * kAcc, lds);
@@ -352,18 +399,19 @@ void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt
 }
 
 __global__ __launch_bounds__(kBlock) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
-                                                      int max_blocks) {
+                                                      int max_blocks, int tile_points) {
   const int b = blockIdx.x;
   GicpState& st = states[b];
   if (st.phase != GICP_LINEARIZE) return;
   __shared__ double acc[kAcc];
   __shared__ double scratch[kBlock];
-  const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
+  const int ntiles = (descs[b].meta->nvalid + tile_points - 1) / tile_points;  // tiles of the linearize kernel that filled `partials`
   reduce_tiles<kAcc>(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);
   if (threadIdx.x == 0) gicp_after_linearize(st, acc, c);
 }
-void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B) {
-  hipLaunchKernelGGL(k_gicp_solve, dim3(B), dim3(kBlock), 0, s, descs, states, c, partials, max_blocks);
+void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
+                       int tile_points) {
+  hipLaunchKernelGGL(k_gicp_solve, dim3(B), dim3(kBlock), 0, s, descs, states, c, partials, max_blocks, tile_points);
 }
 
 // compute_error(xi): same correspondences, Mahalanobis matrices of the linearisation pose x0, residuals at xi.
@@ -434,40 +482,48 @@ void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out,
 // getFitnessScore: per source point exact (unbounded) 1-NN in the target; sum d2 over d2 <= max_range.
 // Algorithmic bytes per source point: 16 + 16 = 32.
 __global__ __launch_bounds__(kBlock) void k_fitness(const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range,
-                                                    double* __restrict__ partials, int max_blocks) {
+                                                    double* __restrict__ partials, int max_blocks, int use_seed) {
   const int b = blockIdx.y;
   const CloudDesc d = descs[b];
   const int n = d.meta->nvalid;
-  const int ntiles = (n + kBlock - 1) / kBlock;
+  const int ntiles = (n + kTileNN - 1) / kTileNN;
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = xcd_tile(blockIdx.x, ntiles);
-  const int i = tile * kBlock + threadIdx.x;
   __shared__ double lds[4 * 2];
+  __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][kNW * 32];
   double acc[2] = {0.0, 0.0};
-  {
-    const bool active = i < n;
-    float Tf[12];
-    const float* Tc = poses[b].T;
+  float Tf[12];
+  const float* Tc = poses[b].T;
 #pragma unroll
-    for (int r = 0; r < 3; r++)
+  for (int r = 0; r < 3; r++)
 #pragma unroll
-      for (int cc = 0; cc < 4; cc++) Tf[r * 4 + cc] = Tc[cc * 4 + r];
-    const float4 a = active ? d.pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
-    float d2;
-    int j, orig;
-    wave_nn1(view_of(tgt), q, active, FLT_MAX, d2, j, orig);
-    if (active && j >= 0 && (double)d2 <= max_range) acc[0] = (double)d2, acc[1] = 1.0;
+    for (int cc = 0; cc < 4; cc++) Tf[r * 4 + cc] = Tc[cc * 4 + r];
+  int idx[kNW], seed[kNW], j[kNW], orig[kNW];
+  bool active[kNW];
+  F3 q[kNW];
+  float d2[kNW];
+#pragma unroll
+  for (int w = 0; w < kNW; w++) {
+    idx[w] = tile * kTileNN + (int)(threadIdx.x >> 6) * (64 * kNW) + w * 64 + (int)(threadIdx.x & 63);
+    active[w] = idx[w] < n;
+    const float4 a = active[w] ? d.pts[idx[w]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    q[w] = transform_point_f(Tf, a.x, a.y, a.z);
+    // use_seed: corr[] holds this cloud's last GICP correspondences against this target — a tight starting bound
+    seed[w] = (active[w] && use_seed) ? d.corr[idx[w]] : -1;
   }
+  wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, FLT_MAX, seed, d2, j, orig);
+#pragma unroll
+  for (int w = 0; w < kNW; w++)
+    if (active[w] && j[w] >= 0 && (double)d2[w] <= max_range) acc[0] += (double)d2[w], acc[1] += 1.0;
   block_reduce_store<2>(acc, partials + ((size_t)b * max_blocks + tile) * 2, lds);
 }
 void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks,
-                    int B) {
-  hipLaunchKernelGGL(k_fitness, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, poses, max_range, partials, max_blocks);
+                    int B, int use_seed) {
+  hipLaunchKernelGGL(k_fitness, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, poses, max_range, partials, max_blocks, use_seed);
 }
 __global__ __launch_bounds__(64) void k_fitness_final(const CloudDesc* descs, const double* __restrict__ partials, int max_blocks, DevResult* out) {
   const int b = blockIdx.x;
-  const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
+  const int ntiles = (descs[b].meta->nvalid + kTileNN - 1) / kTileNN;  // tiles of k_fitness
   double s = 0, c = 0;
   for (int t = threadIdx.x; t < ntiles; t += 64) {
     s += partials[((size_t)b * max_blocks + t) * 2];

@@ -3,127 +3,290 @@
 // gfx950 executes 64 lanes in lock-step; the queries of one wave are consecutive points of a Hilbert-sorted cloud
 // (after a near-rigid transform), i.e. spatially compact.  Instead of 64 private, divergent descents — every node
 // read a 64-way gather, every lane waiting for the slowest — the wave walks ONE path set: the union of the nodes any
-// lane still needs.  The traversal state (node, depth, pending-sibling mask) is wave-uniform and lives in SGPRs, a
-// node's two child boxes are a single aligned 64-byte read shared by all lanes, a leaf is one 128-byte read, and
-// the per-lane work is the box / point distance arithmetic and the private best-so-far.  Results are identical to
-// bvh_nn1 / bvh_knn (exact search; ties towards the lower original index), whatever the grouping of queries.
+// lane still needs.  The traversal state (node, depth, pending-children masks) is wave-uniform and lives in SGPRs;
+// a node group or a leaf is one 128-byte record fetched once per wave (fetch_record below) and the per-lane work is
+// the box / point distance arithmetic against it plus the private best-so-far.
+// The boxes of a group and the points of a leaf are stored SoA so that adjacent slots form the two halves of
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 operands.
 //
-// All 64 lanes must call these functions together from wave-uniform control flow; lanes without a query pass
-// active = false.
+// The walk is 4-ary: the four grandchildren 4n..4n+3 of node n are one 128-byte group record, and a grandchild box
+// that passes implies its parent box passes, so two binary levels are decided per dependent load.  When the tree
+// height is odd the walk starts at the virtual node 0 whose group holds {empty, empty, node 2, node 3}.  The children
+// of a leaf-parent group are visited in place, re-tested against the tightened bounds with their box distances still
+// in registers; a pending child of an inner group is entered directly when popped (its own group evaluation is the
+// re-test).  Children are tried nearest-first as seen by the middle lane of the wave.
+//
+// Results are identical to bvh_nn1 / bvh_knn (exact search; ties towards the lower original index), whatever the
+// grouping of queries.  All 64 lanes must call these functions together from wave-uniform control flow; lanes
+// without a query pass active = false.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "hgs_bvh.h"
 
 namespace hgs {
 
-__device__ __forceinline__ void wave_nn1(const BvhView& t, const F3& q, bool active, float bound2, float& best, int& best_pos, int& best_orig) {
-  best = active ? bound2 : -1.0f;  // an inactive lane wants nothing: no box distance is <= -1
-  best_pos = -1;
-  best_orig = 0x7fffffff;
-  if (t.n <= 0) return;
-  unsigned node = 1, pending = 0;
-  int depth = 0;
-  for (;;) {
-    bool pruned = false;
-    while ((int)node < t.P) {
-      const float4 a0 = t.nodes[4 * node + 0], a1 = t.nodes[4 * node + 1];
-      const float4 b0 = t.nodes[4 * node + 2], b1 = t.nodes[4 * node + 3];
-      const float d0 = box_dist2f(q, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z);
-      const float d1 = box_dist2f(q, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
-      const bool w0 = d0 <= best, w1 = d1 <= best;
-      const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1);
-      if ((m0 | m1) == 0ull) {
-        pruned = true;
-        break;
-      }
-      // the lanes that want a child vote for the closer one; the wave descends into the majority's choice first
-      const int v1 = __popcll(__ballot(w1 && (!w0 || d1 < d0)));
-      const int v0 = __popcll(__ballot(w0 && (!w1 || d0 <= d1)));
-      unsigned first = v1 > v0 ? 1u : 0u;
-      if ((first ? m1 : m0) == 0ull) first ^= 1u;
-      const unsigned long long mother = first ? m0 : m1;
-      depth++;
-      if (mother != 0ull) pending |= 1u << depth;
-      node = 2 * node + first;
+typedef float hgs_f16v __attribute__((ext_vector_type(16)));
+typedef float hgs_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ hgs_f2 pk_axis_gap(hgs_f2 mn, hgs_f2 mx, hgs_f2 q) {
+  const hgs_f2 a = mn - q, b = q - mx;
+  return hgs_f2{fmaxf(fmaxf(a.x, b.x), 0.f), fmaxf(fmaxf(a.y, b.y), 0.f)};
+}
+// squared distances from q to the two boxes whose bounds sit in the two halves of the operands (== box_dist2f)
+__device__ __forceinline__ hgs_f2 pk_box_dist2(hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, hgs_f2 mnx, hgs_f2 mny, hgs_f2 mnz, hgs_f2 mxx, hgs_f2 mxy, hgs_f2 mxz) {
+  const hgs_f2 dx = pk_axis_gap(mnx, mxx, qx), dy = pk_axis_gap(mny, mxy, qy), dz = pk_axis_gap(mnz, mxz, qz);
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+// squared distances from q to two points (bit-identical to dist2f per half: exact products, fused multiply-adds)
+__device__ __forceinline__ hgs_f2 pk_dist2(hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, hgs_f2 px, hgs_f2 py, hgs_f2 pz) {
+  const hgs_f2 dx = qx - px, dy = qy - py, dz = qz - pz;
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
+// One packet walk as an explicit state machine: every step consumes exactly one 128-byte record (a group of boxes or
+// a leaf of points) and decides which record comes next.
+// Lane concept:  bool wants(float box_d2) const;
+//                void visit_leaf(const hgs_f16v& xy, const hgs_f16v& zw, hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, int base);
+//                    xy = {x[8], y[8]}, zw = {z[8], w[8]} of the leaf whose first point is sorted position `base`
+enum { WALK_GROUP = 0, WALK_LEAF = 1, WALK_DONE = 2 };
+
+template <class Lane>
+struct PacketWalk {
+  // wave-uniform
+  unsigned node;            // WALK_GROUP: the node whose group (its four grandchildren) is evaluated next
+  int bd;                   // binary depth of `node`
+  unsigned long long pend;  // 4 bits per group level: children of inner groups some lane wanted, not yet entered
+  unsigned todo, lbase;     // leaves of the current leaf-parent group still to visit, node id of its slot 0
+  int nextc;
+  int kind;
+  unsigned ldnode;          // WALK_LEAF: the leaf node to visit next
+  // per lane
+  float d[4];
+  hgs_f2 qx, qy, qz;
+  Lane lane;
+
+  __device__ __forceinline__ void start(const BvhView& t, const F3& q, int k) {
+    qx = hgs_f2{q.x, q.x}, qy = hgs_f2{q.y, q.y}, qz = hgs_f2{q.z, q.z};
+    pend = 0, todo = 0, lbase = 0, nextc = 0, ldnode = 1;
+    d[0] = d[1] = d[2] = d[3] = 0.f;
+    if (t.n <= 0) {
+      kind = WALK_DONE, node = 1, bd = 0;
+    } else if (k == 0) {
+      kind = WALK_LEAF, node = 1, bd = 0;  // the root is the only leaf
+    } else {
+      kind = WALK_GROUP;
+      node = (k & 1) ? 0u : 1u;
+      bd = (k & 1) ? -1 : 0;
     }
-    if (!pruned) {
-      const int base = ((int)node - t.P) * kLeaf;
+  }
+  __device__ __forceinline__ const hgs_f16v* record(const BvhView& t) const {
+    const float4* p = kind == WALK_LEAF ? t.lpts + 8 * (size_t)(ldnode - (unsigned)t.P) : (kind == WALK_GROUP ? t.nodes + 8 * (size_t)node : t.nodes);
+    return reinterpret_cast<const hgs_f16v*>(p);
+  }
+  __device__ __forceinline__ void step(const BvhView& t, int k, const hgs_f16v& lo, const hgs_f16v& hi) {
+    bool descended = false;
+    if (kind == WALK_LEAF) {
+      lane.visit_leaf(lo, hi, qx, qy, qz, ((int)ldnode - t.P) * kLeaf);
+    } else {
+      // lo = {mnx[4], mny[4], mnz[4], mxx[4]}  hi = {mxy[4], mxz[4], pad[8]}
+      const hgs_f2 d01 = pk_box_dist2(qx, qy, qz, hgs_f2{lo[0], lo[1]}, hgs_f2{lo[4], lo[5]}, hgs_f2{lo[8], lo[9]}, hgs_f2{lo[12], lo[13]},
+                                      hgs_f2{hi[0], hi[1]}, hgs_f2{hi[4], hi[5]});
+      const hgs_f2 d23 = pk_box_dist2(qx, qy, qz, hgs_f2{lo[2], lo[3]}, hgs_f2{lo[6], lo[7]}, hgs_f2{lo[10], lo[11]}, hgs_f2{lo[14], lo[15]},
+                                      hgs_f2{hi[2], hi[3]}, hgs_f2{hi[6], hi[7]});
+      d[0] = d01.x, d[1] = d01.y, d[2] = d23.x, d[3] = d23.y;
+      unsigned any = 0;
+      float pd = INFINITY;
+      int pref = -1;
 #pragma unroll
-      for (int l = 0; l < kLeaf; l++) {
-        const float4 p = t.pts[base + l];
-        const float d = dist2f(q, p.x, p.y, p.z);
-        const int oi = __float_as_int(p.w);
-        if (d < best || (d == best && oi < best_orig)) {
-          best = d;
-          best_pos = base + l;
-          best_orig = oi;
+      for (int c = 0; c < 4; c++) {
+        const bool w = lane.wants(d[c]);
+        if (__ballot(w) != 0ull) any |= 1u << c;
+        if (w && (pref < 0 || d[c] < pd)) pd = d[c], pref = c;
+      }
+      if (any) {
+        // order: the nearest child the middle lane of the packet wants (else the lowest wanted slot)
+        int cstar = __builtin_amdgcn_readlane(pref, 32);
+        if (cstar < 0) cstar = __builtin_ctz(any);
+        const int cd = bd + 2;
+        if (cd == k) {
+          todo = any, lbase = node << 2, nextc = cstar;
+        } else {
+          pend |= (unsigned long long)(any & ~(1u << cstar)) << (4 * (cd >> 1));
+          node = (node << 2) + (unsigned)cstar;
+          bd = cd;
+          descended = true;
         }
       }
     }
+    if (descended) return;  // kind stays WALK_GROUP
     for (;;) {
-      if (!pending) return;
-      const int lvl = 31 - __clz((int)pending);
-      pending ^= 1u << lvl;
-      node = (node >> (depth - lvl)) ^ 1u;
-      depth = lvl;
-      const float4 m0 = t.nodes[2 * node], m1 = t.nodes[2 * node + 1];
-      if (__ballot(box_dist2f(q, m0.x, m0.y, m0.z, m1.x, m1.y, m1.z) <= best) != 0ull) break;
+      if (todo) {
+        // leaves of a leaf-parent group: re-test against the bounds the previous leaves tightened
+        const int c = nextc;
+        todo &= ~(1u << c);
+        nextc = todo ? __builtin_ctz(todo) : 0;
+        const float dc = c == 0 ? d[0] : (c == 1 ? d[1] : (c == 2 ? d[2] : d[3]));
+        if (__ballot(lane.wants(dc)) != 0ull) {
+          kind = WALK_LEAF;
+          ldnode = lbase + (unsigned)c;
+          return;
+        }
+        continue;
+      }
+      if (!pend) {
+        kind = WALK_DONE;
+        return;
+      }
+      // backtrack: enter the lowest pending child of the deepest pending group
+      const int idx = (63 - __clzll((long long)pend)) >> 2;
+      const unsigned nib = (unsigned)(pend >> (4 * idx)) & 0xfu;
+      const int c = __builtin_ctz(nib);
+      pend &= ~(1ull << (4 * idx + c));
+      const int pcd = 2 * idx + (k & 1);
+      node = ((node >> (bd - pcd)) & ~3u) + (unsigned)c;
+      bd = pcd;
+      kind = WALK_GROUP;
+      return;
     }
+  }
+};
+
+// Record delivery.  A record (128 bytes) is the same for all 64 lanes.  Scalar loads would put it straight into
+// SGPRs, but the scalar-memory path sustains only a few outstanding misses per CU: with every wave of the chip chasing
+// its own chain of cold records, kernels built on s_load sat ~50 % of their wave-cycles in s_waitcnt and ran at the
+// same speed whatever their occupancy or VALU count (profiles/r01_*pmc*).  The vector path has the memory-level
+// parallelism: lane l fetches word l of the record (one coalesced 128-byte global_load_dword), the wave parks it in
+// its private 128-byte LDS slot and reads it back as broadcast ds_read_b128 — all 64 lanes end up with the whole
+// record in VGPRs, L2-hit latency ~200 cycles instead of ~1000.
+__device__ __forceinline__ void fetch_record(const hgs_f16v* rec, float* slot /* wave-private, 128-byte aligned, 32 floats */, hgs_f16v& lo, hgs_f16v& hi) {
+  const int l = (int)(__lane_id() & 31u);
+  const float v = reinterpret_cast<const float*>(rec)[l];
+  __builtin_amdgcn_wave_barrier();  // the previous record's reads are issued before the slot is overwritten
+  slot[l] = v;
+  __builtin_amdgcn_wave_barrier();
+  const hgs_f16v* r = reinterpret_cast<const hgs_f16v*>(slot);
+  lo = r[0], hi = r[1];
+}
+
+// NW independent packet walks in lock-step (NW = 1 everywhere today: with VGPR-resident records occupancy provides the
+// overlap; the multi-walk form is kept because it costs nothing at NW = 1).
+template <class Lane, int NW>
+__device__ __forceinline__ void wave_walk_multi(const BvhView& t, PacketWalk<Lane> (&w)[NW], float* slots /* NW * 32 floats, wave-private LDS */) {
+  const int k = 31 - __clz(t.P);  // P = 2^k leaves
+  for (;;) {
+    bool alive = false;
+#pragma unroll
+    for (int i = 0; i < NW; i++) alive = alive || w[i].kind != WALK_DONE;
+    if (!alive) return;
+    hgs_f16v lo[NW], hi[NW];
+#pragma unroll
+    for (int i = 0; i < NW; i++) fetch_record(w[i].record(t), slots + 32 * i, lo[i], hi[i]);
+#pragma unroll
+    for (int i = 0; i < NW; i++)
+      if (w[i].kind != WALK_DONE) w[i].step(t, k, lo[i], hi[i]);
   }
 }
 
-template <int KMAX>
-__device__ __forceinline__ void wave_knn(const BvhView& t, const F3& q, bool active, int k, KnnList<KMAX>& list) {
-  list.init(k);
-  if (!active) {
-#pragma unroll
-    for (int i = 0; i < KMAX; i++) list.d[i] = -1.f;  // worst() = -1: wants nothing, never inserts
+struct Nn1Lane {
+  float best;
+  int pos, orig;
+  __device__ __forceinline__ bool wants(float d) const { return d <= best; }
+  __device__ __forceinline__ void consider(float d, int oi, int p) {
+    const bool better = d < best || (d == best && oi < orig);
+    best = better ? d : best;
+    pos = better ? p : pos;
+    orig = better ? oi : orig;
   }
-  if (t.n <= 0) return;
-  unsigned node = 1, pending = 0;
-  int depth = 0;
-  for (;;) {
-    bool pruned = false;
-    while ((int)node < t.P) {
-      const float4 a0 = t.nodes[4 * node + 0], a1 = t.nodes[4 * node + 1];
-      const float4 b0 = t.nodes[4 * node + 2], b1 = t.nodes[4 * node + 3];
-      const float d0 = box_dist2f(q, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z);
-      const float d1 = box_dist2f(q, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z);
-      const float w = list.worst();
-      const bool w0 = d0 < w, w1 = d1 < w;
-      const unsigned long long m0 = __ballot(w0), m1 = __ballot(w1);
-      if ((m0 | m1) == 0ull) {
-        pruned = true;
-        break;
-      }
-      const int v1 = __popcll(__ballot(w1 && (!w0 || d1 < d0)));
-      const int v0 = __popcll(__ballot(w0 && (!w1 || d0 <= d1)));
-      unsigned first = v1 > v0 ? 1u : 0u;
-      if ((first ? m1 : m0) == 0ull) first ^= 1u;
-      const unsigned long long mother = first ? m0 : m1;
-      depth++;
-      if (mother != 0ull) pending |= 1u << depth;
-      node = 2 * node + first;
-    }
-    if (!pruned) {
-      const int base = ((int)node - t.P) * kLeaf;
+  __device__ __forceinline__ void visit_leaf(const hgs_f16v& xy, const hgs_f16v& zw, hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, int base) {
 #pragma unroll
-      for (int l = 0; l < kLeaf; l++) {
-        const float4 p = t.pts[base + l];
-        const float d = dist2f(q, p.x, p.y, p.z);
-        if (d < list.worst()) list.insert(d, base + l);
-      }
-    }
-    for (;;) {
-      if (!pending) return;
-      const int lvl = 31 - __clz((int)pending);
-      pending ^= 1u << lvl;
-      node = (node >> (depth - lvl)) ^ 1u;
-      depth = lvl;
-      const float4 m0 = t.nodes[2 * node], m1 = t.nodes[2 * node + 1];
-      if (__ballot(box_dist2f(q, m0.x, m0.y, m0.z, m1.x, m1.y, m1.z) < list.worst()) != 0ull) break;
+    for (int l = 0; l < 8; l += 2) {
+      const hgs_f2 d = pk_dist2(qx, qy, qz, hgs_f2{xy[l], xy[l + 1]}, hgs_f2{xy[8 + l], xy[9 + l]}, hgs_f2{zw[l], zw[l + 1]});
+      consider(d.x, __float_as_int(zw[8 + l]), base + l);
+      consider(d.y, __float_as_int(zw[9 + l]), base + l + 1);
     }
   }
+};
+
+// Exact 1-NN of NW queries per lane among the points with d2 <= bound2.  `seed` (a position in the sorted target, or
+// anything out of range) is an optional starting candidate — typically the correspondence of the previous
+// linearisation: any real target point is a valid upper bound, so the result is unchanged, only the ball the wave has
+// to cover shrinks from max_correspondence_distance to about the true NN distance.
+template <int NW>
+__device__ __forceinline__ void wave_nn1(const BvhView& t, float* slots, const F3 (&q)[NW], const bool (&active)[NW], float bound2, const int (&seed)[NW],
+                                         float (&best)[NW], int (&best_pos)[NW], int (&best_orig)[NW]) {
+  PacketWalk<Nn1Lane> w[NW];
+  const int k = 31 - __clz(t.P);
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    Nn1Lane& lane = w[i].lane;
+    lane.best = active[i] ? bound2 : -1.0f;  // an inactive lane wants nothing: no box distance is <= -1
+    lane.pos = -1;
+    lane.orig = 0x7fffffff;
+    if (active[i] && seed[i] >= 0 && seed[i] < t.n) {
+      const float4 p = t.pts[seed[i]];
+      const float d = dist2f(q[i], p.x, p.y, p.z);
+      if (d <= bound2) lane.best = d, lane.pos = seed[i], lane.orig = __float_as_int(p.w);
+    }
+    w[i].start(t, q[i], k);
+  }
+  wave_walk_multi<Nn1Lane, NW>(t, w, slots);
+#pragma unroll
+  for (int i = 0; i < NW; i++) best[i] = w[i].lane.best, best_pos[i] = w[i].lane.pos, best_orig[i] = w[i].lane.orig;
 }
+
+// ---- k-NN radius: sorted list of the k smallest squared distances only (no positions) -----------------------------
+// With d ascending, inserting x makes the new d[i] the median of (d[i-1], d[i], x): one v_med3_f32 per slot.
+template <int KMAX>
+struct KnnRadiusLane {
+  float d[KMAX];  // slots [KMAX-k, KMAX) are live, the others hold -1 and never move
+  __device__ __forceinline__ void init(int k, bool active) {
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) d[i] = (!active || i < KMAX - k) ? -1.f : FLT_MAX;
+  }
+  __device__ __forceinline__ float worst() const { return d[KMAX - 1]; }
+  __device__ __forceinline__ bool wants(float box_d2) const { return box_d2 < worst(); }
+  __device__ __forceinline__ void insert(float x) {  // x < worst()
+#pragma unroll
+    for (int i = KMAX - 1; i > 0; i--) d[i] = __builtin_amdgcn_fmed3f(d[i - 1], d[i], x);
+    d[0] = fminf(d[0], x);
+  }
+  __device__ __forceinline__ void visit_leaf(const hgs_f16v& xy, const hgs_f16v& zw, hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, int base) {
+#pragma unroll
+    for (int l = 0; l < 8; l += 2) {
+      const hgs_f2 dd = pk_dist2(qx, qy, qz, hgs_f2{xy[l], xy[l + 1]}, hgs_f2{xy[8 + l], xy[9 + l]}, hgs_f2{zw[l], zw[l + 1]});
+      if (dd.x < worst()) insert(dd.x);
+      if (dd.y < worst()) insert(dd.y);
+    }
+  }
+};
+
+// ---- k-NN gather: all points with d2 < r2, plus `ties_left` of those with d2 == r2, summed for the covariance -------
+struct KnnGatherLane {
+  float r2;       // squared distance of the k-th neighbour (-1: no query)
+  int ties_left;  // how many points at exactly r2 belong to the k nearest
+  int found;
+  double s1[3];   // sum (p - q)
+  double s2[6];   // sum (p - q)(p - q)^T  xx,xy,xz,yy,yz,zz
+  float qx0, qy0, qz0;
+  __device__ __forceinline__ bool wants(float box_d2) const { return box_d2 <= r2; }
+  __device__ __forceinline__ void take(float dd, float px, float py, float pz) {
+    bool in = dd < r2;
+    if (dd == r2 && ties_left > 0) in = true, ties_left--;
+    if (in) {
+      const double dx = (double)px - (double)qx0, dy = (double)py - (double)qy0, dz = (double)pz - (double)qz0;
+      s1[0] += dx, s1[1] += dy, s1[2] += dz;
+      s2[0] += dx * dx, s2[1] += dx * dy, s2[2] += dx * dz, s2[3] += dy * dy, s2[4] += dy * dz, s2[5] += dz * dz;
+      found++;
+    }
+  }
+  __device__ __forceinline__ void visit_leaf(const hgs_f16v& xy, const hgs_f16v& zw, hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, int base) {
+#pragma unroll
+    for (int l = 0; l < 8; l += 2) {
+      const hgs_f2 dd = pk_dist2(qx, qy, qz, hgs_f2{xy[l], xy[l + 1]}, hgs_f2{xy[8 + l], xy[9 + l]}, hgs_f2{zw[l], zw[l + 1]});
+      take(dd.x, xy[l], xy[8 + l], zw[l]);
+      take(dd.y, xy[l + 1], xy[9 + l], zw[l + 1]);
+    }
+  }
+};
 
 }  // namespace hgs

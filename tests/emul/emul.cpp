@@ -26,7 +26,7 @@ struct ECloud {
   std::vector<int> corr;
   int n_input = 0, nvalid = 0, P = 1;
   float bbmin[3], bbmax[3];
-  BvhView view() const { return BvhView{nodes.data(), pts.data(), P, nvalid}; }
+  BvhView view() const { return BvhView{nodes.data(), pts.data(), nullptr, P, nvalid}; }
 };
 
 static bool finite3(const Float4& p) { return std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z); }
@@ -68,7 +68,7 @@ static void build_cloud(ECloud& c, const float* xyz, int n, size_t stride_floats
   c.pts.assign((size_t)c.P * kLeaf, Float4{INFINITY, INFINITY, INFINITY, int_as_float_hd(-1)});
   for (int i = 0; i < c.nvalid; i++) c.pts[i] = c.raw[vals[i]];
   // k_build_bottom / k_build_top
-  c.nodes.assign((size_t)4 * c.P, Float4{0, 0, 0, 0});
+  c.nodes.assign((size_t)4 * c.P + 8, Float4{0, 0, 0, 0});
   for (int leaf = 0; leaf < c.P; leaf++) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int l = 0; l < kLeaf; l++) {
@@ -79,13 +79,15 @@ static void build_cloud(ECloud& c, const float* xyz, int n, size_t stride_floats
         mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
       }
     }
-    c.nodes[2 * (c.P + leaf)] = Float4{mn[0], mn[1], mn[2], 0};
-    c.nodes[2 * (c.P + leaf) + 1] = Float4{mx[0], mx[1], mx[2], 0};
+    bvh_store_box(c.nodes.data(), (uint32_t)(c.P + leaf), mn, mx);
   }
   for (int id = c.P - 1; id >= 1; id--) {
-    const Float4 a0 = c.nodes[4 * id], a1 = c.nodes[4 * id + 1], b0 = c.nodes[4 * id + 2], b1 = c.nodes[4 * id + 3];
-    c.nodes[2 * id] = Float4{fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0};
-    c.nodes[2 * id + 1] = Float4{fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0};
+    float amn[3], amx[3], bmn[3], bmx[3];
+    bvh_load_box(c.nodes.data(), 2 * (uint32_t)id, amn, amx);
+    bvh_load_box(c.nodes.data(), 2 * (uint32_t)id + 1, bmn, bmx);
+    const float mn[3] = {fminf(amn[0], bmn[0]), fminf(amn[1], bmn[1]), fminf(amn[2], bmn[2])};
+    const float mx[3] = {fmaxf(amx[0], bmx[0]), fmaxf(amx[1], bmx[1]), fmaxf(amx[2], bmx[2])};
+    bvh_store_box(c.nodes.data(), (uint32_t)id, mn, mx);
   }
   c.cov.clear();
   c.corr.assign((size_t)c.P * kLeaf, -1);
@@ -558,3 +560,242 @@ int emul_sorted_order(EmulHandle* h, int target, int32_t* out) {
 }
 
 }  // extern "C"
+
+// ---- host simulation of the wave-cooperative 4-ary walk of hgs_wave_bvh.h (64 lanes in lock-step) -----------------
+// Mirrors wave_walk step by step: used to (a) check on the CPU that the packet search returns exactly what the
+// per-lane search returns and (b) count group evaluations / leaf visits per wave when tuning the traversal.
+struct SimStats {
+  long long groups = 0, leaves = 0, waves = 0, mismatches = 0, inserts = 0, retests = 0;
+};
+static int g_sim_variant = 0;
+static int g_sim_order = 0;  // 0: majority vote for the nearest wanted child; 1: child wanted by most lanes; 2: nearest child of the middle lane
+template <class Wants, class Leaf>
+static void sim_wave_walk_v1(const BvhView& t, const F3* q, int nl, Wants wants, Leaf visit_leaf, SimStats& st);
+template <class Wants, class Leaf>
+static void sim_wave_walk(const BvhView& t, const F3* q, int nl, Wants wants, Leaf visit_leaf, SimStats& st) {
+  if (g_sim_variant == 1) return sim_wave_walk_v1(t, q, nl, wants, visit_leaf, st);
+  if (t.n <= 0) return;
+  int k = 0;
+  while ((1 << k) < t.P) k++;
+  const int kodd = k & 1;
+  unsigned node = 1;
+  int bd = 0;
+  unsigned long long pend = 0;
+  for (;;) {
+    unsigned base = 0, allowed = 0;
+    int cd = 0, s = 2;
+    bool have = false;
+    if (bd < k) {
+      s = (bd == 0 && kodd) ? 1 : 2;
+      base = node << s, cd = bd + s, allowed = (1u << (1u << s)) - 1u, have = true;
+    } else {
+      st.leaves++;
+      visit_leaf(((int)node - t.P) * kLeaf);
+    }
+    for (;;) {
+      if (!have) {
+        if (!pend) return;
+        const int idx = (63 - __builtin_clzll(pend)) >> 2;
+        allowed = (unsigned)(pend >> (4 * idx)) & 0xfu;
+        pend &= ~(0xfull << (4 * idx));
+        cd = 2 * idx + kodd;
+        s = cd == 1 ? 1 : 2;
+        base = ((node >> (bd - cd)) >> s) << s;
+      }
+      have = false;
+      st.groups++;
+      unsigned any = 0;
+      int votes[4] = {0, 0, 0, 0};
+      for (int l = 0; l < nl; l++) {
+        float pd = INFINITY;
+        int pref = -1;
+        for (int c = 0; c < (1 << s); c++) {
+          if (!((allowed >> c) & 1u)) continue;
+          const float d = bvh_box_dist2(t.nodes, base + c, q[l]);
+          if (!wants(l, d)) continue;
+          any |= 1u << c;
+          if (pref < 0 || d < pd) pd = d, pref = c;
+        }
+        if (pref >= 0) votes[pref]++;
+      }
+      if (!any) continue;
+      int cstar = 0, vbest = -1;
+      for (int c = 0; c < 4; c++)
+        if (votes[c] > vbest) vbest = votes[c], cstar = c;
+      pend |= (unsigned long long)(any & ~(1u << cstar)) << (4 * (cd >> 1));
+      node = base + (unsigned)cstar;
+      bd = cd;
+      break;
+    }
+  }
+}
+
+// variant 1: a popped child is entered directly (its own group evaluation prunes it), and the children of a
+// leaf-parent group are visited in place, re-tested against the updated bounds with the distances still in registers
+template <class Wants, class Leaf>
+static void sim_wave_walk_v1(const BvhView& t, const F3* q, int nl, Wants wants, Leaf visit_leaf, SimStats& st) {
+  if (t.n <= 0) return;
+  int k = 0;
+  while ((1 << k) < t.P) k++;
+  const int kodd = k & 1;
+  if (k == 0) {
+    st.leaves++;
+    visit_leaf(0);
+    return;
+  }
+  unsigned node = 1;
+  int bd = 0;
+  unsigned long long pend = 0;
+  for (;;) {
+    // evaluate the group below `node`
+    const int s = (bd == 0 && kodd) ? 1 : 2;
+    const unsigned base = node << s;
+    const int cd = bd + s;
+    st.groups++;
+    float d[64][4];
+    unsigned any = 0;
+    int votes[4] = {0, 0, 0, 0};
+    for (int l = 0; l < nl; l++) {
+      float pd = INFINITY;
+      int pref = -1;
+      for (int c = 0; c < (1 << s); c++) {
+        d[l][c] = bvh_box_dist2(t.nodes, base + c, q[l]);
+        if (!wants(l, d[l][c])) continue;
+        any |= 1u << c;
+        if (g_sim_order == 1) votes[c]++;
+        if (pref < 0 || d[l][c] < pd) pd = d[l][c], pref = c;
+      }
+      if (pref >= 0 && g_sim_order == 0) votes[pref]++;
+    }
+    if (g_sim_order == 2 && any) {
+      const int rep = nl / 2;
+      float bestd = INFINITY;
+      int bc = -1;
+      for (int c = 0; c < 4; c++)
+        if (((any >> c) & 1u) && (bc < 0 || d[rep][c] < bestd)) bestd = d[rep][c], bc = c;
+      votes[bc] = 1;
+    }
+    bool descended = false;
+    if (any) {
+      if (cd == k) {  // children are leaves: visit them in place, most-voted first
+        unsigned todo = any;
+        while (todo) {
+          int c = -1, vb = -1;
+          for (int cc = 0; cc < 4; cc++)
+            if (((todo >> cc) & 1u) && votes[cc] > vb) vb = votes[cc], c = cc;
+          todo &= ~(1u << c);
+          bool still = false;
+          for (int l = 0; l < nl; l++) still = still || wants(l, d[l][c]);
+          st.retests++;
+          if (!still) continue;
+          st.leaves++;
+          visit_leaf(((int)(base + c) - t.P) * kLeaf);
+        }
+      } else {
+        int cstar = 0, vbest = -1;
+        for (int c = 0; c < 4; c++)
+          if (votes[c] > vbest) vbest = votes[c], cstar = c;
+        pend |= (unsigned long long)(any & ~(1u << cstar)) << (4 * (cd >> 1));
+        node = base + (unsigned)cstar;
+        bd = cd;
+        descended = true;
+      }
+    }
+    if (descended) continue;
+    if (!pend) return;
+    const int idx = (63 - __builtin_clzll(pend)) >> 2;
+    const unsigned nib = (unsigned)(pend >> (4 * idx)) & 0xfu;
+    const int c = __builtin_ctz(nib);
+    pend &= ~(1ull << (4 * idx + c));
+    const int pcd = 2 * idx + kodd;
+    const int ps = pcd == 1 ? 1 : 2;
+    node = (((node >> (bd - pcd)) >> ps) << ps) + (unsigned)c;
+    bd = pcd;
+  }
+}
+
+extern "C" void emul_set_sim_variant(int v) { g_sim_variant = v & 0xff, g_sim_order = v >> 8; }
+
+extern "C" int emul_walk_stats(EmulHandle* h, const float* T16, float bound2, int use_seed, long long* out5) {
+  float Tf[12];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) Tf[r * 4 + c] = T16[c * 4 + r];
+  const BvhView tv = h->tgt.view();
+  SimStats st;
+  for (int w0 = 0; w0 < h->src.nvalid; w0 += 64) {
+    const int nl = std::min(64, h->src.nvalid - w0);
+    F3 q[64];
+    float best[64];
+    int pos[64], orig[64];
+    for (int l = 0; l < nl; l++) {
+      const Float4 a = h->src.pts[w0 + l];
+      q[l] = transform_point_f(Tf, a.x, a.y, a.z);
+      best[l] = bound2, pos[l] = -1, orig[l] = 0x7fffffff;
+      const int seed = use_seed ? h->src.corr[w0 + l] : -1;
+      if (seed >= 0 && seed < tv.n) {
+        const Float4 p = tv.pts[seed];
+        const float d = dist2f(q[l], p.x, p.y, p.z);
+        if (d <= bound2) best[l] = d, pos[l] = seed, orig[l] = float_as_int_hd(p.w);
+      }
+    }
+    st.waves++;
+    sim_wave_walk(
+        tv, q, nl, [&](int l, float d) { return d <= best[l]; },
+        [&](int pbase) {
+          for (int l = 0; l < nl; l++)
+            for (int j = 0; j < kLeaf; j++) {
+              const Float4 p = tv.pts[pbase + j];
+              const float d = dist2f(q[l], p.x, p.y, p.z);
+              const int oi = float_as_int_hd(p.w);
+              if (d < best[l] || (d == best[l] && oi < orig[l])) best[l] = d, pos[l] = pbase + j, orig[l] = oi;
+            }
+        },
+        st);
+    for (int l = 0; l < nl; l++) {
+      float d2;
+      int o;
+      const int j = bvh_nn1(tv, q[l], bound2, &d2, &o);
+      if (j != pos[l] || (j >= 0 && d2 != best[l])) st.mismatches++;
+    }
+  }
+  out5[0] = st.groups, out5[1] = st.leaves, out5[2] = st.waves, out5[3] = st.mismatches, out5[4] = 0;
+  return 0;
+}
+
+// kNN variant on the target cloud against itself (k_knn_cov): also counts leaf points for which at least one lane inserts
+extern "C" int emul_walk_stats_knn(EmulHandle* h, int k, long long* out5) {
+  const BvhView tv = h->tgt.view();
+  SimStats st;
+  for (int w0 = 0; w0 < h->tgt.nvalid; w0 += 64) {
+    const int nl = std::min(64, h->tgt.nvalid - w0);
+    F3 q[64];
+    std::vector<std::vector<float>> lists(nl);
+    for (int l = 0; l < nl; l++) {
+      const Float4 a = h->tgt.pts[w0 + l];
+      q[l] = F3{a.x, a.y, a.z};
+    }
+    auto worst = [&](int l) { return (int)lists[l].size() < k ? FLT_MAX : lists[l].back(); };
+    st.waves++;
+    sim_wave_walk(
+        tv, q, nl, [&](int l, float d) { return d < worst(l); },
+        [&](int pbase) {
+          for (int j = 0; j < kLeaf; j++) {
+            const Float4 p = tv.pts[pbase + j];
+            bool anyins = false;
+            for (int l = 0; l < nl; l++) {
+              const float d = dist2f(q[l], p.x, p.y, p.z);
+              if (d < worst(l)) {
+                auto& L = lists[l];
+                L.insert(std::upper_bound(L.begin(), L.end(), d), d);
+                if ((int)L.size() > k) L.pop_back();
+                anyins = true;
+              }
+            }
+            if (anyins) st.inserts++;
+          }
+        },
+        st);
+  }
+  out5[0] = st.groups, out5[1] = st.leaves, out5[2] = st.waves, out5[3] = 0, out5[4] = st.inserts;
+  return 0;
+}

@@ -13,7 +13,7 @@ _ROOT = os.path.dirname(os.path.dirname(_HERE))
 
 
 def build():
-    srcs = [os.path.join(_HERE, "emul.cpp")] + [os.path.join(_ROOT, "hdl_graph_slam_amd", "csrc", f) for f in ("hgs_math.h", "hgs_bvh.h", "hgs_gicp.h", "hgs_ndt.h")]
+    srcs = [os.path.join(_HERE, "emul.cpp")] + [os.path.join(_ROOT, "hdl_graph_slam_amd", "csrc", f) for f in ("hgs_math.h", "hgs_bvh.h", "hgs_gicp.h", "hgs_ndt.h", "hgs_vgicp.h")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.run(["g++", "-O2", "-march=x86-64-v3", "-mfma", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                         "-o", _LIB, srcs[0]], check=True)
@@ -42,6 +42,8 @@ def lib():
         L.emul_ndt_grid.argtypes = [vp, vp, vp]
         L.emul_ndt_derivatives.argtypes = [vp, vp, vp, vp, vp]
         L.emul_sorted_order.argtypes = [vp, C.c_int, vp]
+        L.emul_walk_stats.argtypes = [vp, vp, C.c_float, C.c_int, vp]
+        L.emul_walk_stats_knn.argtypes = [vp, C.c_int, vp]
         _lib = L
     return _lib
 
@@ -128,3 +130,16 @@ class EmulRegistration:
         out = np.zeros(self.n_target if target else self.n_source, np.int32)
         n = lib().emul_sorted_order(self._h, int(target), _p(out))
         return out[:n]
+
+    def walk_stats(self, T, bound2=np.finfo(np.float32).max, use_seed=False):
+        """Host simulation of the wave-cooperative 4-ary walk (hgs_wave_bvh.h) over the source cloud at pose T:
+        (group evaluations, leaf visits, waves, mismatches vs the per-lane search)."""
+        out = np.zeros(5, np.int64)
+        T16 = np.ascontiguousarray(np.asarray(T, np.float32).T.reshape(-1))
+        lib().emul_walk_stats(self._h, _p(T16), C.c_float(bound2), int(use_seed), _p(out))
+        return tuple(int(v) for v in out[:4])
+
+    def walk_stats_knn(self, k=20):
+        out = np.zeros(5, np.int64)
+        lib().emul_walk_stats_knn(self._h, int(k), _p(out))
+        return int(out[0]), int(out[1]), int(out[2]), int(out[4])

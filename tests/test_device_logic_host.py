@@ -154,3 +154,20 @@ def test_empty_and_tiny_inputs():
     e.setInputSource(np.zeros((0, 3), np.float32))
     r = e.align(np.eye(4))
     assert r.iterations >= 1   # an empty source yields H = 0: the LM loop runs and terminates without crashing
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_wave_walk_simulation_is_exact(gicp_case, variant):
+    """The wave-cooperative 4-ary walk of hgs_wave_bvh.h, simulated lane by lane on the host (both the re-test-on-pop
+    and the in-place-leaves / direct-pop scheduling), returns exactly what the per-lane search returns — bounded,
+    unbounded and seeded with the previous correspondences."""
+    e, o, tgt, src, T = gicp_case
+    emul.lib().emul_set_sim_variant(variant)
+    try:
+        for bound2, seeded in ((np.float32(2.5 ** 2), False), (np.finfo(np.float32).max, False), (np.float32(2.5 ** 2), True)):
+            if seeded:
+                e.gicp_linearize(np.eye(4))          # leaves the correspondences at the identity pose behind as seeds
+            groups, leaves, waves, mismatches = e.walk_stats(T, bound2, seeded)
+            assert mismatches == 0 and waves == (len(src) + 63) // 64 and leaves >= waves
+    finally:
+        emul.lib().emul_set_sim_variant(0)
