@@ -95,14 +95,15 @@ struct PacketWalk {
                                       hgs_f2{hi[2], hi[3]}, hgs_f2{hi[6], hi[7]});
       d[0] = d01.x, d[1] = d01.y, d[2] = d23.x, d[3] = d23.y;
       unsigned any = 0;
-      float pd = INFINITY;
-      int pref = -1;
+      float dw[4];  // distance of the children this lane wants, +inf for the others
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const bool w = lane.wants(d[c]);
         if (__ballot(w) != 0ull) any |= 1u << c;
-        if (w && (pref < 0 || d[c] < pd)) pd = d[c], pref = c;
+        dw[c] = w ? d[c] : INFINITY;
       }
+      const float dmin = fminf(fminf(dw[0], dw[1]), fminf(dw[2], dw[3]));
+      const int pref = dmin == INFINITY ? -1 : (dw[0] == dmin ? 0 : (dw[1] == dmin ? 1 : (dw[2] == dmin ? 2 : 3)));
       if (any) {
         // order: the nearest child the middle lane of the packet wants (else the lowest wanted slot)
         int cstar = __builtin_amdgcn_readlane(pref, 32);
@@ -187,15 +188,20 @@ __device__ __forceinline__ void wave_walk_multi(const BvhView& t, PacketWalk<Lan
   }
 }
 
+// Best-so-far of one lane as a single 64-bit key {d2 bits : original index}: squared distances are non-negative
+// floats, whose bit patterns order like unsigned integers, so "closer, or equally close with the lower original index"
+// is ONE unsigned 64-bit compare (v_cmp_lt_u64) instead of three compares and mask algebra on the scalar unit.
 struct Nn1Lane {
-  float best;
-  int pos, orig;
-  __device__ __forceinline__ bool wants(float d) const { return d <= best; }
+  unsigned long long key;
+  int pos;
+  __device__ __forceinline__ float best() const { return __uint_as_float((unsigned)(key >> 32)); }
+  __device__ __forceinline__ int orig() const { return (int)(unsigned)key; }
+  __device__ __forceinline__ bool wants(float d) const { return d <= best(); }
   __device__ __forceinline__ void consider(float d, int oi, int p) {
-    const bool better = d < best || (d == best && oi < orig);
-    best = better ? d : best;
+    const unsigned long long nk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)oi;
+    const bool better = nk < key;
+    key = better ? nk : key;
     pos = better ? p : pos;
-    orig = better ? oi : orig;
   }
   __device__ __forceinline__ void visit_leaf(const hgs_f16v& xy, const hgs_f16v& zw, hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, int base) {
 #pragma unroll
@@ -219,19 +225,20 @@ __device__ __forceinline__ void wave_nn1(const BvhView& t, float* slots, const F
 #pragma unroll
   for (int i = 0; i < NW; i++) {
     Nn1Lane& lane = w[i].lane;
-    lane.best = active[i] ? bound2 : -1.0f;  // an inactive lane wants nothing: no box distance is <= -1
+    // a lane without a query sits infinitely far away with an unbeatable key: it wants no box and accepts no point
+    const F3 qq = active[i] ? q[i] : F3{FLT_MAX, FLT_MAX, FLT_MAX};
+    lane.key = active[i] ? (((unsigned long long)__float_as_uint(bound2) << 32) | 0x7fffffffull) : 0ull;
     lane.pos = -1;
-    lane.orig = 0x7fffffff;
     if (active[i] && seed[i] >= 0 && seed[i] < t.n) {
       const float4 p = t.pts[seed[i]];
-      const float d = dist2f(q[i], p.x, p.y, p.z);
-      if (d <= bound2) lane.best = d, lane.pos = seed[i], lane.orig = __float_as_int(p.w);
+      const float d = dist2f(qq, p.x, p.y, p.z);
+      if (d <= bound2) lane.key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w), lane.pos = seed[i];
     }
-    w[i].start(t, q[i], k);
+    w[i].start(t, qq, k);
   }
   wave_walk_multi<Nn1Lane, NW>(t, w, slots);
 #pragma unroll
-  for (int i = 0; i < NW; i++) best[i] = w[i].lane.best, best_pos[i] = w[i].lane.pos, best_orig[i] = w[i].lane.orig;
+  for (int i = 0; i < NW; i++) best[i] = w[i].lane.best(), best_pos[i] = w[i].lane.pos, best_orig[i] = w[i].lane.orig();
 }
 
 // ---- k-NN radius: sorted list of the k smallest squared distances only (no positions) -----------------------------
