@@ -140,8 +140,22 @@ def main():
     ms, launches = prof[dom]
     kname, bytes_per_unit = ALG_BYTES[dom]
     achieved = units[dom] * bytes_per_unit / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    # HBM traffic of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per dispatch, collected in separate passes over this
+    # same command (scripts/gpu_pmc.sh) and committed as profiles/pmc_<method>.json; FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for gfx950 (calibrated there for wide coalesced reads only — our reads are 128-byte
+    # records and 16-byte gathers, so treat it as an upper estimate).  null when no committed counters match.
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.method.lower()}.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
+        for kn, cv in pmc.get("kernels", {}).items():
+            if kn.split("<")[0].endswith(kname) and "FETCH_SIZE" in cv:
+                traffic = (2.0 * cv["FETCH_SIZE"] + cv.get("WRITE_SIZE", 0.0)) * 1024.0
+                traffic_src = os.path.relpath(pmc_path, ROOT)
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if traffic is None else round(traffic, 1), "traffic_source": traffic_src,
+                "limiter": "instruction issue (VALU+SALU) of the exact tree search, not HBM: see DESIGN.md section 4",
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches": launches,
                 "algorithmic_bytes_per_launch": round(units[dom] * bytes_per_unit / max(launches, 1), 1),
                 "stage_ms_per_step": {s: round(prof[s][0] / prof_steps, 3) for s in prof}}

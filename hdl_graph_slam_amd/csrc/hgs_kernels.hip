@@ -64,9 +64,16 @@ __device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int n
   const int t = threadIdx.x;
   if (t < ROWS * N) {
     const int col = t % N, row = t / N;
-    double s = 0;
-    for (int tile = row; tile < ntiles; tile += ROWS) s += p[(size_t)tile * N + col];
-    scratch[row * N + col] = s;
+    // four independent partial sums keep four loads in flight per thread (one dependent chain was latency bound)
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int tile = row;
+    for (; tile + 3 * ROWS < ntiles; tile += 4 * ROWS) {
+      const double a = p[(size_t)tile * N + col], b = p[(size_t)(tile + ROWS) * N + col];
+      const double c = p[(size_t)(tile + 2 * ROWS) * N + col], d = p[(size_t)(tile + 3 * ROWS) * N + col];
+      s0 += a, s1 += b, s2 += c, s3 += d;
+    }
+    for (; tile < ntiles; tile += ROWS) s0 += p[(size_t)tile * N + col];
+    scratch[row * N + col] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   if (t < N) {
@@ -288,9 +295,24 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   int ties;
   {
     PacketWalk<KnnRadiusLane<KMAX>> w[1];
-    w[0].lane.init(live, active);
-    w[0].start(tv, q, height);
-    wave_walk_multi<KnnRadiusLane<KMAX>, 1>(tv, w, slot);
+    KnnRadiusLane<KMAX>& L = w[0].lane;
+    L.init(live, active);
+    // The wave's own 64 points (8 whole leaves of the Hilbert order) are every lane's first candidates: all-pairs
+    // through v_readlane, no memory traffic — the walk then starts with every list full and a bound within ~1.2x of
+    // the final radius instead of +inf, which is what keeps it from wandering (3x fewer insertions and leaves).
+    const int i0 = i - (int)(threadIdx.x & 63);
+    const int own = min(64, n - i0);
+    for (int jj = 0; jj < own; jj++) {
+      const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), jj)), py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), jj)),
+                  pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), jj));
+      const float dd = dist2f(q, px, py, pz);
+      if (dd < L.worst()) L.insert(dd);
+    }
+    if (n > 64) {  // otherwise the own window was the whole cloud
+      w[0].start(tv, q, height);
+      w[0].skip_lo = (unsigned)(tv.P + (i0 >> 3)), w[0].skip_n = 8u;
+      wave_walk_multi<KnnRadiusLane<KMAX>, 1>(tv, w, slot);
+    }
     r2 = w[0].lane.worst();
     int n_lt = 0;
 #pragma unroll
@@ -666,7 +688,7 @@ void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const f
 
 // computeDerivatives: per source point, transform, visit the DIRECT1/DIRECT7 cells, accumulate score / gradient /
 // Hessian.  Algorithmic bytes per source point: 16 + 7*40 = 296 (DIRECT7), 56 (DIRECT1).
-__global__ __launch_bounds__(kBlock) void k_ndt_derivatives(const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles,
+__global__ __launch_bounds__(kBlock, 2) void k_ndt_derivatives(const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles,
                                                             NdtConsts c, double* __restrict__ partials, int max_blocks) {
   const int b = blockIdx.y;
   if (states[b].phase != NDT_DERIV) return;

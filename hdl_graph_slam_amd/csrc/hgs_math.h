@@ -240,7 +240,7 @@ HGS_HD void solve_svd6(const double* A, const double* b, double* x) {
           beta += U[k * 6 + q] * U[k * 6 + q];
           gamma += U[k * 6 + p] * U[k * 6 + q];
         }
-        if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+        if (gamma == 0.0 || fabs(gamma) <= DBL_EPSILON * sqrt(alpha * beta)) continue;
         rotated = true;
         const double zeta = (beta - alpha) / (2.0 * gamma);
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

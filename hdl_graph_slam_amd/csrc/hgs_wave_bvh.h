@@ -60,6 +60,7 @@ struct PacketWalk {
   int nextc;
   int kind;
   unsigned ldnode;          // WALK_LEAF: the leaf node to visit next
+  unsigned skip_lo, skip_n; // leaf nodes [skip_lo, skip_lo + skip_n) are never visited (the caller has handled them)
   // per lane
   float d[4];
   hgs_f2 qx, qy, qz;
@@ -67,7 +68,7 @@ struct PacketWalk {
 
   __device__ __forceinline__ void start(const BvhView& t, const F3& q, int k) {
     qx = hgs_f2{q.x, q.x}, qy = hgs_f2{q.y, q.y}, qz = hgs_f2{q.z, q.z};
-    pend = 0, todo = 0, lbase = 0, nextc = 0, ldnode = 1;
+    pend = 0, todo = 0, lbase = 0, nextc = 0, ldnode = 1, skip_lo = 0, skip_n = 0;
     d[0] = d[1] = d[2] = d[3] = 0.f;
     if (t.n <= 0) {
       kind = WALK_DONE, node = 1, bd = 0;
@@ -126,6 +127,7 @@ struct PacketWalk {
         const int c = nextc;
         todo &= ~(1u << c);
         nextc = todo ? __builtin_ctz(todo) : 0;
+        if (lbase + (unsigned)c - skip_lo < skip_n) continue;
         const float dc = c == 0 ? d[0] : (c == 1 ? d[1] : (c == 2 ? d[2] : d[3]));
         if (__ballot(lane.wants(dc)) != 0ull) {
           kind = WALK_LEAF;

@@ -6,6 +6,7 @@
 // registration engines that hdl_graph_slam selects in src/hdl_graph_slam/registrations.cpp:22-124.
 // (Upstream uses Eigen: Matrix3d/Matrix4d inverse, SelfAdjointEigenSolver<Matrix3d>, LDLT<6x6>, JacobiSVD<6x6>.)
 #pragma once
+#include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <algorithm>
@@ -224,7 +225,7 @@ inline V6 solve_svd6(const M6& A, const V6& b) {
       for (int q = p + 1; q < 6; q++) {
         double alpha = 0, beta = 0, gamma = 0;
         for (int k = 0; k < 6; k++) alpha += U[k][p] * U[k][p], beta += U[k][q] * U[k][q], gamma += U[k][p] * U[k][q];
-        if (gamma == 0.0 || std::fabs(gamma) <= 1e-17 * std::sqrt(alpha * beta)) continue;
+        if (gamma == 0.0 || std::fabs(gamma) <= DBL_EPSILON * std::sqrt(alpha * beta)) continue;
         rotated = true;
         const double zeta = (beta - alpha) / (2.0 * gamma);
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));

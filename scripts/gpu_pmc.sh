@@ -19,4 +19,4 @@ run_pass sq2 SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 find "$OUT" -name "*counter_collection.csv" | head
-python "$ROOT/scripts/pmc_summary.py" "$OUT" | tee "$OUT/summary.md"
+python "$ROOT/scripts/pmc_summary.py" "$OUT" "$OUT/summary.json" | tee "$OUT/summary.md"

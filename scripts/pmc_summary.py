@@ -17,7 +17,7 @@ def short(name: str) -> str:
     return name[:40]
 
 
-def main(root):
+def main(root, json_out=None):
     agg = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(lambda: defaultdict(set))
     for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
@@ -34,9 +34,17 @@ def main(root):
     for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0)):
         nd = max(len(s) for s in disp[k].values())
         print(f"| {k} | {nd} | " + " | ".join(f"{agg[k].get(c, 0) / max(len(disp[k].get(c, [1])), 1):.4g}" for c in counters) + " |")
+    if json_out:
+        import json
+        out = {}
+        for k in agg:
+            out[k] = {c: agg[k][c] / max(len(disp[k].get(c, [1])), 1) for c in agg[k]}
+            out[k]["dispatches"] = max(len(s) for s in disp[k].values())
+        with open(json_out, "w") as fh:
+            json.dump({"note": "rocprofv3 --pmc per-dispatch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported", "kernels": out}, fh, indent=1, sort_keys=True)
     print("\n(values are per-dispatch averages; SQ_* cycle counters are in quad-cycles; FETCH_SIZE/WRITE_SIZE in KiB as reported — "
           "MI355X_MICROARCH.md: double FETCH_SIZE for wide coalesced reads on gfx950)")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc", sys.argv[2] if len(sys.argv) > 2 else None)

@@ -159,30 +159,36 @@ def test_ndt_derivatives(ndt_case):
 
 
 def test_ndt_align(ndt_case):
-    """ndt_omp's Newton iteration (normalised direction, step clamped to [eps/2, 0.1], no line search) amplifies a
-    perturbation of its state by up to ~1e3 per iteration on weakly constrained scans (DESIGN.md "NDT conditioning"), so
-    a last-bit difference in a double sum decides the trajectory after ~5 iterations.  Parity is therefore asserted
-    (i) per derivative pass at 1e-10 (test_ndt_derivatives), (ii) after truncated runs from a deliberately bad guess
-    (2 and 3 derivative passes), and (iii) end-to-end at the north-star tolerance wherever the oracle settles within 8
-    iterations, i.e. wherever the iteration is contractive."""
+    """End-to-end NDT parity.  Every stage is bit-faithful up to the association of double sums: per-pass score /
+    gradient / Hessian agree to ~1e-15 (test_ndt_derivatives), the Newton control path is contraction-free fp64 and the
+    initial Euler angles use libm-independent arithmetic (one float ulp near pi = 2.4e-7 rad used to split the
+    trajectories).  What remains is ndt_omp's iteration itself: normalised direction, step clamped to [eps/2, 0.1], no
+    line search — on weakly constrained scans (VLP-16) it is not contractive and amplifies the last-bit difference of
+    a re-associated sum by up to ~10x per iteration.  So: runs the oracle finishes within 12 iterations must match at
+    1e-6 with the same iteration count (measured 1e-16..4e-9, profiles/r01_b_diag.log, including a 66-iteration
+    HDL-32E run); longer ones must match over their first 8 iterations."""
     e, o, tgt, src, T, kind, p = ndt_case
-    wild = T @ synth.pose_matrix([0.05, 0.02, 0.0], [0.0, 0.0, 0.004])
-    for max_it in (0, 1):
+
+    def truncated(max_it, guess):
         p2 = O.default_params(O.HGS_NDT_OMP)
         p2.resolution, p2.neighbor_search, p2.max_iterations = p.resolution, p.neighbor_search, max_it
         e2, o2 = _hip(p2), O.OracleRegistration(p2)
         PC.load_pair(e2, o2, tgt, src)
-        PC.check_align(e2, o2, wild, tol_m=1e-6, tol_rad=1e-6)
+        PC.check_align(e2, o2, guess, tol_m=1e-6, tol_rad=1e-6)
         e2.close()
-    settled = 0
-    for off in ([0.02, 0.01, 0.0, 0.002], [0.1, -0.05, 0.0, 0.01], [0.3, 0.1, 0.0, 0.02], [0.1, 0.0, 0.0, 0.01]):
+
+    wild = T @ synth.pose_matrix([0.05, 0.02, 0.0], [0.0, 0.0, 0.004])
+    for max_it in (0, 1):   # 2 and 3 derivative passes from a deliberately bad guess
+        truncated(max_it, wild)
+    tight = 0
+    for off in ([0.02, 0.01, 0.0, 0.002], [0.1, -0.05, 0.0, 0.01], [0.3, 0.1, 0.0, 0.02], [0.05, 0.02, 0.0, 0.004]):
         guess = T @ synth.pose_matrix(off[:3], [0, 0, off[3]])
-        ro = o.align(guess)
-        if ro.iterations <= 8:
-            PC.check_align(e, o, guess, same_iterations=False)
-            settled += 1
-    if kind == "hdl32" and p.resolution == 1.0:
-        assert settled >= 2
+        if o.align(guess).iterations <= 12:
+            PC.check_align(e, o, guess, tol_m=1e-6, tol_rad=1e-6)
+            tight += 1
+        else:
+            truncated(6, guess)   # max_iterations 6 -> 8 iterations executed
+    assert tight >= 1
     PC.check_fitness(e, o, T.astype(np.float32))
 
 
