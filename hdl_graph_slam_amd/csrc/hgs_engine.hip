@@ -781,6 +781,11 @@ size_t hgs_cloud_size(const hgs_cloud* c) { return c ? c->n_input : 0; }
 int hgs_cloud_invalidate(hgs_cloud* c) {
   if (!c) return HGS_ERR_INVALID_ARGUMENT;
   c->has_index = false, c->has_cov = false, c->has_ndt = false, c->has_vg = false;
+  // also forget the correspondences of earlier registrations (they seed the next search): a truly cold cloud
+  if (c->owner && c->block) {
+    (void)hipSetDevice(c->owner->device);
+    (void)hipMemsetAsync(c->desc.corr, 0xff, (size_t)c->P * kLeaf * sizeof(int), c->owner->stream);
+  }
   return HGS_OK;
 }
 

@@ -362,6 +362,18 @@ __device__ __forceinline__ Sym3 load_cov(const float4* cov, int i) {
   const float4 a = cov[2 * i], b = cov[2 * i + 1];
   return sym3_from_floats(a.x, a.y, a.z, a.w, b.x, b.y);
 }
+// Streamed-once data (the source side of a registration: points, covariances, correspondences) is read and written
+// with the non-temporal policy so that it does not evict the target's tree / leaves / covariances, which every wave
+// of every candidate re-reads, from the 4 MiB L2 of its XCD.
+__device__ __forceinline__ float4 load_stream(const float4* p) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ Sym3 load_cov_stream(const float4* cov, int i) {
+  const float4 a = load_stream(cov + 2 * i), b = load_stream(cov + 2 * i + 1);
+  return sym3_from_floats(a.x, a.y, a.z, a.w, b.x, b.y);
+}
 
 // update_correspondences + linearize fused: per source point 1-NN in the target tree, Mahalanobis matrix,
 // 6x6 normal-equation terms; wave shuffle + LDS reduction to one 28-double partial per block.
@@ -393,10 +405,10 @@ __global__ __launch_bounds__(kBlock) void k_gicp_linearize(const CloudDesc* desc
   for (int w = 0; w < kNW; w++) {
     idx[w] = tile * kTileNN + (int)(threadIdx.x >> 6) * (64 * kNW) + w * 64 + (int)(threadIdx.x & 63);
     active[w] = idx[w] < n;
-    a[w] = active[w] ? d.pts[idx[w]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    a[w] = active[w] ? load_stream(d.pts + idx[w]) : make_float4(0.f, 0.f, 0.f, 0.f);
     q[w] = transform_point_f(Tf, a[w].x, a[w].y, a[w].z);
     // seed: the correspondence of the previous linearisation (or of an earlier align; -1 / stale values are harmless)
-    seed[w] = active[w] ? d.corr[idx[w]] : -1;
+    seed[w] = active[w] ? __builtin_nontemporal_load(d.corr + idx[w]) : -1;
   }
   wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, c.search_bound2, seed, d2, j, orig);
   const double R[9] = {T.m[0], T.m[1], T.m[2], T.m[4], T.m[5], T.m[6], T.m[8], T.m[9], T.m[10]};
@@ -405,9 +417,9 @@ __global__ __launch_bounds__(kBlock) void k_gicp_linearize(const CloudDesc* desc
     if (active[w]) {
       int jj = j[w];
       if (jj >= 0 && !((double)d2[w] < c.max_corr2)) jj = -1;
-      d.corr[idx[w]] = jj;
+      __builtin_nontemporal_store(jj, d.corr + idx[w]);
       if (jj >= 0) {
-        const Sym3 M = gicp_mahalanobis(R, load_cov(d.cov, idx[w]), load_cov(tgt.cov, jj));
+        const Sym3 M = gicp_mahalanobis(R, load_cov_stream(d.cov, idx[w]), load_cov(tgt.cov, jj));
         const float4 bp = tgt.pts[jj];
         acc[27] += gicp_point_terms<true>(T, M, a[w].x, a[w].y, a[w].z, bp.x, bp.y, bp.z, acc);
       }
@@ -528,10 +540,10 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const CloudDesc* descs, Targ
   for (int w = 0; w < kNW; w++) {
     idx[w] = tile * kTileNN + (int)(threadIdx.x >> 6) * (64 * kNW) + w * 64 + (int)(threadIdx.x & 63);
     active[w] = idx[w] < n;
-    const float4 a = active[w] ? d.pts[idx[w]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = active[w] ? load_stream(d.pts + idx[w]) : make_float4(0.f, 0.f, 0.f, 0.f);
     q[w] = transform_point_f(Tf, a.x, a.y, a.z);
     // use_seed: corr[] holds this cloud's last GICP correspondences against this target — a tight starting bound
-    seed[w] = (active[w] && use_seed) ? d.corr[idx[w]] : -1;
+    seed[w] = (active[w] && use_seed) ? __builtin_nontemporal_load(d.corr + idx[w]) : -1;
   }
   wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, FLT_MAX, seed, d2, j, orig);
 #pragma unroll

@@ -53,3 +53,30 @@ def make_loop_closure_set(sensor: str, scene_seed: int, n_candidates: int, n_dis
         T_gt.append(Tg)
         guesses.append(g)
     return LoopClosureSet(target, cands, T_gt, guesses)
+
+
+@dataclasses.dataclass
+class OdometryStream:
+    scans: List[np.ndarray]           # PointXYZI records, one per LiDAR sweep (sensor frame)
+    poses: List[np.ndarray]           # ground-truth sensor poses in the world frame (4x4 float64)
+    stamps: List[float]
+
+
+def make_odometry_stream(sensor: str, scene_seed: int, n_scans: int, speed: float = 8.0, rate_hz: float = 10.0, yaw_rate_deg: float = 2.0,
+                         downsample: float | None = None) -> OdometryStream:
+    """A vehicle driving along the free corridor of the synthetic scene at `speed` m/s, one sweep every 1/rate_hz s
+    (config 3: KITTI-like 64-beam odometry stream; config 1 with sensor='VLP-16' and a 0.1 m prefilter)."""
+    scene = synth.make_scene(scene_seed)
+    step = speed / rate_hz
+    x0 = -0.5 * step * (n_scans - 1)
+    scans, poses, stamps = [], [], []
+    for i in range(n_scans):
+        yaw = np.deg2rad(yaw_rate_deg) * np.sin(0.35 * i)
+        pose = synth.pose_matrix([x0 + step * i, 0.4 * np.sin(0.2 * i), 0.0], [0.0, 0.0, yaw])
+        sc = synth.scan(scene, sensor, pose, 5000 + 31 * scene_seed + i)
+        if downsample:
+            sc = synth.voxel_downsample(sc, downsample)
+        scans.append(sc)
+        poses.append(pose)
+        stamps.append(i / rate_hz)
+    return OdometryStream(scans, poses, stamps)
