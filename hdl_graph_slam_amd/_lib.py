@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhgs_hip.so")
 HGS_OK = 0
 HGS_FAST_GICP, HGS_FAST_VGICP, HGS_NDT_OMP = 0, 1, 2
 HGS_KDTREE, HGS_DIRECT1, HGS_DIRECT7, HGS_DIRECT27 = 0, 1, 2, 3
-STAGES = ["upload", "index", "covariance", "voxelize", "linearize", "error", "solve", "fitness"]
+STAGES = ["upload", "index", "covariance", "voxelize", "linearize", "error", "solve", "fitness", "prefilter"]
 DBL_MAX = float(np.finfo(np.float64).max)
 
 STATUS = {1: "invalid argument", 2: "no target set", 3: "no source set", 4: "HIP runtime error", 5: "no usable HIP device", 6: "unsupported"}
@@ -32,6 +32,21 @@ class HgsParams(C.Structure):
         ("lm_max_iterations", C.c_int32), ("lm_init_lambda_factor", C.c_double),
         ("device_id", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+class HgsPrefilterParams(C.Structure):
+    """hgs_prefilter_params: the rosparams of apps/prefiltering_nodelet.cpp:51-96."""
+    _fields_ = [
+        ("use_distance_filter", C.c_int32), ("downsample_method", C.c_int32),
+        ("distance_near_thresh", C.c_double), ("distance_far_thresh", C.c_double), ("downsample_resolution", C.c_double),
+        ("outlier_removal_method", C.c_int32), ("statistical_mean_k", C.c_int32),
+        ("statistical_stddev", C.c_double), ("radius_radius", C.c_double),
+        ("radius_min_neighbors", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+HGS_DOWNSAMPLE_NONE, HGS_DOWNSAMPLE_VOXELGRID = 0, 1
+HGS_OUTLIER_NONE, HGS_OUTLIER_STATISTICAL, HGS_OUTLIER_RADIUS = 0, 1, 2
 
 
 class HgsResult(C.Structure):
@@ -56,6 +71,7 @@ EXPORTS = [
     "hgs_set_target", "hgs_set_target_cloud", "hgs_set_source", "hgs_set_source_cloud",
     "hgs_align", "hgs_transform_source", "hgs_fitness", "hgs_nn_target",
     "hgs_loop_match_batch", "hgs_select_best", "hgs_calc_fitness_score",
+    "hgs_prefilter_params_default", "hgs_prefilter", "hgs_cloud_download",
     "hgs_profile_enable", "hgs_profile_read", "hgs_synchronize",
     "hgs_debug_target_covariances", "hgs_debug_gicp_linearize", "hgs_debug_ndt_cells", "hgs_debug_ndt_derivatives",
 ]
@@ -93,6 +109,9 @@ def lib():
     L.hgs_loop_match_batch.argtypes = [vp, C.POINTER(vp), sz, vp, C.c_double, vp, C.POINTER(C.c_int32)]
     L.hgs_select_best.argtypes = [vp, sz, C.POINTER(C.c_int32)]
     L.hgs_calc_fitness_score.argtypes = [vp, vp, vp, fp, C.c_double, C.POINTER(C.c_double)]
+    L.hgs_prefilter_params_default.argtypes = [C.POINTER(HgsPrefilterParams)]
+    L.hgs_prefilter.argtypes = [vp, vp, sz, sz, C.POINTER(HgsPrefilterParams), C.POINTER(vp)]
+    L.hgs_cloud_download.argtypes = [vp, vp, sz]
     L.hgs_profile_enable.argtypes = [vp, C.c_int]
     L.hgs_profile_read.argtypes = [vp, vp, vp, C.c_int]
     L.hgs_synchronize.argtypes = [vp]

@@ -71,7 +71,7 @@ constexpr int kNW = 1;                    // packets of 64 queries a wave walks 
 constexpr int kTileNN = kBlock * kNW;     // source points per block of k_gicp_linearize / k_fitness
 
 // ---- launchers (hgs_kernels.hip) --------------------------------------------------------------------------
-void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw);
+void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw, float* intensity /* may be null */);
 void launch_meta_init(hipStream_t s, const CloudDesc* descs, int ncloud);
 void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n);
 void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals);
@@ -112,6 +112,21 @@ void launch_vgicp_linearize(hipStream_t s, const CloudDesc* descs, NdtTargetView
                             int max_blocks, int B);
 void launch_vgicp_error(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const GicpState* states, VgicpConsts c, double* partials_err,
                         int max_blocks, int B);
+
+// prefilter (apps/prefiltering_nodelet.cpp)
+void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out);
+void launch_pf_distance_flags(hipStream_t s, const float4* pts, int n, int use_filter, double near_thresh, double far_thresh, unsigned* keep);
+void launch_pf_compact(hipStream_t s, const float4* in, int n, const unsigned* keep, const unsigned* slot, float4* out, int* count);
+void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta);
+void launch_pf_grid(hipStream_t s, unsigned* meta, float inv_leaf);
+void launch_pf_voxel_keys(hipStream_t s, const float4* pts, const int* count, const unsigned* meta, float inv_leaf, int cap, unsigned long long* keys, unsigned* vals);
+void launch_pf_voxel_heads(hipStream_t s, const unsigned long long* keys, int cap, unsigned* head);
+void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* slot,
+                               int cap, float4* out, int* count_out);
+void launch_pf_radius_flags(hipStream_t s, CloudDesc d, float r2, int min_neighbors, unsigned* keep);
+void launch_pf_mean_knn_dist(hipStream_t s, CloudDesc d, int mean_k, double* dist);
+void launch_pf_statistical(hipStream_t s, const double* dist, int n, double* stats, double stddev_mul, unsigned* keep);
+void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity);
 
 // stage-level test hooks
 void launch_gicp_debug_state(hipStream_t s, GicpState* st, const double* T12_dev);

@@ -91,6 +91,7 @@ struct hgs_cloud {
   void* block = nullptr;
   size_t block_bytes = 0;
   CloudDesc desc{};
+  float* intensity = nullptr;  // [n_input] PointXYZI intensity (what hgs_cloud_download / the prefilter hand back)
   bool has_index = false;
   bool has_cov = false;
   int cov_k = 0;
@@ -130,6 +131,7 @@ struct hgs_handle {
   float final_T[16];
 
   DeviceBuffer staging, sort_keys[2], sort_vals[2], sort_tmp, descs, states, angles, partials, partials_err, results, guesses, done, misc;
+  DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_descs, h_results, h_small;
 
   bool profiling = false;
@@ -208,6 +210,8 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   off = align_up(off + 2 * slots * sizeof(float4), 256);
   const size_t o_corr = off;
   off = align_up(off + slots * sizeof(int), 256);
+  const size_t o_int = off;
+  off = align_up(off + std::max<size_t>(n, 1) * sizeof(float), 256);
   c->block_bytes = off;
   hipError_t e = hipMalloc(&c->block, off);
   if (e != hipSuccess) {
@@ -223,6 +227,7 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   c->desc.nodes = (float4*)(base + o_nodes);
   c->desc.cov = (float4*)(base + o_cov);
   c->desc.corr = (int*)(base + o_corr);
+  c->intensity = (float*)(base + o_int);
   c->desc.n_input = (int)n;
   c->desc.P = c->P;
   c->desc.sort_off = 0;
@@ -709,7 +714,8 @@ int hgs_destroy(hgs_handle* h) {
   if (h->own_target) cloud_free(h->target);
   if (h->own_source) cloud_free(h->source);
   DeviceBuffer* bufs[] = {&h->staging, &h->sort_keys[0], &h->sort_keys[1], &h->sort_vals[0], &h->sort_vals[1], &h->sort_tmp, &h->descs, &h->states,
-                          &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc};
+                          &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc,
+                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist};
   for (DeviceBuffer* b : bufs) b->release();
   h->h_descs.release();
   h->h_results.release();
@@ -738,7 +744,7 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
         cloud_free(c);
         return HGS_ERR_HIP;
       }
-      launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)n, const_cast<float4*>(c->desc.raw));
+      launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)n, const_cast<float4*>(c->desc.raw), c->intensity);
     }
     // nvalid + bounding box of the finite points
     hipError_t e = h->descs.reserve(sizeof(CloudDesc));
@@ -910,7 +916,7 @@ int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_by
   int* didx = reinterpret_cast<int*>((char*)h->misc.p + align_up(nq * sizeof(float4), 256));
   float* dd2 = reinterpret_cast<float*>(didx + nq);
   HGS_HIP(h, hipMemcpyAsync(h->staging.p, q_xyz, nq * stride_bytes, hipMemcpyHostToDevice, h->stream));
-  launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)nq, dq);
+  launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)nq, dq, nullptr);
   launch_nn_query(h->stream, target_view(h->target), dq, (int)nq, didx, dd2);
   HGS_HIP(h, hipMemcpyAsync(idx, didx, nq * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipMemcpyAsync(d2, dd2, nq * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -949,6 +955,202 @@ int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_c
   HGS_TRY(fetch_results(h, (int)n_candidates, r));
   for (size_t i = 0; i < n_candidates; i++) to_public(r[i], (int)i, true, &out[i]);
   if (best) HGS_TRY(hgs_select_best(out, n_candidates, best));
+  return HGS_OK;
+}
+
+// ---- prefilter (apps/prefiltering_nodelet.cpp:131-182) -------------------------------------------------------
+namespace {
+
+int scan_u32(hgs_handle* h, const uint32_t* in, uint32_t* out, size_t n) {
+  size_t tmp = 0;
+  if (hgs_exclusive_scan_u32(nullptr, &tmp, in, out, n, h->stream) != 0) {
+    h->err = "rocprim exclusive_scan (size query) failed";
+    return HGS_ERR_HIP;
+  }
+  HGS_HIP(h, h->sort_tmp.reserve(tmp));
+  if (hgs_exclusive_scan_u32(h->sort_tmp.p, &tmp, in, out, n, h->stream) != 0) {
+    h->err = "rocprim exclusive_scan failed";
+    return HGS_ERR_HIP;
+  }
+  return HGS_OK;
+}
+
+// a resident cloud from a device array of {x, y, z, intensity}
+int cloud_from_device(hgs_handle* h, const float4* src, size_t m, hgs_cloud** out) {
+  hgs_cloud* c = nullptr;
+  HGS_TRY(cloud_alloc(h, m, &c));
+  launch_pf_to_cloud(h->stream, src, (int)m, const_cast<float4*>(c->desc.raw), c->intensity);
+  hipError_t e = h->descs.reserve(sizeof(CloudDesc));
+  if (e == hipSuccess) e = h->h_descs.reserve(sizeof(CloudDesc));
+  if (e == hipSuccess) {
+    *h->h_descs.as<CloudDesc>() = c->desc;
+    e = hipMemcpyAsync(h->descs.p, h->h_descs.p, sizeof(CloudDesc), hipMemcpyHostToDevice, h->stream);
+  }
+  if (e == hipSuccess) {
+    launch_meta_init(h->stream, h->descs.as<CloudDesc>(), 1);
+    launch_bbox_count(h->stream, h->descs.as<CloudDesc>(), 1, (int)m);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) {
+    h->err = std::string("prefilter: building the resident cloud failed: ") + hipGetErrorString(e);
+    cloud_free(c);
+    return HGS_ERR_HIP;
+  }
+  *out = c;
+  return HGS_OK;
+}
+
+}  // namespace
+
+extern "C" int hgs_prefilter_params_default(hgs_prefilter_params* p) {
+  if (!p) return HGS_ERR_INVALID_ARGUMENT;
+  std::memset(p, 0, sizeof(*p));
+  p->use_distance_filter = 1;          // prefiltering_nodelet.cpp:94
+  p->distance_near_thresh = 1.0;       // :95
+  p->distance_far_thresh = 100.0;      // :96
+  p->downsample_method = HGS_DOWNSAMPLE_VOXELGRID;   // :52
+  p->downsample_resolution = 0.1;      // :53
+  p->outlier_removal_method = HGS_OUTLIER_STATISTICAL;  // :73
+  p->statistical_mean_k = 20;          // :75
+  p->statistical_stddev = 1.0;         // :76
+  p->radius_radius = 0.8;              // :85
+  p->radius_min_neighbors = 2;         // :86
+  return HGS_OK;
+}
+
+extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, hgs_cloud** out) {
+  if (!h || !p || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
+  if (p->downsample_method < HGS_DOWNSAMPLE_NONE || p->downsample_method > HGS_DOWNSAMPLE_VOXELGRID || p->outlier_removal_method < HGS_OUTLIER_NONE ||
+      p->outlier_removal_method > HGS_OUTLIER_RADIUS || (p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID && !(p->downsample_resolution > 0)) ||
+      (p->outlier_removal_method == HGS_OUTLIER_STATISTICAL && (p->statistical_mean_k < 1 || p->statistical_mean_k > 62)) ||
+      (p->outlier_removal_method == HGS_OUTLIER_RADIUS && (!(p->radius_radius > 0) || p->radius_min_neighbors < 0)))
+    return HGS_ERR_INVALID_ARGUMENT;
+  HGS_TRY(set_device(h));
+  *out = nullptr;
+  StageTimer tm(h, HGS_STAGE_PREFILTER);
+  const size_t cap = std::max<size_t>(n, 1);
+  HGS_HIP(h, h->staging.reserve(cap * stride_bytes));
+  HGS_HIP(h, h->pf_a.reserve(cap * sizeof(float4)));
+  HGS_HIP(h, h->pf_b.reserve(cap * sizeof(float4)));
+  HGS_HIP(h, h->pf_keep.reserve(cap * sizeof(uint32_t)));
+  HGS_HIP(h, h->pf_slot.reserve(cap * sizeof(uint32_t)));
+  HGS_HIP(h, h->pf_small.reserve(256));
+  HGS_HIP(h, h->h_small.reserve(64));
+  float4* cur = h->pf_a.as<float4>();
+  float4* other = h->pf_b.as<float4>();
+  int* d_count = h->pf_small.as<int>();                    // [0] current point count
+  unsigned* d_meta = h->pf_small.as<unsigned>() + 16;      // voxel-grid bbox / grid parameters
+  double* d_stats = reinterpret_cast<double*>(h->pf_small.as<char>() + 192);
+  if (n > 0) {
+    HGS_HIP(h, hipMemcpyAsync(h->staging.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream));
+    launch_pf_load(h->stream, h->staging.p, stride_bytes, (int)n, cur);
+  }
+  int host_n = (int)n;
+  HGS_HIP(h, hipMemcpyAsync(d_count, &host_n, sizeof(int), hipMemcpyHostToDevice, h->stream));  // (pageable 4-byte copy: staged by the runtime)
+  if (n > 0 && p->use_distance_filter) {
+    launch_pf_distance_flags(h->stream, cur, (int)n, 1, p->distance_near_thresh, p->distance_far_thresh, h->pf_keep.as<unsigned>());
+    HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));
+    launch_pf_compact(h->stream, cur, (int)n, h->pf_keep.as<unsigned>(), h->pf_slot.as<unsigned>(), other, d_count);
+    std::swap(cur, other);
+  }
+  if (n > 0 && p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID) {
+    const float inv_leaf = 1.0f / (float)p->downsample_resolution;
+    unsigned init[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HGS_HIP(h, hipMemcpyAsync(d_meta, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    launch_pf_bbox(h->stream, cur, d_count, (int)n, d_meta);
+    launch_pf_grid(h->stream, d_meta, inv_leaf);
+    for (int i = 0; i < 2; i++) {
+      HGS_HIP(h, h->sort_keys[i].reserve(n * sizeof(uint64_t)));
+      HGS_HIP(h, h->sort_vals[i].reserve(n * sizeof(uint32_t)));
+    }
+    launch_pf_voxel_keys(h->stream, cur, d_count, d_meta, inv_leaf, (int)n, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
+    size_t tmp_bytes = 0;
+    int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                    h->sort_vals[1].as<uint32_t>(), n, 0, 32, h->stream);
+    if (rc == 0) {
+      HGS_HIP(h, h->sort_tmp.reserve(tmp_bytes));
+      rc = hgs_sort_pairs_u64_u32(h->sort_tmp.p, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                  h->sort_vals[1].as<uint32_t>(), n, 0, 32, h->stream);
+    }
+    if (rc != 0) {
+      h->err = "rocprim radix_sort_pairs failed";
+      return HGS_ERR_HIP;
+    }
+    launch_pf_voxel_heads(h->stream, h->sort_keys[1].as<unsigned long long>(), (int)n, h->pf_keep.as<unsigned>());
+    HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));
+    launch_pf_voxel_centroids(h->stream, cur, h->sort_keys[1].as<unsigned long long>(), h->sort_vals[1].as<unsigned>(), h->pf_keep.as<unsigned>(),
+                              h->pf_slot.as<unsigned>(), (int)n, other, d_count);
+    std::swap(cur, other);
+  }
+  HGS_HIP(h, hipGetLastError());
+  int* hs = h->h_small.as<int>();
+  HGS_HIP(h, hipMemcpyAsync(hs, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipMemcpyAsync(hs + 1, reinterpret_cast<int*>(d_meta) + 12, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  size_t m = (size_t)std::max(0, hs[0]);
+  if (n > 0 && p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID && hs[1]) {
+    h->err = "prefilter: voxel grid too fine for this cloud (index overflow; pcl::VoxelGrid refuses it too)";
+    return HGS_ERR_INVALID_ARGUMENT;
+  }
+  hgs_cloud* c = nullptr;
+  HGS_TRY(cloud_from_device(h, cur, m, &c));
+  if (m > 0 && p->outlier_removal_method != HGS_OUTLIER_NONE) {
+    std::vector<hgs_cloud*> one{c};
+    int rc = ensure_index(h, one);
+    if (rc == HGS_OK) {
+      hipError_t e = hipMemsetAsync(h->pf_keep.p, 0, m * sizeof(uint32_t), h->stream);  // non-finite points are dropped
+      if (e != hipSuccess) rc = HGS_ERR_HIP;
+    }
+    if (rc == HGS_OK) {
+      if (p->outlier_removal_method == HGS_OUTLIER_RADIUS) {
+        launch_pf_radius_flags(h->stream, c->desc, (float)(p->radius_radius * p->radius_radius), p->radius_min_neighbors, h->pf_keep.as<unsigned>());
+      } else {
+        hipError_t e = h->pf_dist.reserve(m * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(h->pf_dist.p, 0, m * sizeof(double), h->stream);
+        if (e != hipSuccess) rc = HGS_ERR_HIP;
+        else {
+          launch_pf_mean_knn_dist(h->stream, c->desc, p->statistical_mean_k, h->pf_dist.as<double>());
+          launch_pf_statistical(h->stream, h->pf_dist.as<double>(), (int)m, d_stats, p->statistical_stddev, h->pf_keep.as<unsigned>());
+        }
+      }
+    }
+    if (rc == HGS_OK) rc = scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), m);
+    if (rc == HGS_OK) {
+      launch_pf_compact(h->stream, cur, (int)m, h->pf_keep.as<unsigned>(), h->pf_slot.as<unsigned>(), other, d_count);
+      hipError_t e = hipMemcpyAsync(hs, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) rc = HGS_ERR_HIP;
+    }
+    cloud_free(c);
+    c = nullptr;
+    if (rc != HGS_OK) {
+      if (h->err.empty()) h->err = "prefilter: outlier removal failed";
+      return rc;
+    }
+    HGS_TRY(cloud_from_device(h, other, (size_t)std::max(0, hs[0]), &c));
+  }
+  *out = c;
+  return HGS_OK;
+}
+
+extern "C" int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_bytes) {
+  if (!c || !c->owner || stride_bytes < 12 || (stride_bytes % 4) != 0 || (c->n_input > 0 && !out_pts)) return HGS_ERR_INVALID_ARGUMENT;
+  hgs_handle* h = c->owner;
+  HGS_TRY(set_device(h));
+  const size_t n = c->n_input;
+  if (n == 0) return HGS_OK;
+  std::vector<float> xyzw(n * 4), inten(n);
+  HGS_HIP(h, hipMemcpyAsync(xyzw.data(), c->desc.raw, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipMemcpyAsync(inten.data(), c->intensity, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  char* o = (char*)out_pts;
+  for (size_t i = 0; i < n; i++) {
+    float* f = reinterpret_cast<float*>(o + i * stride_bytes);
+    f[0] = xyzw[4 * i], f[1] = xyzw[4 * i + 1], f[2] = xyzw[4 * i + 2];
+    if (stride_bytes >= 16) f[3] = 1.0f;
+    if (stride_bytes >= 20) f[4] = inten[i];
+  }
   return HGS_OK;
 }
 

@@ -92,15 +92,16 @@ __device__ __forceinline__ BvhView view_of(const TargetView& t) {
 }
 
 // ------------------------------------------------------------------------------------------------ upload
-__global__ __launch_bounds__(kBlock) void k_pack_aos(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ raw) {
+__global__ __launch_bounds__(kBlock) void k_pack_aos(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ raw, float* __restrict__ intensity) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float* f = reinterpret_cast<const float*>(staging + (size_t)i * stride);
   raw[i] = make_float4(f[0], f[1], f[2], __int_as_float(i));
+  if (intensity) intensity[i] = stride >= 20 ? f[4] : 0.f;  // pcl::PointXYZI keeps the intensity at float 4
 }
-void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw) {
+void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw, float* intensity) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_pack_aos, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const char*)staging, stride, n, raw);
+  hipLaunchKernelGGL(k_pack_aos, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const char*)staging, stride, n, raw, intensity);
 }
 
 // ------------------------------------------------------------------------------------------------ search index
@@ -929,6 +930,256 @@ __global__ __launch_bounds__(kBlock) void k_vgicp_error(const CloudDesc* descs, 
 void launch_vgicp_error(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const GicpState* states, VgicpConsts c, double* partials_err,
                         int max_blocks, int B) {
   hipLaunchKernelGGL(k_vgicp_error, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, c, partials_err, max_blocks);
+}
+
+// ------------------------------------------------------------------------------------------------ prefilter (next row f2)
+// PrefilteringNodelet::cloud_callback, apps/prefiltering_nodelet.cpp:131-133: distance_filter -> downsample
+// (pcl::VoxelGrid) -> outlier_removal (pcl::RadiusOutlierRemoval / pcl::StatisticalOutlierRemoval), on the device.
+// Working format: float4 {x, y, z, intensity}.  Every stage writes keep-flags; a rocPRIM exclusive scan turns them into
+// output slots (order preserving, hence deterministic); the voxel grid reuses the sort-by-cell + segment-head scheme
+// of the NDT / VGICP targets with FLOAT centroids accumulated in input order (CentroidPoint semantics).
+__global__ __launch_bounds__(kBlock) void k_pf_load(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float* f = reinterpret_cast<const float*>(staging + (size_t)i * stride);
+  out[i] = make_float4(f[0], f[1], f[2], stride >= 20 ? f[4] : 0.f);
+}
+void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out) {
+  if (n > 0) hipLaunchKernelGGL(k_pf_load, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const char*)staging, stride, n, out);
+}
+
+// keep[i] = near < |p| < far  (float norm against double thresholds, :170-173); use_filter == 0 keeps everything
+__global__ __launch_bounds__(kBlock) void k_pf_distance_flags(const float4* __restrict__ pts, int n, int use_filter, double near_thresh, double far_thresh,
+                                                              unsigned* __restrict__ keep) {
+  HGS_FP_STRICT
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  const float n2 = p.x * p.x + p.y * p.y + p.z * p.z;
+  const double d = (double)sqrtf(n2);
+  keep[i] = (!use_filter || (d > near_thresh && d < far_thresh)) ? 1u : 0u;
+}
+void launch_pf_distance_flags(hipStream_t s, const float4* pts, int n, int use_filter, double near_thresh, double far_thresh, unsigned* keep) {
+  if (n > 0) hipLaunchKernelGGL(k_pf_distance_flags, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, use_filter, near_thresh, far_thresh, keep);
+}
+
+// out[slot[i]] = in[i] for kept points; *count = number kept (slot = exclusive scan of keep)
+__global__ __launch_bounds__(kBlock) void k_pf_compact(const float4* __restrict__ in, int n, const unsigned* __restrict__ keep, const unsigned* __restrict__ slot,
+                                                       float4* __restrict__ out, int* __restrict__ count) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  if (keep[i]) out[slot[i]] = in[i];
+  if (i == n - 1) *count = (int)(slot[i] + keep[i]);
+}
+void launch_pf_compact(hipStream_t s, const float4* in, int n, const unsigned* keep, const unsigned* slot, float4* out, int* count) {
+  if (n > 0) hipLaunchKernelGGL(k_pf_compact, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, in, n, keep, slot, out, count);
+}
+
+// pcl::VoxelGrid pass 1: bounding box of the finite points (getMinMax3D) into meta[0..5] (ordered-uint encoding)
+__global__ __launch_bounds__(kBlock) void k_pf_bbox(const float4* __restrict__ pts, const int* __restrict__ count, unsigned* __restrict__ meta) {
+  const int n = *count;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = pts[i];
+    if (finite3(p)) {
+      mn[0] = fminf(mn[0], p.x), mn[1] = fminf(mn[1], p.y), mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      mn[k] = fminf(mn[k], __shfl_down(mn[k], off, 64));
+      mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0 && mn[0] <= mx[0])
+    for (int k = 0; k < 3; k++) {
+      atomicMin(&meta[k], f2ord(mn[k]));
+      atomicMax(&meta[3 + k], f2ord(mx[k]));
+    }
+}
+// meta: [0..2] bbmin, [3..5] bbmax (ordered uints) -> [6..8] min_b, [9..11] div_mul, [12] error (index overflow)
+__global__ void k_pf_grid(unsigned* meta, float inv_leaf) {
+  int* im = reinterpret_cast<int*>(meta);
+  if (meta[0] == 0xffffffffu) {  // no finite point
+    for (int k = 6; k < 13; k++) im[k] = 0;
+    return;
+  }
+  long long div[3];
+  for (int k = 0; k < 3; k++) {
+    im[6 + k] = (int)floorf(ord2f(meta[k]) * inv_leaf);
+    div[k] = (long long)(int)floorf(ord2f(meta[3 + k]) * inv_leaf) - im[6 + k] + 1;
+  }
+  im[12] = div[0] * div[1] * div[2] > 2147483647LL ? 1 : 0;
+  im[9] = 1, im[10] = (int)div[0], im[11] = (int)(div[0] * div[1]);
+}
+__global__ __launch_bounds__(kBlock) void k_pf_voxel_keys(const float4* __restrict__ pts, const int* __restrict__ count, const unsigned* __restrict__ meta, float inv_leaf,
+                                                          int cap, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= cap) return;
+  const int* im = reinterpret_cast<const int*>(meta);
+  unsigned long long key = 0xffffffffull;
+  if (i < *count && !im[12]) {
+    const float4 p = pts[i];
+    if (finite3(p)) {
+      const int ix = (int)floorf(p.x * inv_leaf) - im[6], iy = (int)floorf(p.y * inv_leaf) - im[7], iz = (int)floorf(p.z * inv_leaf) - im[8];
+      key = (unsigned long long)(unsigned)(ix * im[9] + iy * im[10] + iz * im[11]);
+    }
+  }
+  keys[i] = key;
+  vals[i] = (unsigned)i;
+}
+// head flags of the sorted key runs (keep) — the scan of these gives each voxel its output slot
+__global__ __launch_bounds__(kBlock) void k_pf_voxel_heads(const unsigned long long* __restrict__ keys, int cap, unsigned* __restrict__ head) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= cap) return;
+  const unsigned long long k = keys[i];
+  head[i] = (k != 0xffffffffull && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+// one thread per voxel: float centroid of x, y, z, intensity over the run in (stable) input order
+__global__ __launch_bounds__(kBlock) void k_pf_voxel_centroids(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                               const unsigned* __restrict__ head, const unsigned* __restrict__ slot, int cap,
+                                                               float4* __restrict__ out, int* __restrict__ count_out) {
+  HGS_FP_STRICT
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= cap) return;
+  if (i == cap - 1) *count_out = (int)(slot[i] + head[i]);
+  if (!head[i]) return;
+  const unsigned long long key = keys[i];
+  float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+  int n = 0;
+  for (int j = i; j < cap && keys[j] == key; j++) {
+    const float4 p = pts[vals[j]];
+    sx += p.x, sy += p.y, sz += p.z, si += p.w;
+    n++;
+  }
+  const float fn = (float)n;
+  out[slot[i]] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+}
+void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta) {
+  int gx = (cap + kBlock * 8 - 1) / (kBlock * 8);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_pf_bbox, dim3(gx), dim3(kBlock), 0, s, pts, count, meta);
+}
+void launch_pf_grid(hipStream_t s, unsigned* meta, float inv_leaf) { hipLaunchKernelGGL(k_pf_grid, dim3(1), dim3(1), 0, s, meta, inv_leaf); }
+void launch_pf_voxel_keys(hipStream_t s, const float4* pts, const int* count, const unsigned* meta, float inv_leaf, int cap, unsigned long long* keys,
+                          unsigned* vals) {
+  if (cap > 0) hipLaunchKernelGGL(k_pf_voxel_keys, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, count, meta, inv_leaf, cap, keys, vals);
+}
+void launch_pf_voxel_heads(hipStream_t s, const unsigned long long* keys, int cap, unsigned* head) {
+  if (cap > 0) hipLaunchKernelGGL(k_pf_voxel_heads, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, keys, cap, head);
+}
+void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* slot,
+                               int cap, float4* out, int* count_out) {
+  if (cap > 0)
+    hipLaunchKernelGGL(k_pf_voxel_centroids, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, keys, vals, head, slot, cap, out, count_out);
+}
+
+// pcl::RadiusOutlierRemoval (:85-93): keep p iff more than min_neighbors points (p included) lie strictly within the
+// radius.  One thread per Hilbert-sorted point, packet walk on the cloud's own tree; the flag lands at the point's
+// ORIGINAL index so that the compaction keeps the input order.
+__global__ __launch_bounds__(kBlock) void k_pf_radius_flags(CloudDesc d, float r2, int min_neighbors, unsigned* __restrict__ keep) {
+  const int n = d.meta->nvalid;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (blockIdx.x * kBlock >= n) return;
+  const bool active = i < n;
+  BvhView tv;
+  tv.nodes = d.nodes, tv.pts = d.pts, tv.lpts = d.lpts, tv.P = d.P, tv.n = n;
+  __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][32];
+  const float4 qp = active ? d.pts[i] : make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+  PacketWalk<RadiusCountLane> w[1];
+  w[0].lane.r2 = active ? r2 : -1.f, w[0].lane.cnt = 0, w[0].lane.need = min_neighbors + 1;
+  w[0].start(tv, F3{qp.x, qp.y, qp.z}, 31 - __clz(tv.P));
+  wave_walk_multi<RadiusCountLane, 1>(tv, w, walk_slots[threadIdx.x >> 6]);
+  if (active) keep[__float_as_int(qp.w)] = w[0].lane.cnt > min_neighbors ? 1u : 0u;
+}
+void launch_pf_radius_flags(hipStream_t s, CloudDesc d, float r2, int min_neighbors, unsigned* keep) {
+  if (d.n_input > 0) hipLaunchKernelGGL(k_pf_radius_flags, dim3((d.n_input + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d, r2, min_neighbors, keep);
+}
+
+// pcl::StatisticalOutlierRemoval (:73-84), pass 1: mean distance of every point to its mean_k nearest OTHER points
+// (k+1 search, the nearest — the point itself — dropped), at the point's ORIGINAL index.
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void k_pf_mean_knn_dist(CloudDesc d, int mean_k, double* __restrict__ dist) {
+  HGS_FP_STRICT
+  const int n = d.meta->nvalid;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (blockIdx.x * kBlock >= n) return;
+  const bool active = i < n;
+  BvhView tv;
+  tv.nodes = d.nodes, tv.pts = d.pts, tv.lpts = d.lpts, tv.P = d.P, tv.n = n;
+  __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][32];
+  const float4 qp = active ? d.pts[i] : make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+  const int live = mean_k + 1 < KMAX ? mean_k + 1 : KMAX;
+  PacketWalk<KnnRadiusLane<KMAX>> w[1];
+  w[0].lane.init(live, active);
+  w[0].start(tv, F3{qp.x, qp.y, qp.z}, 31 - __clz(tv.P));
+  wave_walk_multi<KnnRadiusLane<KMAX>, 1>(tv, w, walk_slots[threadIdx.x >> 6]);
+  if (!active) return;
+  double sum = 0.0;
+  int found = 0;
+#pragma unroll
+  for (int j = KMAX - live; j < KMAX; j++) {
+    const float dd = w[0].lane.d[j];
+    if (dd < FLT_MAX) {
+      if (found > 0) sum += sqrt((double)dd);  // ascending; the first (the point itself) is dropped
+      found++;
+    }
+  }
+  dist[__float_as_int(qp.w)] = found > 1 ? sum / (double)mean_k : 0.0;
+}
+void launch_pf_mean_knn_dist(hipStream_t s, CloudDesc d, int mean_k, double* dist) {
+  if (d.n_input <= 0) return;
+  const dim3 grid((d.n_input + kBlock - 1) / kBlock), block(kBlock);
+  if (mean_k + 1 <= 16) hipLaunchKernelGGL(k_pf_mean_knn_dist<16>, grid, block, 0, s, d, mean_k, dist);
+  else if (mean_k + 1 <= 32) hipLaunchKernelGGL(k_pf_mean_knn_dist<32>, grid, block, 0, s, d, mean_k, dist);
+  else hipLaunchKernelGGL(k_pf_mean_knn_dist<64>, grid, block, 0, s, d, mean_k < 63 ? mean_k : 63, dist);
+}
+// pass 2: sum and sum of squares of dist[0..n) in a fixed order (one block: per-thread strided sums, tree over the block)
+__global__ __launch_bounds__(kBlock) void k_pf_dist_stats(const double* __restrict__ dist, int n, double* __restrict__ out2) {
+  __shared__ double s1[kBlock], s2[kBlock];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const double v = dist[i];
+    a += v, b += v * v;
+  }
+  s1[threadIdx.x] = a, s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s1[threadIdx.x] += s1[threadIdx.x + off], s2[threadIdx.x] += s2[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out2[0] = s1[0], out2[1] = s2[0];
+}
+// pass 3: keep[i] = dist[i] <= mean + mul * stddev (sample standard deviation)
+__global__ __launch_bounds__(kBlock) void k_pf_statistical_flags(const double* __restrict__ dist, int n, const double* __restrict__ stats, double stddev_mul,
+                                                                 unsigned* __restrict__ keep) {
+  HGS_FP_STRICT
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double dn = (double)n;
+  const double mean = stats[0] / dn;
+  const double var = n > 1 ? (stats[1] - stats[0] * stats[0] / dn) / (dn - 1.0) : 0.0;
+  const double thr = mean + stddev_mul * sqrt(var);
+  keep[i] = dist[i] <= thr ? 1u : 0u;
+}
+void launch_pf_statistical(hipStream_t s, const double* dist, int n, double* stats, double stddev_mul, unsigned* keep) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_pf_dist_stats, dim3(1), dim3(kBlock), 0, s, dist, n, stats);
+  hipLaunchKernelGGL(k_pf_statistical_flags, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dist, n, stats, stddev_mul, keep);
+}
+
+// pack a resident float4 {x,y,z,intensity} array into a cloud: raw = {x,y,z,index}, intensity kept beside it
+__global__ __launch_bounds__(kBlock) void k_pf_to_cloud(const float4* __restrict__ in, int n, float4* __restrict__ raw, float* __restrict__ intensity) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  raw[i] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+  intensity[i] = p.w;
+}
+void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity) {
+  if (n > 0) hipLaunchKernelGGL(k_pf_to_cloud, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, in, n, raw, intensity);
 }
 
 }  // namespace hgs

@@ -4,11 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include "hgs_sort.h"
 
 extern "C" int hgs_sort_pairs_u64_u32(void* temp, size_t* temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
                                       uint32_t* vals_out, size_t n, int begin_bit, int end_bit, void* stream) {
   hipError_t e = rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out, n, (unsigned)begin_bit, (unsigned)end_bit,
                                            (hipStream_t)stream, false);
+  return (int)e;
+}
+
+extern "C" int hgs_exclusive_scan_u32(void* temp, size_t* temp_bytes, const uint32_t* in, uint32_t* out, size_t n, void* stream) {
+  hipError_t e = rocprim::exclusive_scan(temp, *temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), (hipStream_t)stream, false);
   return (int)e;
 }

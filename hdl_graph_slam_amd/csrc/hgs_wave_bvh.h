@@ -298,4 +298,18 @@ struct KnnGatherLane {
   }
 };
 
+// ---- radius count: how many points lie strictly within r2 of the query, counting stops once `need` are found ------
+struct RadiusCountLane {
+  float r2;   // -1: no query
+  int cnt, need;
+  __device__ __forceinline__ bool wants(float box_d2) const { return box_d2 < r2 && cnt < need; }
+  __device__ __forceinline__ void visit_leaf(const hgs_f16v& xy, const hgs_f16v& zw, hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, int base) {
+#pragma unroll
+    for (int l = 0; l < 8; l += 2) {
+      const hgs_f2 dd = pk_dist2(qx, qy, qz, hgs_f2{xy[l], xy[l + 1]}, hgs_f2{xy[8 + l], xy[9 + l]}, hgs_f2{zw[l], zw[l + 1]});
+      cnt += (dd.x < r2 ? 1 : 0) + (dd.y < r2 ? 1 : 0);
+    }
+  }
+};
+
 }  // namespace hgs

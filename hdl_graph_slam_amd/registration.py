@@ -28,6 +28,21 @@ class DeviceCloud:
         reg._check(L.lib().hgs_cloud_create(reg._h, arr.ctypes.data_as(C.c_void_p), n, stride, C.byref(self._h)))
         self.size = n
 
+    @classmethod
+    def _adopt(cls, reg: "RegistrationHIP", handle) -> "DeviceCloud":
+        """Wrap an hgs_cloud the library created (hgs_prefilter)."""
+        self = cls.__new__(cls)
+        self._reg, self._h = reg, handle
+        self.size = int(L.lib().hgs_cloud_size(handle))
+        return self
+
+    def download(self) -> np.ndarray:
+        """The resident cloud as pcl::PointXYZI records (x, y, z, 1, intensity)."""
+        from . import synth
+        out = np.zeros(self.size, dtype=synth.POINT_XYZI_DTYPE)
+        self._reg._check(L.lib().hgs_cloud_download(self._h, out.ctypes.data_as(C.c_void_p), out.dtype.itemsize))
+        return out
+
     def invalidate(self):
         L.lib().hgs_cloud_invalidate(self._h)
 
@@ -144,6 +159,17 @@ class RegistrationHIP:
     # ---- device clouds / batch (LoopDetector::matching)
     def upload(self, cloud) -> DeviceCloud:
         return DeviceCloud(self, cloud)
+
+    def prefilter(self, cloud, params=None) -> DeviceCloud:
+        """PrefilteringNodelet::cloud_callback (apps/prefiltering_nodelet.cpp:131-133) on the device: distance filter ->
+        voxel grid -> outlier removal.  Returns a resident cloud usable as setInputSource / setInputTarget argument."""
+        if params is None:
+            params = L.HgsPrefilterParams()
+            self._check(L.lib().hgs_prefilter_params_default(C.byref(params)))
+        arr, n, stride = L.cloud_args(cloud)
+        h = C.c_void_p()
+        self._check(L.lib().hgs_prefilter(self._h, arr.ctypes.data_as(C.c_void_p), n, stride, C.byref(params), C.byref(h)))
+        return DeviceCloud._adopt(self, h)
 
     def loop_match_batch(self, candidates, guesses, max_range: float = L.DBL_MAX):
         """Register every candidate DeviceCloud against the current target; returns (records ndarray, best index)."""

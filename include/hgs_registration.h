@@ -136,6 +136,32 @@ int hgs_select_best(const hgs_result* records, size_t n, int32_t* best);
 /* ---- "next" row f1: InformationMatrixCalculator::calc_fitness_score (information_matrix_calculator.cpp:49-80) */
 int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, const float relpose[16], double max_range, double* score);
 
+/* ---- "next" row f2: the prefilter in front of the path (apps/prefiltering_nodelet.cpp:131-182) -------------------- */
+enum hgs_downsample_method { HGS_DOWNSAMPLE_NONE = 0, HGS_DOWNSAMPLE_VOXELGRID = 1 };          /* :51-72  */
+enum hgs_outlier_removal { HGS_OUTLIER_NONE = 0, HGS_OUTLIER_STATISTICAL = 1, HGS_OUTLIER_RADIUS = 2 }; /* :73-93 */
+typedef struct hgs_prefilter_params {
+  int32_t use_distance_filter;     /* use_distance_filter   (true)   :94                                  */
+  int32_t downsample_method;       /* downsample_method     (VOXELGRID)                                    */
+  double distance_near_thresh;     /* distance_near_thresh  (1.0)    :95                                  */
+  double distance_far_thresh;      /* distance_far_thresh   (100.0)  :96                                  */
+  double downsample_resolution;    /* downsample_resolution (0.1)    :53                                  */
+  int32_t outlier_removal_method;  /* outlier_removal_method (STATISTICAL)                                 */
+  int32_t statistical_mean_k;      /* statistical_mean_k    (20)                                           */
+  double statistical_stddev;       /* statistical_stddev    (1.0)                                          */
+  double radius_radius;            /* radius_radius         (0.8)                                          */
+  int32_t radius_min_neighbors;    /* radius_min_neighbors  (2)                                            */
+  int32_t reserved;
+} hgs_prefilter_params;
+int hgs_prefilter_params_default(hgs_prefilter_params* p);
+/* distance_filter -> downsample -> outlier_removal of PrefilteringNodelet::cloud_callback (:131-133) on the device.
+ * Input: pcl::PointXYZI records (intensity = float 4 of each record when stride >= 20).  The result stays resident as
+ * an hgs_cloud that can be handed to hgs_set_source_cloud / hgs_set_target_cloud directly (no second upload) and
+ * fetched with hgs_cloud_download. */
+int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, hgs_cloud** out);
+/* Copy a resident cloud back: out_pts[i] = {x, y, z, (1.0), intensity, ...} with the PointXYZI layout for stride >= 20,
+ * packed xyz(+w) otherwise.  Needs room for hgs_cloud_size(c) records. */
+int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_bytes);
+
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 enum hgs_stage {
   HGS_STAGE_UPLOAD = 0,     /* H2D + pack                                            */
@@ -146,7 +172,8 @@ enum hgs_stage {
   HGS_STAGE_ERROR = 5,      /* LM trial error evaluation                             */
   HGS_STAGE_SOLVE = 6,      /* 6x6 reductions + solve + LM/Newton update             */
   HGS_STAGE_FITNESS = 7,    /* fitness score NN pass                                 */
-  HGS_STAGE_COUNT = 8
+  HGS_STAGE_PREFILTER = 8,  /* distance filter + voxel grid + outlier removal        */
+  HGS_STAGE_COUNT = 9
 };
 /* Enable/disable hipEvent bracketing of every kernel stage on the handle's stream (adds sync cost when read). */
 int hgs_profile_enable(hgs_handle* h, int enabled);

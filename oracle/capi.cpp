@@ -9,6 +9,7 @@
 #include "gicp.hpp"
 #include "ndt.hpp"
 #include "vgicp.hpp"
+#include "prefilter.hpp"
 
 using namespace hgso;
 
@@ -223,6 +224,20 @@ int hgso_ndt_derivatives(hgso_handle* h, const double* p, double* score, double*
   }
   return 0;
 }
+// Prefilter (apps/prefiltering_nodelet.cpp): points are records with x,y,z at floats 0..2 and intensity at float 4
+// (pcl::PointXYZI) when the stride allows, else intensity 0.  out receives {x,y,z,intensity} float4 records;
+// returns the number of output points or -1 (voxel index overflow).
+long hgso_prefilter(const void* pts, size_t n, size_t stride, const PrefilterParams* prm, float* out4, size_t cap) {
+  std::vector<PfPoint> in(n), out;
+  for (size_t i = 0; i < n; i++) {
+    const float* f = (const float*)((const char*)pts + i * stride);
+    in[i] = {f[0], f[1], f[2], stride >= 20 ? f[4] : 0.f};
+  }
+  if (!prefilter(in, *prm, out)) return -1;
+  for (size_t i = 0; i < out.size() && i < cap; i++) out4[4 * i] = out[i].x, out4[4 * i + 1] = out[i].y, out4[4 * i + 2] = out[i].z, out4[4 * i + 3] = out[i].intensity;
+  return (long)out.size();
+}
+
 // helpers exposed for unit tests of the math primitives
 int hgso_se3_exp(const double* d6, double* T12) {
   V6 d;

@@ -65,7 +65,29 @@ public:
     return r;
   }
 
+  // number of points with d2 < r2 (strict), counting stops at `cap`
+  int count_within(const P3f& q, float r2, int cap) const {
+    if (nodes_.empty()) return 0;
+    int cnt = 0;
+    count_rec(0, q, r2, cap, cnt);
+    return cnt;
+  }
+
 private:
+  void count_rec(int id, const P3f& q, float r2, int cap, int& cnt) const {
+    if (cnt >= cap) return;
+    const Node& nd = nodes_[id];
+    if (nd.left < 0) {
+      for (int i = nd.lo; i < nd.hi && cnt < cap; i++)
+        if (dist2f(q, (*pts_)[order_[i]]) < r2) cnt++;
+      return;
+    }
+    const float qc = nd.dim == 0 ? q.x : (nd.dim == 1 ? q.y : q.z);
+    const float diff = qc - nd.split;
+    count_rec(diff < 0 ? nd.left : nd.right, q, r2, cap, cnt);
+    if (diff * diff < r2) count_rec(diff < 0 ? nd.right : nd.left, q, r2, cap, cnt);
+  }
+
   struct Node {
     int lo, hi;      // range in order_
     int left, right; // children (-1 for leaf)

@@ -98,6 +98,8 @@ def lib():
         L.hgso_covariances.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
         L.hgso_gicp_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_gicp_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hgso_prefilter.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.hgso_prefilter.restype = C.c_long
         L.hgso_ndt_cells.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
@@ -239,6 +241,35 @@ def covariances(points: np.ndarray, k: int = 20) -> np.ndarray:
     out = np.zeros((n, 6))
     lib().hgso_covariances(_ptr(p), n, s, k, _ptr(out))
     return out
+
+
+class PrefilterParams(C.Structure):
+    """Same layout as hgs_prefilter_params (include/hgs_registration.h): the rosparams of apps/prefiltering_nodelet.cpp:51-96."""
+    _fields_ = [
+        ("use_distance_filter", C.c_int32), ("downsample_method", C.c_int32),
+        ("distance_near_thresh", C.c_double), ("distance_far_thresh", C.c_double), ("downsample_resolution", C.c_double),
+        ("outlier_removal_method", C.c_int32), ("statistical_mean_k", C.c_int32),
+        ("statistical_stddev", C.c_double), ("radius_radius", C.c_double),
+        ("radius_min_neighbors", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+def default_prefilter_params() -> PrefilterParams:
+    """Defaults of apps/prefiltering_nodelet.cpp:51-96."""
+    return PrefilterParams(1, 1, 1.0, 100.0, 0.1, 1, 20, 1.0, 0.8, 2, 0)
+
+
+def prefilter(cloud: np.ndarray, params) -> np.ndarray:
+    """distance_filter -> pcl::VoxelGrid -> outlier removal; returns [m, 4] float32 {x, y, z, intensity}."""
+    arr, n, stride = _cloud_args(cloud)
+    p = PrefilterParams()
+    for name, _ in PrefilterParams._fields_:
+        setattr(p, name, getattr(params, name))
+    out = np.zeros((max(n, 1), 4), np.float32)
+    m = lib().hgso_prefilter(_ptr(arr), n, stride, C.byref(p), _ptr(out), max(n, 1))
+    if m < 0:
+        raise ValueError("voxel grid index overflow")
+    return out[:m].copy()
 
 
 def se3_exp(d6) -> np.ndarray:

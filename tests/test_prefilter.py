@@ -1,0 +1,136 @@
+"""Prefilter ("next" row f2: apps/prefiltering_nodelet.cpp:131-182): the oracle against an independent numpy
+restatement, the ABI, and (-m gpu) the HIP pipeline against the oracle — point for point, in order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from hdl_graph_slam_amd import synth
+
+
+def _scan(seed=3, n_extra=40):
+    scene = synth.make_scene(seed)
+    cloud = synth.scan(scene, "VLP-16", synth.pose_matrix([0, 0, 0], [0, 0, 0]), 100 + seed)
+    rng = np.random.default_rng(seed)
+    cloud["intensity"] = rng.uniform(0, 255, len(cloud)).astype(np.float32)
+    # a few isolated far-away points (outliers) and two non-finite records
+    extra = synth.to_xyzi(rng.uniform(-80, 80, (n_extra, 3)).astype(np.float32) * [1, 1, 0.2], rng.uniform(0, 255, n_extra))
+    bad = synth.to_xyzi(np.array([[np.nan, 0, 0], [1, np.inf, 2]], np.float32))
+    return np.concatenate([cloud, extra, bad])
+
+
+def _np_distance_voxel(cloud, near, far, leaf):
+    xyz = synth.xyz_of(cloud).astype(np.float32)
+    inten = cloud["intensity"].astype(np.float32)
+    d = np.sqrt((xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1]) + xyz[:, 2] * xyz[:, 2]).astype(np.float64)
+    keep = (d > near) & (d < far)
+    xyz, inten = xyz[keep], inten[keep]
+    inv = np.float32(1.0) / np.float32(leaf)
+    ijk = np.floor(xyz * inv).astype(np.int64)
+    mn = np.floor(xyz.min(axis=0) * inv).astype(np.int64)
+    div = np.floor(xyz.max(axis=0) * inv).astype(np.int64) - mn + 1
+    key = (ijk[:, 0] - mn[0]) + (ijk[:, 1] - mn[1]) * div[0] + (ijk[:, 2] - mn[2]) * div[0] * div[1]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    starts = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+    ends = np.concatenate([starts[1:], [len(ks)]])
+    out = np.zeros((len(starts), 4), np.float32)
+    for v, (a, b) in enumerate(zip(starts, ends)):
+        acc = np.zeros(4, np.float32)
+        for i in order[a:b]:
+            acc = (acc + np.array([xyz[i, 0], xyz[i, 1], xyz[i, 2], inten[i]], np.float32)).astype(np.float32)
+        out[v] = acc / np.float32(b - a)
+    return out
+
+
+def test_oracle_distance_filter_and_voxelgrid_match_numpy():
+    cloud = _scan()
+    p = O.default_prefilter_params()
+    p.outlier_removal_method = 0
+    p.downsample_resolution = 0.25
+    got = O.prefilter(cloud, p)
+    ref = _np_distance_voxel(cloud[np.isfinite(synth.xyz_of(cloud)).all(axis=1)], 1.0, 100.0, 0.25)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_oracle_outlier_removal_properties():
+    cloud = _scan()
+    base = O.default_prefilter_params()
+    base.outlier_removal_method = 0
+    pts = O.prefilter(cloud, base)
+    from scipy.spatial import cKDTree
+    tree = cKDTree(pts[:, :3].astype(np.float64))
+    # radius: kept <=> at least min_neighbors OTHER points within the radius
+    pr = O.default_prefilter_params()
+    pr.outlier_removal_method, pr.radius_radius, pr.radius_min_neighbors = 2, 0.5, 2
+    kept = O.prefilter(cloud, pr)
+    cnt = np.array([len(v) for v in tree.query_ball_point(pts[:, :3].astype(np.float64), 0.5 * (1 - 1e-7))]) - 1
+    borderline = np.array([len(v) for v in tree.query_ball_point(pts[:, :3].astype(np.float64), 0.5 * (1 + 1e-6))]) - 1
+    sure = cnt == borderline
+    expect = pts[(cnt >= 2) | ~sure]
+    assert len(kept) <= len(expect) and len(kept) >= int(((cnt >= 2) & sure).sum())
+    # statistical: idempotent ordering, removes the isolated points, keeps most of the scan
+    ps = O.default_prefilter_params()
+    kept_s = O.prefilter(cloud, ps)
+    assert 0.7 * len(pts) < len(kept_s) < len(pts)
+    d, _ = tree.query(kept_s[:, :3].astype(np.float64), k=1)
+    assert d.max() < 1e-6    # a subset of the downsampled points, unchanged
+
+
+def test_prefilter_abi_defaults():
+    from hdl_graph_slam_amd import _lib as L
+    assert C.sizeof(L.HgsPrefilterParams) == C.sizeof(O.PrefilterParams) == 64
+    p = L.HgsPrefilterParams()
+    assert L.lib().hgs_prefilter_params_default(C.byref(p)) == 0
+    q = O.default_prefilter_params()
+    assert all(getattr(p, n) == getattr(q, n) for n, _ in L.HgsPrefilterParams._fields_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("outlier", [0, 1, 2])
+@pytest.mark.parametrize("leaf", [0.1, 0.5, None])
+def test_hip_prefilter_matches_oracle(outlier, leaf):
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    cloud = _scan(5)
+    p = L.HgsPrefilterParams()
+    L.lib().hgs_prefilter_params_default(C.byref(p))
+    p.outlier_removal_method = outlier
+    p.radius_radius, p.radius_min_neighbors = 0.5, 2
+    if leaf is None:
+        p.downsample_method = 0
+    else:
+        p.downsample_resolution = leaf
+    reg = RegistrationHIP(L.default_params(L.HGS_FAST_GICP))
+    dc = reg.prefilter(cloud, p)
+    got = dc.download()
+    ref = O.prefilter(cloud, p)
+    assert len(got) == len(ref), (len(got), len(ref))
+    g4 = np.stack([got["x"], got["y"], got["z"], got["intensity"]], axis=1)
+    assert np.array_equal(g4, ref)      # float centroids accumulated in the same order: bit-identical, same order
+    # the resident result is a registration input without a second upload
+    reg.setInputTarget(dc)
+    reg.setInputSource(dc)
+    r = reg.align(np.eye(4))
+    assert r.converged and np.abs(r.matrix() - np.eye(4)).max() < 1e-5
+    dc.close()
+    reg.close()
+
+
+@pytest.mark.gpu
+def test_hip_prefilter_edge_cases():
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    reg = RegistrationHIP(L.default_params(L.HGS_NDT_OMP))
+    empty = reg.prefilter(np.zeros((0, 4), np.float32))
+    assert empty.size == 0 and len(empty.download()) == 0
+    near = synth.to_xyzi(np.array([[0.1, 0.1, 0.0], [0.2, 0.0, 0.1]], np.float32))   # everything inside distance_near_thresh
+    assert reg.prefilter(near).size == 0
+    one = synth.to_xyzi(np.array([[5.0, 1.0, 0.5]], np.float32), [7.0])
+    p = L.HgsPrefilterParams()
+    L.lib().hgs_prefilter_params_default(C.byref(p))
+    p.outlier_removal_method = 0
+    out = reg.prefilter(one, p).download()
+    assert len(out) == 1 and out["intensity"][0] == 7.0 and out["x"][0] == 5.0
+    reg.close()
