@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--candidates", type=int, default=16, help="candidate keyframes per GPU per step")
     ap.add_argument("--sensor", default="HDL-64E")
     ap.add_argument("--distinct", type=int, default=8, help="distinct ray-cast scans behind the candidates")
-    ap.add_argument("--method", default="FAST_GICP", choices=["FAST_GICP", "NDT_OMP"])
+    ap.add_argument("--method", default="FAST_GICP", choices=["FAST_GICP", "FAST_VGICP", "NDT_OMP"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=3, help="candidates registered by the CPU oracle for cpu_baseline")
     args = ap.parse_args()
@@ -64,8 +64,8 @@ def main():
     from hdl_graph_slam_amd.distributed import CandidateShard
 
     pnh = {"registration_method": args.method}
-    if args.method == "NDT_OMP":
-        pnh["reg_resolution"] = 1.0   # launch files use 1.0 (factory default 0.5)
+    if args.method in ("NDT_OMP", "FAST_VGICP"):
+        pnh["reg_resolution"] = 1.0   # launch files use 1.0 (NDT factory default 0.5)
     B = args.candidates
     # every rank holds the query keyframe (replicated target) and its own shard of the N*B candidates
     wl = workloads.make_loop_closure_set(args.sensor, scene_seed=0, n_candidates=B, n_distinct=min(args.distinct, B))
@@ -136,6 +136,9 @@ def main():
         ALG_BYTES["linearize"] = ("k_ndt_derivatives", 296.0)
         units["linearize"] = prof_steps * float(np.sum(rec_p["lm_tries"].astype(np.float64) * np.array(n_pts)))
         units["covariance"] = units["error"] = 0.0
+    if args.method == "FAST_VGICP":
+        ALG_BYTES["linearize"] = ("k_vgicp_linearize", 80.0)
+        ALG_BYTES["error"] = ("k_vgicp_error", 80.0)
     dom = max((s for s in ALG_BYTES if prof[s][1] > 0), key=lambda s: prof[s][0])
     ms, launches = prof[dom]
     kname, bytes_per_unit = ALG_BYTES[dom]
@@ -199,7 +202,7 @@ def main():
         out = {
             "metric": "registrations/sec (64-beam ~120k-pt pair), loop-closure batch", "value": round(regs / dt, 3), "unit": "registrations/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.method == "FAST_GICP" else "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.method == "NDT_OMP" else "f64",
             "data": "synthetic",
             "config": {"workload": f"loop-closure batch: {B} candidate keyframes/GPU x {args.sensor} (~{int(np.mean(n_pts))} pts) vs 1 query keyframe, "
                                    f"{args.method} + getFitnessScore, cold (index + covariances rebuilt every step)",

@@ -76,3 +76,56 @@ def test_hip_reproduces_golden():
     assert (np.abs(cov - G["target_cov"]).max(axis=1) / np.abs(G["target_cov"]).max(axis=1)).max() < 5e-6
     e.close()
     n.close()
+
+
+# ---- second fixture: FAST_VGICP + prefilter ------------------------------------------------------------------------
+G2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vlp16_vgicp_prefilter_seed2.npz"))
+
+
+def _raw2():
+    a = G2["raw_xyzi"]
+    return synth.to_xyzi(a[:, :3], a[:, 3])
+
+
+def _prefilter_cases():
+    p = O.default_prefilter_params()
+    yield "prefilter_default", p
+    q = O.default_prefilter_params()
+    q.downsample_resolution, q.outlier_removal_method, q.radius_radius, q.radius_min_neighbors = 0.25, 2, 0.5, 2
+    yield "prefilter_kitti_radius", q
+
+
+def _check_vgicp(e, tol_pose, rel_stage):
+    e.setInputTarget(G2["target_xyz"])
+    e.setInputSource(G2["source_xyz"])
+    H, b, err, hits = e.gicp_linearize(np.eye(4))
+    assert np.array_equal(hits, G2["vgicp_hits_identity"])
+    assert np.abs(H - G2["vgicp_H_identity"]).max() <= rel_stage * np.abs(G2["vgicp_H_identity"]).max()
+    assert np.abs(b - G2["vgicp_b_identity"]).max() <= rel_stage * np.abs(G2["vgicp_b_identity"]).max()
+    assert abs(err - G2["vgicp_err_identity"]) <= rel_stage * G2["vgicp_err_identity"]
+    r = e.align(np.eye(4))
+    dt, dr = synth.pose_error(r.matrix(), G2["vgicp_final"])
+    assert dt <= tol_pose and dr <= tol_pose
+    assert r.converged == G2["vgicp_converged"] and r.iterations == G2["vgicp_iterations"] and r.lm_tries == G2["vgicp_lm_tries"]
+
+
+def test_oracle_reproduces_golden_v2():
+    for name, p in _prefilter_cases():
+        assert np.array_equal(O.prefilter(_raw2(), p), G2[name])
+    _check_vgicp(O.OracleRegistration(O.default_params(O.HGS_FAST_VGICP)), tol_pose=1e-7, rel_stage=1e-9)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_v2():
+    import ctypes as C
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    e = RegistrationHIP(L.default_params(L.HGS_FAST_VGICP))
+    for name, p in _prefilter_cases():
+        q = L.HgsPrefilterParams()
+        for f, _ in L.HgsPrefilterParams._fields_:
+            setattr(q, f, getattr(p, f))
+        got = e.prefilter(_raw2(), q).download()
+        assert np.array_equal(np.stack([got["x"], got["y"], got["z"], got["intensity"]], axis=1), G2[name])
+    _check_vgicp(e, tol_pose=1e-5, rel_stage=2e-5)
+    e.close()
