@@ -58,9 +58,10 @@ __device__ __forceinline__ void block_reduce_store(const double* acc, double* ou
 // ROWS x N threads (ROWS = 256 / N: 9 x 28 for GICP, 5 x 43 for NDT) read ROWS*N consecutive doubles per step (fully
 // coalesced), each thread owns one (row, column) and walks tiles row, row+ROWS, ... ; the rows are then added in a
 // fixed order -> bitwise reproducible.
+constexpr int kSolveBlock = 256;  // 1024 was measured slower: the serial 6x6 solve that follows runs with a quarter of the registers
 template <int N>
-__device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int ntiles, double* out /* LDS [N] */, double* scratch /* LDS [(256/N)*N] */) {
-  constexpr int ROWS = kBlock / N;
+__device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int ntiles, double* out /* LDS [N] */, double* scratch /* LDS [kSolveBlock] */) {
+  constexpr int ROWS = kSolveBlock / N;
   const int t = threadIdx.x;
   if (t < ROWS * N) {
     const int col = t % N, row = t / N;
@@ -433,20 +434,20 @@ void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt
   hipLaunchKernelGGL(k_gicp_linearize, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks);
 }
 
-__global__ __launch_bounds__(kBlock) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
+__global__ __launch_bounds__(kSolveBlock) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
                                                       int max_blocks, int tile_points) {
   const int b = blockIdx.x;
   GicpState& st = states[b];
   if (st.phase != GICP_LINEARIZE) return;
   __shared__ double acc[kAcc];
-  __shared__ double scratch[kBlock];
+  __shared__ double scratch[kSolveBlock];
   const int ntiles = (descs[b].meta->nvalid + tile_points - 1) / tile_points;  // tiles of the linearize kernel that filled `partials`
   reduce_tiles<kAcc>(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);
   if (threadIdx.x == 0) gicp_after_linearize(st, acc, c);
 }
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
                        int tile_points) {
-  hipLaunchKernelGGL(k_gicp_solve, dim3(B), dim3(kBlock), 0, s, descs, states, c, partials, max_blocks, tile_points);
+  hipLaunchKernelGGL(k_gicp_solve, dim3(B), dim3(kSolveBlock), 0, s, descs, states, c, partials, max_blocks, tile_points);
 }
 
 // compute_error(xi): same correspondences, Mahalanobis matrices of the linearisation pose x0, residuals at xi.
@@ -746,13 +747,13 @@ void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView
   hipLaunchKernelGGL(k_ndt_derivatives, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, angles, c, partials, max_blocks);
 }
 
-__global__ __launch_bounds__(kBlock) void k_ndt_solve(const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c,
+__global__ __launch_bounds__(kSolveBlock) void k_ndt_solve(const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c,
                                                      const double* __restrict__ partials, int max_blocks, int* done_counter) {
   const int b = blockIdx.x;
   NdtState& st = states[b];
   if (st.phase != NDT_DERIV) return;
   __shared__ double acc[kAccNdt];
-  __shared__ double scratch[kBlock];
+  __shared__ double scratch[kSolveBlock];
   const int ntiles = (descs[b].n_input + kBlock - 1) / kBlock;
   reduce_tiles<kAccNdt>(partials + (size_t)b * max_blocks * kAccNdt, ntiles, acc, scratch);
   if (threadIdx.x == 0) {
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void k_ndt_solve(const CloudDesc* descs, Nd
 }
 void launch_ndt_solve(hipStream_t s, const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c, const double* partials, int max_blocks,
                       int B, int* done_counter) {
-  hipLaunchKernelGGL(k_ndt_solve, dim3(B), dim3(kBlock), 0, s, descs, states, angles, c, partials, max_blocks, done_counter);
+  hipLaunchKernelGGL(k_ndt_solve, dim3(B), dim3(kSolveBlock), 0, s, descs, states, angles, c, partials, max_blocks, done_counter);
 }
 
 __global__ void k_ndt_results(const CloudDesc* descs, const NdtState* states, DevResult* out, int B) {
@@ -1206,15 +1207,15 @@ void launch_ndt_debug_state(hipStream_t s, NdtState* st, NdtAngles* ang, const d
 
 // out[k] = sum over tiles of partials[t*N + k], in the order k_gicp_solve (N = kAcc) / k_ndt_solve (N = kAccNdt) use
 template <int N>
-__global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ partials, int ntiles, double* out) {
+__global__ __launch_bounds__(kSolveBlock) void k_reduce_partials(const double* __restrict__ partials, int ntiles, double* out) {
   __shared__ double acc[N];
-  __shared__ double scratch[kBlock];
+  __shared__ double scratch[kSolveBlock];
   reduce_tiles<N>(partials, ntiles, acc, scratch);
   if (threadIdx.x < N) out[threadIdx.x] = acc[threadIdx.x];
 }
 void launch_reduce_partials(hipStream_t s, const double* partials, int ntiles, int width, double* out) {
-  if (width == kAccNdt) hipLaunchKernelGGL(k_reduce_partials<kAccNdt>, dim3(1), dim3(kBlock), 0, s, partials, ntiles, out);
-  else hipLaunchKernelGGL(k_reduce_partials<kAcc>, dim3(1), dim3(kBlock), 0, s, partials, ntiles, out);
+  if (width == kAccNdt) hipLaunchKernelGGL(k_reduce_partials<kAccNdt>, dim3(1), dim3(kSolveBlock), 0, s, partials, ntiles, out);
+  else hipLaunchKernelGGL(k_reduce_partials<kAcc>, dim3(1), dim3(kSolveBlock), 0, s, partials, ntiles, out);
 }
 
 }  // namespace hgs
