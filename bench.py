@@ -81,10 +81,11 @@ def main():
     n_pts = [len(c) for c in wl.candidates]
     shard = CandidateShard(rank, world, device=torch.device("cuda", local_rank)) if world > 1 else None
 
-    def step():
-        d_target.invalidate()
-        for c in d_cands:
-            c.invalidate()
+    def step(cold=True):
+        d_target.invalidate()           # the query keyframe is new in every detection
+        if cold:
+            for c in d_cands:           # reference behaviour: setInputSource rebuilds tree + covariances of every candidate
+                c.invalidate()
         reg.setInputTarget(d_target)
         rec, best = reg.loop_match_batch(d_cands, wl.guesses, L.DBL_MAX)
         if shard is not None:
@@ -111,6 +112,16 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- informational: the same batch with the candidate keyframes' index + covariances kept resident between
+    # detections (what a keyframe device cache gives; never `value`)
+    step(cold=False)
+    barrier()
+    tw = time.perf_counter()
+    for _ in range(args.steps):
+        step(cold=False)
+    barrier()
+    dt_warm = time.perf_counter() - tw
 
     # ---- accuracy of the timed results (rank-local): vs ground truth
     et = [synth.pose_error(np.array(r["final_transformation"]).reshape(4, 4).T, Tg) for r, Tg in zip(rec, wl.T_gt)]
@@ -209,6 +220,7 @@ def main():
                        "candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": args.method,
                        "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU"},
             "pose_rmse_vs_ground_truth": {"translation_m": round(rmse_t, 5), "rotation_rad": round(rmse_r, 6)},
+            "resident_keyframes_value": round(world * B * args.steps / dt_warm, 3) if world == 1 else None,
             "converged": int(np.sum(rec["converged"])), "mean_iterations": float(np.mean(rec["iterations"])), "best_candidate": int(best),
             "roofline": roofline, "cpu_baseline": cpu,
         }
