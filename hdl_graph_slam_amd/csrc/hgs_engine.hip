@@ -134,6 +134,10 @@ struct hgs_handle {
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_descs, h_results, h_small;
 
+  // freed cloud blocks kept for reuse: the odometry path creates and destroys one cloud per sweep, and hipMalloc /
+  // hipFree (which synchronises the device) cost more than the upload itself
+  std::vector<std::pair<void*, size_t>> block_pool;
+
   bool profiling = false;
   std::vector<ProfEvent> prof_events;
   std::vector<ProfEvent> prof_free;
@@ -213,7 +217,16 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   const size_t o_int = off;
   off = align_up(off + std::max<size_t>(n, 1) * sizeof(float), 256);
   c->block_bytes = off;
-  hipError_t e = hipMalloc(&c->block, off);
+  hipError_t e = hipSuccess;
+  for (size_t k = 0; k < h->block_pool.size(); k++) {
+    if (h->block_pool[k].second >= off && h->block_pool[k].second <= 2 * off + (1u << 20)) {
+      c->block = h->block_pool[k].first;
+      c->block_bytes = h->block_pool[k].second;
+      h->block_pool.erase(h->block_pool.begin() + k);
+      break;
+    }
+  }
+  if (!c->block) e = hipMalloc(&c->block, off);
   if (e != hipSuccess) {
     h->err = std::string("hipMalloc(cloud) failed: ") + hipGetErrorString(e);
     delete c;
@@ -239,7 +252,12 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
 
 void cloud_free(hgs_cloud* c) {
   if (!c) return;
-  if (c->block) (void)hipFree(c->block);
+  if (c->block) {
+    // stream order makes reuse safe: every kernel that touches the block was enqueued on the owner's stream
+    hgs_handle* h = c->owner;
+    if (h && h->block_pool.size() < 6) h->block_pool.emplace_back(c->block, c->block_bytes);
+    else (void)hipFree(c->block);
+  }
   if (c->ndt_block) (void)hipFree(c->ndt_block);
   if (c->vg_block) (void)hipFree(c->vg_block);
   delete c;
@@ -717,6 +735,8 @@ int hgs_destroy(hgs_handle* h) {
                           &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc,
                           &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist};
   for (DeviceBuffer* b : bufs) b->release();
+  for (auto& blk : h->block_pool) (void)hipFree(blk.first);
+  h->block_pool.clear();
   h->h_descs.release();
   h->h_results.release();
   h->h_small.release();
@@ -796,14 +816,14 @@ int hgs_cloud_invalidate(hgs_cloud* c) {
 }
 
 int hgs_set_target_cloud(hgs_handle* h, hgs_cloud* c) {
-  if (!h || !c) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h || !c || c->owner != h) return HGS_ERR_INVALID_ARGUMENT;  // clouds belong to the engine (stream) that created them
   if (h->own_target && h->target != c) cloud_free(h->target);
   h->target = c;
   h->own_target = false;
   return HGS_OK;
 }
 int hgs_set_source_cloud(hgs_handle* h, hgs_cloud* c) {
-  if (!h || !c) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h || !c || c->owner != h) return HGS_ERR_INVALID_ARGUMENT;
   if (h->own_source && h->source != c) cloud_free(h->source);
   h->source = c;
   h->own_source = false;
@@ -888,7 +908,7 @@ int hgs_fitness(hgs_handle* h, const float T[16], double max_range, double* scor
 }
 
 int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, const float relpose[16], double max_range, double* score) {
-  if (!h || !cloud1 || !cloud2 || !relpose || !score) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h || !cloud1 || !cloud2 || cloud1->owner != h || cloud2->owner != h || !relpose || !score) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   hgs_cloud* saved_t = h->target;
   h->target = cloud1;
@@ -948,7 +968,7 @@ int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_c
   HGS_TRY(set_device(h));
   std::vector<hgs_cloud*> src(candidates, candidates + n_candidates);
   for (hgs_cloud* c : src)
-    if (!c) return HGS_ERR_INVALID_ARGUMENT;
+    if (!c || c->owner != h) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(run_batch(h, src, guesses));
   HGS_TRY(run_fitness(h, src, max_range));
   std::vector<DevResult> r;

@@ -98,7 +98,9 @@ int hgs_abi_version(void);
 
 /* ---- clouds resident on the device -------------------------------------------------------------------- */
 /* Upload + pack a host cloud (H2D on the handle's stream).  The cloud caches its search structure and
- * covariances once an engine has computed them, like fast_gicp keeps them per input pointer. */
+ * covariances once an engine has computed them, like fast_gicp keeps them per input pointer.  A cloud belongs to the
+ * handle that created it (its memory is recycled in that handle's stream order): using it with another handle is
+ * rejected with HGS_ERR_INVALID_ARGUMENT. */
 int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, hgs_cloud** out);
 int hgs_cloud_destroy(hgs_cloud* c);
 size_t hgs_cloud_size(const hgs_cloud* c);

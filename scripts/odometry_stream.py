@@ -27,9 +27,10 @@ def main():
     ap.add_argument("--scans", type=int, default=40)
     ap.add_argument("--oracle-scans", type=int, default=6)
     ap.add_argument("--downsample", type=float, default=0.0)
+    ap.add_argument("--speed", type=float, default=8.0, help="vehicle speed [m/s] at 10 Hz sweeps (8 m/s = KITTI-like 0.8 m per sweep)")
     args = ap.parse_args()
     pnh = {"registration_method": args.method, "reg_resolution": 1.0}
-    stream = workloads.make_odometry_stream(args.sensor, 0, args.scans, downsample=args.downsample or None)
+    stream = workloads.make_odometry_stream(args.sensor, 0, args.scans, speed=args.speed, downsample=args.downsample or None)
     # keyframe rule of launch/hdl_graph_slam_kitti.launch:41-43
     kf = dict(keyframe_delta_trans=5.0, keyframe_delta_angle=2.0, keyframe_delta_time=10000.0)
     reg = select_registration_method(pnh, device_id=0)
@@ -43,7 +44,7 @@ def main():
     gt0 = np.linalg.inv(stream.poses[0])
     err = [synth.pose_error(e, gt0 @ p) for e, p in zip(est, stream.poses)]
     lat_ms = np.array(lat[2:]) * 1e3      # skip the keyframe-only first call and the first (warm-up) registration
-    out = {"sensor": args.sensor, "method": args.method, "points_per_scan": int(np.mean([len(c) for c in stream.scans])), "scans": args.scans,
+    out = {"sensor": args.sensor, "method": args.method, "speed_mps": args.speed, "points_per_scan": int(np.mean([len(c) for c in stream.scans])), "scans": args.scans,
            "latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 3), "p90": round(float(np.percentile(lat_ms, 90)), 3),
                           "p99": round(float(np.percentile(lat_ms, 99)), 3), "max": round(float(lat_ms.max()), 3)},
            "registrations_per_sec": round(float(len(lat_ms) / (lat_ms.sum() * 1e-3)), 2), "mean_iterations": float(np.mean(its[1:])),
