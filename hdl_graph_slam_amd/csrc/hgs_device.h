@@ -66,6 +66,15 @@ struct DevResult {
   unsigned pad2;
 };
 
+// Progress of a batch of optimisers: counters in HBM, mirrored into host-mapped pinned memory (see progress_tick).
+struct Progress {
+  int* dev;                   // [0] problems finished, [1] per-problem end-of-round ticks
+  volatile int* host_done;    // 1 once every problem has finished
+  volatile int* host_rounds;  // number of completed rounds
+  int B;
+  int pad;
+};
+
 constexpr int kBlock = 256;
 constexpr int kNW = 1;                    // packets of 64 queries a wave walks in lock-step in the 1-NN kernels (hgs_wave_bvh.h)
 constexpr int kTileNN = kBlock * kNW;     // source points per block of k_gicp_linearize / k_fitness
@@ -79,12 +88,12 @@ void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int
 void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int max_P);
 void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k);
 
-void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, int* done_counter);
+void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog);
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B);
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
                        int tile_points /* kTileNN after k_gicp_linearize, kBlock after k_vgicp_linearize */);
 void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B);
-void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B, int* done_counter);
+void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B, Progress prog);
 void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out, int B);
 
 void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks, int B,
@@ -97,11 +106,11 @@ void launch_ndt_grid_params(hipStream_t s, CloudDesc desc, float inv_leaf);
 void launch_ndt_cell_keys(hipStream_t s, CloudDesc desc, float inv_leaf, unsigned long long* keys, unsigned* vals);
 void launch_ndt_build_cells(hipStream_t s, CloudDesc desc, const unsigned long long* sorted_keys, const unsigned* sorted_vals, int min_points,
                             int* hash_keys, int* hash_vals, int hash_mask, NdtCellRec* cells);
-void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, int* done_counter);
+void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog);
 void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles, NdtConsts c,
                             double* partials, int max_blocks, int B);
 void launch_ndt_solve(hipStream_t s, const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c, const double* partials, int max_blocks,
-                      int B, int* done_counter);
+                      int B, Progress prog);
 void launch_ndt_results(hipStream_t s, const CloudDesc* descs, const NdtState* states, DevResult* out, int B);
 
 void launch_vgicp_grid_params(hipStream_t s, CloudDesc desc, double resolution);

@@ -132,7 +132,7 @@ struct hgs_handle {
 
   DeviceBuffer staging, sort_keys[2], sort_vals[2], sort_tmp, descs, states, angles, partials, partials_err, results, guesses, done, misc;
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
-  PinnedBuffer h_descs, h_results, h_small;
+  PinnedBuffer h_descs, h_results, h_small, h_flags;  // h_flags: host-mapped progress mirror (Progress)
 
   // freed cloud blocks kept for reuse: the odometry path creates and destroys one cloud per sweep, and hipMalloc /
   // hipFree (which synchronises the device) cost more than the upload itself
@@ -507,13 +507,37 @@ NdtConsts ndt_consts(const hgs_params& p) {
   return c;
 }
 
-// Read the device done-counter (tiny pinned D2H + stream sync).
-int read_done(hgs_handle* h, int* out) {
-  HGS_HIP(h, h->h_small.reserve(64));
-  HGS_HIP(h, hipMemcpyAsync(h->h_small.p, h->done.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HGS_HIP(h, hipStreamSynchronize(h->stream));
-  *out = *h->h_small.as<int>();
+// Progress mirror of a batch: device counters + two ints of host-mapped pinned memory the kernels write into.
+int make_progress(hgs_handle* h, int B, Progress* out) {
+  HGS_HIP(h, h->done.reserve(64));
+  HGS_HIP(h, h->h_flags.reserve(64));
+  volatile int* hf = h->h_flags.as<volatile int>();
+  hf[0] = 0, hf[1] = 0;  // everything enqueued earlier on this stream has completed (results were fetched with a sync)
+  out->dev = h->done.as<int>();
+  out->host_done = hf, out->host_rounds = hf + 1;
+  out->B = B, out->pad = 0;
   return HGS_OK;
+}
+
+// Keeps the queue `kRunAhead` rounds ahead of the device without synchronising: returns true when another round should
+// be enqueued, false when every problem has finished.  Falls back to a blocking read if the mirror stops advancing
+// although the stream has drained (a launch failed): the caller then sees the error from hipGetLastError.
+constexpr long kRunAhead = 3;
+bool want_another_round(hgs_handle* h, const Progress& prog, long rounds_enqueued) {
+  long spins = 0;
+  for (;;) {
+    if (*prog.host_done) return false;
+    if (rounds_enqueued - (long)*prog.host_rounds < kRunAhead) return true;
+    if ((++spins & 0x3ff) == 0 && hipStreamQuery(h->stream) == hipSuccess) {
+      // drained: either the mirror has just been updated or something went wrong
+      if (*prog.host_done) return false;
+      if (rounds_enqueued - (long)*prog.host_rounds < kRunAhead) return true;
+      return true;  // do not spin forever; max_rounds bounds the loop
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
 }
 
 // Run all B registrations (sources vs the handle's target) to completion; results land in h->results (device).
@@ -540,20 +564,20 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   HGS_HIP(h, h->results.reserve((size_t)B * sizeof(DevResult)));
   HGS_HIP(h, h->partials.reserve((size_t)B * max_blocks * kAccNdt * sizeof(double)));
   HGS_HIP(h, h->partials_err.reserve((size_t)B * max_blocks * 2 * sizeof(double)));
-  int done = 0;
   if (method == HGS_FAST_GICP || method == HGS_FAST_VGICP) {
     const bool voxel = method == HGS_FAST_VGICP;
     const GicpConsts c = gicp_consts(h->prm);
     const VgicpConsts vc = vgicp_consts(h->prm);
     HGS_HIP(h, h->states.reserve((size_t)B * sizeof(GicpState)));
     GicpState* st = h->states.as<GicpState>();
-    launch_gicp_init(h->stream, st, h->guesses.as<float>(), B, h->done.as<int>());
+    Progress prog;
+    HGS_TRY(make_progress(h, B, &prog));
+    launch_gicp_init(h->stream, st, h->guesses.as<float>(), B, prog);
     const TargetView tv = target_view(tgt);
     const NdtTargetView vtv = voxel ? vgicp_target_view(tgt) : NdtTargetView{};
     const long max_rounds = (long)std::max(1, c.max_iterations) * std::max(1, c.lm_max_iterations) + 2;
     long round = 0;
-    int next_check = 3;
-    while (round < max_rounds) {
+    while (round < max_rounds && want_another_round(h, prog, round)) {
       {
         StageTimer tm(h, HGS_STAGE_LINEARIZE);
         if (voxel) launch_vgicp_linearize(h->stream, d_descs, vtv, st, vc, h->partials.as<double>(), max_blocks, B);
@@ -570,14 +594,9 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       }
       {
         StageTimer tm(h, HGS_STAGE_SOLVE);
-        launch_gicp_decide(h->stream, d_descs, st, c, h->partials_err.as<double>(), max_blocks, B, h->done.as<int>());
+        launch_gicp_decide(h->stream, d_descs, st, c, h->partials_err.as<double>(), max_blocks, B, prog);
       }
       round++;
-      if (round >= next_check) {
-        HGS_TRY(read_done(h, &done));
-        if (done >= B) break;
-        next_check = (int)round + 2;
-      }
     }
     launch_gicp_results(h->stream, st, h->results.as<DevResult>(), B);
   } else {
@@ -586,28 +605,24 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     HGS_HIP(h, h->angles.reserve((size_t)B * sizeof(NdtAngles)));
     NdtState* st = h->states.as<NdtState>();
     NdtAngles* ang = h->angles.as<NdtAngles>();
-    launch_ndt_init(h->stream, st, ang, h->guesses.as<float>(), c, B, h->done.as<int>());
+    Progress prog;
+    HGS_TRY(make_progress(h, B, &prog));
+    launch_ndt_init(h->stream, st, ang, h->guesses.as<float>(), c, B, prog);
     NdtTargetView tv;
     tv.hash_keys = tgt->ndt_hash_keys, tv.hash_vals = tgt->ndt_hash_vals, tv.cells = tgt->ndt_cells, tv.meta = tgt->desc.meta;
     tv.hash_mask = tgt->ndt_hash_cap - 1, tv.inv_leaf = 1.0f / (float)h->prm.resolution;
     const long max_rounds = (long)c.max_iterations + 4;
     long round = 0;
-    int next_check = 4;
-    while (round < max_rounds) {
+    while (round < max_rounds && want_another_round(h, prog, round)) {
       {
         StageTimer tm(h, HGS_STAGE_LINEARIZE);
         launch_ndt_derivatives(h->stream, d_descs, tv, st, ang, c, h->partials.as<double>(), max_blocks, B);
       }
       {
         StageTimer tm(h, HGS_STAGE_SOLVE);
-        launch_ndt_solve(h->stream, d_descs, st, ang, c, h->partials.as<double>(), max_blocks, B, h->done.as<int>());
+        launch_ndt_solve(h->stream, d_descs, st, ang, c, h->partials.as<double>(), max_blocks, B, prog);
       }
       round++;
-      if (round >= next_check) {
-        HGS_TRY(read_done(h, &done));
-        if (done >= B) break;
-        next_check = (int)round + 3;
-      }
     }
     launch_ndt_results(h->stream, d_descs, st, h->results.as<DevResult>(), B);
   }
@@ -740,6 +755,7 @@ int hgs_destroy(hgs_handle* h) {
   h->h_descs.release();
   h->h_results.release();
   h->h_small.release();
+  h->h_flags.release();
   for (auto& ev : h->prof_events) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   if (h->stream) (void)hipStreamDestroy(h->stream);

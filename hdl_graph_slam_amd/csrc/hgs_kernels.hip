@@ -41,6 +41,21 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// End-of-round bookkeeping, called by ONE thread of each of the B per-problem blocks of the last kernel of a round:
+// counts finished problems and completed rounds in HBM and mirrors both into host-mapped pinned memory, so that the
+// host can keep the queue filled and stop enqueueing rounds without ever synchronising the stream.
+__device__ __forceinline__ void progress_tick(Progress p, bool finished_now) {
+  if (finished_now && atomicAdd(&p.dev[0], 1) + 1 == p.B) {
+    *p.host_done = 1;
+    __threadfence_system();
+  }
+  const int t = atomicAdd(&p.dev[1], 1) + 1;
+  if (t % p.B == 0) {
+    *p.host_rounds = t / p.B;
+    __threadfence_system();
+  }
+}
+
 // Sum N per-thread doubles over a 256-thread block in a fixed order; thread k < N stores result k.
 template <int N>
 __device__ __forceinline__ void block_reduce_store(const double* acc, double* out, double* lds /* [4*N] */) {
@@ -58,10 +73,11 @@ __device__ __forceinline__ void block_reduce_store(const double* acc, double* ou
 // ROWS x N threads (ROWS = 256 / N: 9 x 28 for GICP, 5 x 43 for NDT) read ROWS*N consecutive doubles per step (fully
 // coalesced), each thread owns one (row, column) and walks tiles row, row+ROWS, ... ; the rows are then added in a
 // fixed order -> bitwise reproducible.
-constexpr int kSolveBlock = 256;  // 1024 was measured slower: the serial 6x6 solve that follows runs with a quarter of the registers
-template <int N>
-__device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int ntiles, double* out /* LDS [N] */, double* scratch /* LDS [kSolveBlock] */) {
-  constexpr int ROWS = kSolveBlock / N;
+constexpr int kSolveBlock = 256;     // GICP / VGICP solve
+constexpr int kNdtSolveBlock = 512;  // NDT: 43 columns leave only 5 rows at 256 threads (1024 was measured slower)
+template <int N, int THREADS = kSolveBlock>
+__device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int ntiles, double* out /* LDS [N] */, double* scratch /* LDS [THREADS] */) {
+  constexpr int ROWS = THREADS / N;
   const int t = threadIdx.x;
   if (t < ROWS * N) {
     const int col = t % N, row = t / N;
@@ -350,14 +366,14 @@ void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n
 }
 
 // ------------------------------------------------------------------------------------------------ GICP iteration
-__global__ void k_gicp_init(GicpState* states, const float* guesses, int B, int* done_counter) {
+__global__ void k_gicp_init(GicpState* states, const float* guesses, int B, Progress prog) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0) *done_counter = 0;
+  if (b == 0) prog.dev[0] = 0, prog.dev[1] = 0;
   if (b >= B) return;
   gicp_state_init(states[b], guesses + 16 * b);
 }
-void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, int* done_counter) {
-  hipLaunchKernelGGL(k_gicp_init, dim3((B + 63) / 64), dim3(64), 0, s, states, guesses, B, done_counter);
+void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog) {
+  hipLaunchKernelGGL(k_gicp_init, dim3((B + 63) / 64), dim3(64), 0, s, states, guesses, B, prog);
 }
 
 __device__ __forceinline__ Sym3 load_cov(const float4* cov, int i) {
@@ -481,22 +497,25 @@ void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, co
 }
 
 __global__ __launch_bounds__(64) void k_gicp_decide(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials_err,
-                                                   int max_blocks, int* done_counter) {
+                                                   int max_blocks, Progress prog) {
   const int b = blockIdx.x;
   GicpState& st = states[b];
-  if (st.phase != GICP_TRY) return;
-  const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
-  double s = 0;
-  for (int t = threadIdx.x; t < ntiles; t += 64) s += partials_err[(size_t)b * max_blocks + t];
-  s = wave_sum(s);
-  if (threadIdx.x == 0) {
-    gicp_after_error(st, s, c);
-    if (st.phase == GICP_DONE) atomicAdd(done_counter, 1);
+  bool finished_now = false;
+  if (st.phase == GICP_TRY) {
+    const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
+    double s = 0;
+    for (int t = threadIdx.x; t < ntiles; t += 64) s += partials_err[(size_t)b * max_blocks + t];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+      gicp_after_error(st, s, c);
+      finished_now = st.phase == GICP_DONE;
+    }
   }
+  if (threadIdx.x == 0) progress_tick(prog, finished_now);
 }
 void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B,
-                        int* done_counter) {
-  hipLaunchKernelGGL(k_gicp_decide, dim3(B), dim3(64), 0, s, descs, states, c, partials_err, max_blocks, done_counter);
+                        Progress prog) {
+  hipLaunchKernelGGL(k_gicp_decide, dim3(B), dim3(64), 0, s, descs, states, c, partials_err, max_blocks, prog);
 }
 
 __global__ void k_gicp_results(const GicpState* states, DevResult* out, int B) {
@@ -689,15 +708,15 @@ void launch_ndt_build_cells(hipStream_t s, CloudDesc desc, const unsigned long l
 }
 
 // ------------------------------------------------------------------------------------------------ NDT iteration
-__global__ void k_ndt_init(NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, int* done_counter) {
+__global__ void k_ndt_init(NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0) *done_counter = 0;
+  if (b == 0) prog.dev[0] = 0, prog.dev[1] = 0;
   if (b >= B) return;
   ndt_state_init(states[b], guesses + 16 * b);
   ndt_angle_tables(states[b].p, c.upstream_hd1_sign, angles[b]);
 }
-void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, int* done_counter) {
-  hipLaunchKernelGGL(k_ndt_init, dim3((B + 63) / 64), dim3(64), 0, s, states, angles, guesses, c, B, done_counter);
+void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog) {
+  hipLaunchKernelGGL(k_ndt_init, dim3((B + 63) / 64), dim3(64), 0, s, states, angles, guesses, c, B, prog);
 }
 
 // computeDerivatives: per source point, transform, visit the DIRECT1/DIRECT7 cells, accumulate score / gradient /
@@ -747,27 +766,30 @@ void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView
   hipLaunchKernelGGL(k_ndt_derivatives, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, angles, c, partials, max_blocks);
 }
 
-__global__ __launch_bounds__(kSolveBlock) void k_ndt_solve(const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c,
-                                                     const double* __restrict__ partials, int max_blocks, int* done_counter) {
+__global__ __launch_bounds__(kNdtSolveBlock) void k_ndt_solve(const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c,
+                                                     const double* __restrict__ partials, int max_blocks, Progress prog) {
   const int b = blockIdx.x;
   NdtState& st = states[b];
-  if (st.phase != NDT_DERIV) return;
+  if (st.phase != NDT_DERIV) {  // wave-uniform: finished in an earlier round
+    if (threadIdx.x == 0) progress_tick(prog, false);
+    return;
+  }
   __shared__ double acc[kAccNdt];
-  __shared__ double scratch[kSolveBlock];
+  __shared__ double scratch[kNdtSolveBlock];
   const int ntiles = (descs[b].n_input + kBlock - 1) / kBlock;
-  reduce_tiles<kAccNdt>(partials + (size_t)b * max_blocks * kAccNdt, ntiles, acc, scratch);
+  reduce_tiles<kAccNdt, kNdtSolveBlock>(partials + (size_t)b * max_blocks * kAccNdt, ntiles, acc, scratch);
   if (threadIdx.x == 0) {
     ndt_after_derivatives(st, acc, c);
     if (c.pad)  // HGS_TRACE=1: per-iteration trace for parity debugging
       printf("hgs ndt b=%d it=%d passes=%d p=%.9f %.9f %.9f %.9f %.9f %.9f score=%.9f a_t=%.9f phase=%d\n", b, st.iterations, st.passes, st.p[0], st.p[1],
              st.p[2], st.p[3], st.p[4], st.p[5], st.score, st.a_t, st.phase);
-    if (st.phase == NDT_DONE) atomicAdd(done_counter, 1);
-    else ndt_angle_tables(st.p, c.upstream_hd1_sign, angles[b]);
+    if (st.phase != NDT_DONE) ndt_angle_tables(st.p, c.upstream_hd1_sign, angles[b]);
+    progress_tick(prog, st.phase == NDT_DONE);
   }
 }
 void launch_ndt_solve(hipStream_t s, const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c, const double* partials, int max_blocks,
-                      int B, int* done_counter) {
-  hipLaunchKernelGGL(k_ndt_solve, dim3(B), dim3(kSolveBlock), 0, s, descs, states, angles, c, partials, max_blocks, done_counter);
+                      int B, Progress prog) {
+  hipLaunchKernelGGL(k_ndt_solve, dim3(B), dim3(kNdtSolveBlock), 0, s, descs, states, angles, c, partials, max_blocks, prog);
 }
 
 __global__ void k_ndt_results(const CloudDesc* descs, const NdtState* states, DevResult* out, int B) {
@@ -1206,16 +1228,16 @@ void launch_ndt_debug_state(hipStream_t s, NdtState* st, NdtAngles* ang, const d
 }
 
 // out[k] = sum over tiles of partials[t*N + k], in the order k_gicp_solve (N = kAcc) / k_ndt_solve (N = kAccNdt) use
-template <int N>
-__global__ __launch_bounds__(kSolveBlock) void k_reduce_partials(const double* __restrict__ partials, int ntiles, double* out) {
+template <int N, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_reduce_partials(const double* __restrict__ partials, int ntiles, double* out) {
   __shared__ double acc[N];
-  __shared__ double scratch[kSolveBlock];
-  reduce_tiles<N>(partials, ntiles, acc, scratch);
+  __shared__ double scratch[THREADS];
+  reduce_tiles<N, THREADS>(partials, ntiles, acc, scratch);
   if (threadIdx.x < N) out[threadIdx.x] = acc[threadIdx.x];
 }
 void launch_reduce_partials(hipStream_t s, const double* partials, int ntiles, int width, double* out) {
-  if (width == kAccNdt) hipLaunchKernelGGL(k_reduce_partials<kAccNdt>, dim3(1), dim3(kSolveBlock), 0, s, partials, ntiles, out);
-  else hipLaunchKernelGGL(k_reduce_partials<kAcc>, dim3(1), dim3(kSolveBlock), 0, s, partials, ntiles, out);
+  if (width == kAccNdt) hipLaunchKernelGGL((k_reduce_partials<kAccNdt, kNdtSolveBlock>), dim3(1), dim3(kNdtSolveBlock), 0, s, partials, ntiles, out);
+  else hipLaunchKernelGGL((k_reduce_partials<kAcc, kSolveBlock>), dim3(1), dim3(kSolveBlock), 0, s, partials, ntiles, out);
 }
 
 }  // namespace hgs
