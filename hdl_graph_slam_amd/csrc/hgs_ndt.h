@@ -174,20 +174,21 @@ HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx
   if (e > 1.f || e < 0.f || e != e) return;
   e *= d1;
   acc[42] += (double)score_inc;
-  // point gradient (3x6): identity | columns 3..5 from xj
-  float pg[3][6];
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int k = 0; k < 6; k++) pg[r][k] = (r == k) ? 1.f : 0.f;
-  pg[1][3] = pd.xj[0], pg[2][3] = pd.xj[1];
-  pg[0][4] = pd.xj[2], pg[1][4] = pd.xj[3], pg[2][4] = pd.xj[4];
-  pg[0][5] = pd.xj[5], pg[1][5] = pd.xj[6], pg[2][5] = pd.xj[7];
+  // point gradient pg (3x6) = [ I | columns 3..5 from xj ], with pg[0][3] = 0.  Upstream multiplies the full matrices
+  // in float; a product with the identity part contributes exact zeros (x*1 = x, 0*y = 0, z + 0 = z for finite
+  // operands), so the structurally-zero terms are left out here — the remaining operations and their order are
+  // upstream's, the results are bit-identical (up to the sign of an exact zero) and a fifth of the arithmetic is gone.
+  const float pg13 = pd.xj[0], pg23 = pd.xj[1];
+  const float pg04 = pd.xj[2], pg14 = pd.xj[3], pg24 = pd.xj[4];
+  const float pg05 = pd.xj[5], pg15 = pd.xj[6], pg25 = pd.xj[7];
   float Cpg[3][6], qCpg[6];
 #pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int k = 0; k < 6; k++) Cpg[r][k] = C[r][0] * pg[0][k] + C[r][1] * pg[1][k] + C[r][2] * pg[2][k];
+  for (int r = 0; r < 3; r++) {
+    Cpg[r][0] = C[r][0], Cpg[r][1] = C[r][1], Cpg[r][2] = C[r][2];
+    Cpg[r][3] = C[r][1] * pg13 + C[r][2] * pg23;
+    Cpg[r][4] = C[r][0] * pg04 + C[r][1] * pg14 + C[r][2] * pg24;
+    Cpg[r][5] = C[r][0] * pg05 + C[r][1] * pg15 + C[r][2] * pg25;
+  }
 #pragma unroll
   for (int k = 0; k < 6; k++) qCpg[k] = qx * Cpg[0][k] + qy * Cpg[1][k] + qz * Cpg[2][k];
 #pragma unroll
@@ -207,9 +208,13 @@ HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx
       if (i >= 3 && j >= 3) {
         const int lo = i < j ? i : j, hi = i < j ? j : i;
         const int hidx = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
-        qCh = qC[0] * ph[hidx][0] + qC[1] * ph[hidx][1] + qC[2] * ph[hidx][2];
+        // rows a, b, c have a zero first component: qC[0]*0 drops out exactly
+        qCh = hidx < 3 ? qC[1] * ph[hidx][1] + qC[2] * ph[hidx][2] : qC[0] * ph[hidx][0] + qC[1] * ph[hidx][1] + qC[2] * ph[hidx][2];
       }
-      const float pgCpg = pg[0][j] * Cpg[0][i] + pg[1][j] * Cpg[1][i] + pg[2][j] * Cpg[2][i];
+      // pg[.][j]^T Cpg[.][i]
+      const float pgCpg = j < 3 ? Cpg[j][i]
+                                : (j == 3 ? pg13 * Cpg[1][i] + pg23 * Cpg[2][i]
+                                          : (j == 4 ? pg04 * Cpg[0][i] + pg14 * Cpg[1][i] + pg24 * Cpg[2][i] : pg05 * Cpg[0][i] + pg15 * Cpg[1][i] + pg25 * Cpg[2][i]));
       acc[i * 6 + j] += (double)(e * (-d2 * qCpg[i] * qCpg[j] + qCh + pgCpg));
     }
 }

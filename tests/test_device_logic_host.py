@@ -121,9 +121,10 @@ def test_ndt_derivatives(ndt_case):
 
 
 def test_ndt_align_follows_oracle_iteration_by_iteration(ndt_case):
-    """ndt_omp's Newton iteration (step clamped to [eps/2, 0.1], no effective line search) is chaotic for some guesses:
-    rounding-level differences are amplified after ~8 iterations.  Parity is therefore asserted (a) per pass (above),
-    (b) after a fixed, truncated number of iterations, (c) end-to-end from a well-behaved guess."""
+    """ndt_omp's Newton iteration (step clamped to [eps/2, 0.1], no effective line search) is not contractive for every
+    guess on weakly constrained scans: a last-bit difference of a re-associated double sum can be amplified until the
+    trajectories separate after a dozen iterations (see test_hip_parity.test_ndt_align).  Parity is therefore asserted
+    (a) per pass (above), (b) after a fixed, truncated number of iterations, (c) end-to-end from well-behaved guesses."""
     e, o, tgt, src, T, kind = ndt_case
     wild = T @ synth.pose_matrix([0.05, 0.02, 0.0], [0.0, 0.0, 0.004])
     for max_it in (0, 3):

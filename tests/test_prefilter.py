@@ -134,3 +134,16 @@ def test_hip_prefilter_edge_cases():
     out = reg.prefilter(one, p).download()
     assert len(out) == 1 and out["intensity"][0] == 7.0 and out["x"][0] == 5.0
     reg.close()
+
+
+@pytest.mark.gpu
+def test_cloud_download_round_trip():
+    """hgs_cloud_download of an uploaded cloud returns x, y, z and the PointXYZI intensity unchanged, in input order."""
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    cloud = _scan(7)[:2000]
+    reg = RegistrationHIP(L.default_params(L.HGS_FAST_GICP))
+    got = reg.upload(cloud).download()
+    for f in ("x", "y", "z", "intensity"):
+        assert np.array_equal(got[f], cloud[f], equal_nan=True)
+    reg.close()
