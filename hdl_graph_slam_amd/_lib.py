@@ -71,7 +71,7 @@ EXPORTS = [
     "hgs_set_target", "hgs_set_target_cloud", "hgs_set_source", "hgs_set_source_cloud",
     "hgs_align", "hgs_transform_source", "hgs_fitness", "hgs_nn_target",
     "hgs_loop_match_batch", "hgs_select_best", "hgs_calc_fitness_score",
-    "hgs_prefilter_params_default", "hgs_prefilter", "hgs_cloud_download",
+    "hgs_prefilter_params_default", "hgs_prefilter", "hgs_cloud_download", "hgs_map_cloud_generate",
     "hgs_profile_enable", "hgs_profile_read", "hgs_synchronize",
     "hgs_debug_target_covariances", "hgs_debug_gicp_linearize", "hgs_debug_ndt_cells", "hgs_debug_ndt_derivatives",
 ]
@@ -112,6 +112,7 @@ def lib():
     L.hgs_prefilter_params_default.argtypes = [C.POINTER(HgsPrefilterParams)]
     L.hgs_prefilter.argtypes = [vp, vp, sz, sz, C.POINTER(HgsPrefilterParams), C.POINTER(vp)]
     L.hgs_cloud_download.argtypes = [vp, vp, sz]
+    L.hgs_map_cloud_generate.argtypes = [vp, C.POINTER(vp), vp, sz, C.c_double, C.POINTER(vp)]
     L.hgs_profile_enable.argtypes = [vp, C.c_int]
     L.hgs_profile_read.argtypes = [vp, vp, vp, C.c_int]
     L.hgs_synchronize.argtypes = [vp]

@@ -122,6 +122,20 @@ void launch_vgicp_linearize(hipStream_t s, const CloudDesc* descs, NdtTargetView
 void launch_vgicp_error(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const GicpState* states, VgicpConsts c, double* partials_err,
                         int max_blocks, int B);
 
+// map cloud (src/hdl_graph_slam/map_cloud_generator.cpp)
+struct MapSource {
+  const float4* raw;       // keyframe cloud, original order
+  const float* intensity;
+  int n, offset;           // size, position of its first point in the concatenated cloud
+  float T[16];             // keyframe pose, column-major float
+};
+void launch_map_transform(hipStream_t s, const MapSource* srcs, int nsrc, int max_n, float4* out);
+void launch_map_first_finite(hipStream_t s, const float4* pts, int n, int* meta);
+void launch_map_cell_bbox(hipStream_t s, const float4* pts, int n, double res, int* meta);
+void launch_map_keys(hipStream_t s, const float4* pts, int n, double res, int* meta, unsigned long long* keys, unsigned* vals);
+void launch_map_centers(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* head, const unsigned* slot, int n, double res,
+                        const int* meta, float4* out, int* count_out);
+
 // prefilter (apps/prefiltering_nodelet.cpp)
 void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out);
 void launch_pf_distance_flags(hipStream_t s, const float4* pts, int n, int use_filter, double near_thresh, double far_thresh, unsigned* keep);

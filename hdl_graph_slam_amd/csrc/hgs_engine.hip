@@ -1190,6 +1190,90 @@ extern "C" int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_byt
   return HGS_OK;
 }
 
+// ---- map cloud (src/hdl_graph_slam/map_cloud_generator.cpp:13-51) --------------------------------------------
+extern "C" int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes, const float* poses /* 16 * n, column-major */, size_t n_keyframes,
+                                      double resolution, hgs_cloud** out) {
+  if (!h || !out || (n_keyframes > 0 && (!keyframes || !poses))) return HGS_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  size_t total = 0;
+  int max_n = 0;
+  for (size_t k = 0; k < n_keyframes; k++) {
+    if (!keyframes[k] || keyframes[k]->owner != h) return HGS_ERR_INVALID_ARGUMENT;
+    total += keyframes[k]->n_input;
+    max_n = std::max(max_n, (int)keyframes[k]->n_input);
+  }
+  if (total > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
+  HGS_TRY(set_device(h));
+  StageTimer tm(h, HGS_STAGE_PREFILTER);
+  const size_t cap = std::max<size_t>(total, 1);
+  HGS_HIP(h, h->pf_a.reserve(cap * sizeof(float4)));
+  HGS_HIP(h, h->pf_b.reserve(cap * sizeof(float4)));
+  HGS_HIP(h, h->pf_keep.reserve(cap * sizeof(uint32_t)));
+  HGS_HIP(h, h->pf_slot.reserve(cap * sizeof(uint32_t)));
+  HGS_HIP(h, h->pf_small.reserve(256));
+  HGS_HIP(h, h->h_small.reserve(64));
+  float4* all = h->pf_a.as<float4>();
+  if (n_keyframes > 0 && total > 0) {
+    std::vector<MapSource> srcs(n_keyframes);
+    size_t off = 0;
+    for (size_t k = 0; k < n_keyframes; k++) {
+      srcs[k].raw = keyframes[k]->desc.raw, srcs[k].intensity = keyframes[k]->intensity;
+      srcs[k].n = (int)keyframes[k]->n_input, srcs[k].offset = (int)off;
+      std::memcpy(srcs[k].T, poses + 16 * k, sizeof(float) * 16);
+      off += keyframes[k]->n_input;
+    }
+    HGS_HIP(h, h->misc.reserve(n_keyframes * sizeof(MapSource)));
+    HGS_HIP(h, hipMemcpyAsync(h->misc.p, srcs.data(), n_keyframes * sizeof(MapSource), hipMemcpyHostToDevice, h->stream));
+    launch_map_transform(h->stream, h->misc.as<MapSource>(), (int)n_keyframes, max_n, all);
+    HGS_HIP(h, hipStreamSynchronize(h->stream));  // `srcs` is pageable host memory
+  }
+  size_t m = total;
+  float4* result = all;
+  if (resolution > 0.0 && total > 0) {
+    int* d_meta = h->pf_small.as<int>() + 16;
+    int* d_count = h->pf_small.as<int>();
+    const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0};
+    HGS_HIP(h, hipMemcpyAsync(d_meta, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    const int n = (int)total;
+    launch_map_first_finite(h->stream, all, n, d_meta);
+    launch_map_cell_bbox(h->stream, all, n, resolution, d_meta);
+    for (int i = 0; i < 2; i++) {
+      HGS_HIP(h, h->sort_keys[i].reserve(total * sizeof(uint64_t)));
+      HGS_HIP(h, h->sort_vals[i].reserve(total * sizeof(uint32_t)));
+    }
+    launch_map_keys(h->stream, all, n, resolution, d_meta, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
+    size_t tmp_bytes = 0;
+    int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                    h->sort_vals[1].as<uint32_t>(), total, 0, 32, h->stream);
+    if (rc == 0) {
+      HGS_HIP(h, h->sort_tmp.reserve(tmp_bytes));
+      rc = hgs_sort_pairs_u64_u32(h->sort_tmp.p, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                  h->sort_vals[1].as<uint32_t>(), total, 0, 32, h->stream);
+    }
+    if (rc != 0) {
+      h->err = "rocprim radix_sort_pairs failed";
+      return HGS_ERR_HIP;
+    }
+    launch_pf_voxel_heads(h->stream, h->sort_keys[1].as<unsigned long long>(), n, h->pf_keep.as<unsigned>());
+    HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), total));
+    launch_map_centers(h->stream, all, h->sort_keys[1].as<unsigned long long>(), h->pf_keep.as<unsigned>(), h->pf_slot.as<unsigned>(), n, resolution, d_meta,
+                       h->pf_b.as<float4>(), d_count);
+    HGS_HIP(h, hipGetLastError());
+    int* hs = h->h_small.as<int>();
+    HGS_HIP(h, hipMemcpyAsync(hs, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HGS_HIP(h, hipMemcpyAsync(hs + 1, d_meta + 7, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HGS_HIP(h, hipStreamSynchronize(h->stream));
+    if (hs[1]) {
+      h->err = "map cloud: resolution too fine for the extent of the map (cell index overflow)";
+      return HGS_ERR_INVALID_ARGUMENT;
+    }
+    m = (size_t)std::max(0, hs[0]);
+    result = h->pf_b.as<float4>();
+  }
+  HGS_HIP(h, hipGetLastError());
+  return cloud_from_device(h, result, m, out);
+}
+
 int hgs_profile_enable(hgs_handle* h, int enabled) {
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   h->profiling = enabled != 0;

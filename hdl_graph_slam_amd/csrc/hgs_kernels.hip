@@ -1193,6 +1193,104 @@ void launch_pf_statistical(hipStream_t s, const double* dist, int n, double* sta
   hipLaunchKernelGGL(k_pf_statistical_flags, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dist, n, stats, stddev_mul, keep);
 }
 
+// ------------------------------------------------------------------------------------------------ map cloud (next row f3)
+// MapCloudGenerator::generate, src/hdl_graph_slam/map_cloud_generator.cpp:13-51: every keyframe cloud transformed by
+// its (float) pose and concatenated; with a positive resolution, the centres of the occupied voxels of the
+// pcl::octree::OctreePointCloud lattice (anchored on the first finite point) instead of the points themselves.
+__global__ __launch_bounds__(kBlock) void k_map_transform(const MapSource* __restrict__ srcs, float4* __restrict__ out) {
+  HGS_FP_STRICT
+  const MapSource m = srcs[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m.n) return;
+  const float4 p = m.raw[i];
+  float4 o;
+  o.x = ((m.T[0] * p.x + m.T[4] * p.y) + m.T[8] * p.z) + m.T[12];
+  o.y = ((m.T[1] * p.x + m.T[5] * p.y) + m.T[9] * p.z) + m.T[13];
+  o.z = ((m.T[2] * p.x + m.T[6] * p.y) + m.T[10] * p.z) + m.T[14];
+  o.w = m.intensity[i];
+  out[m.offset + i] = o;
+}
+void launch_map_transform(hipStream_t s, const MapSource* srcs, int nsrc, int max_n, float4* out) {
+  if (nsrc > 0 && max_n > 0) hipLaunchKernelGGL(k_map_transform, dim3((max_n + kBlock - 1) / kBlock, nsrc), dim3(kBlock), 0, s, srcs, out);
+}
+
+// meta (ints): [0] index of the first finite point, [1..3] min cell, [4..6] max cell, [7] overflow flag
+__global__ __launch_bounds__(kBlock) void k_map_first_finite(const float4* __restrict__ pts, int n, int* __restrict__ meta) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool ok = i < n && finite3(pts[i]);
+  const unsigned long long m = __ballot(ok);
+  if (m != 0ull && (threadIdx.x & 63) == 0) atomicMin(&meta[0], (int)(blockIdx.x * kBlock + (threadIdx.x & ~63u)) + (__ffsll((long long)m) - 1));
+}
+__device__ __forceinline__ bool map_cell_of(const float4& p, const float4& p0, double res, long long* c) {
+  HGS_FP_STRICT
+  const double h = res / 2;
+  const double mn[3] = {(double)p0.x - h, (double)p0.y - h, (double)p0.z - h};
+  c[0] = (long long)floor(((double)p.x - mn[0]) / res);
+  c[1] = (long long)floor(((double)p.y - mn[1]) / res);
+  c[2] = (long long)floor(((double)p.z - mn[2]) / res);
+  return c[0] > -(1ll << 30) && c[0] < (1ll << 30) && c[1] > -(1ll << 30) && c[1] < (1ll << 30) && c[2] > -(1ll << 30) && c[2] < (1ll << 30);
+}
+__global__ __launch_bounds__(kBlock) void k_map_cell_bbox(const float4* __restrict__ pts, int n, double res, int* __restrict__ meta) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n || meta[0] >= n) return;
+  const float4 p = pts[i];
+  if (!finite3(p)) return;
+  long long c[3];
+  if (!map_cell_of(p, pts[meta[0]], res, c)) {
+    meta[7] = 1;
+    return;
+  }
+  for (int a = 0; a < 3; a++) atomicMin(&meta[1 + a], (int)c[a]), atomicMax(&meta[4 + a], (int)c[a]);
+}
+__global__ __launch_bounds__(kBlock) void k_map_keys(const float4* __restrict__ pts, int n, double res, int* __restrict__ meta, unsigned long long* __restrict__ keys,
+                                                     unsigned* __restrict__ vals) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long key = 0xffffffffull;
+  if (meta[0] < n && !meta[7]) {
+    const long long dx = (long long)meta[4] - meta[1] + 1, dy = (long long)meta[5] - meta[2] + 1, dz = (long long)meta[6] - meta[3] + 1;
+    if (dx * dy * dz > 2147483647LL) {
+      if (i == 0) meta[7] = 1;
+    } else {
+      const float4 p = pts[i];
+      long long c[3];
+      if (finite3(p) && map_cell_of(p, pts[meta[0]], res, c)) key = (unsigned long long)((c[0] - meta[1]) + (c[1] - meta[2]) * dx + (c[2] - meta[3]) * dx * dy);
+    }
+  }
+  keys[i] = key;
+  vals[i] = (unsigned)i;
+}
+// one thread per occupied voxel (head of a sorted key run): its centre
+__global__ __launch_bounds__(kBlock) void k_map_centers(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys, const unsigned* __restrict__ head,
+                                                        const unsigned* __restrict__ slot, int n, double res, const int* __restrict__ meta, float4* __restrict__ out,
+                                                        int* __restrict__ count_out) {
+  HGS_FP_STRICT
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) *count_out = (int)(slot[i] + head[i]);
+  if (!head[i]) return;
+  const long long dx = (long long)meta[4] - meta[1] + 1, dy = (long long)meta[5] - meta[2] + 1;
+  const long long k = (long long)keys[i];
+  const long long cx = k % dx + meta[1], cy = (k / dx) % dy + meta[2], cz = k / (dx * dy) + meta[3];
+  const float4 p0 = pts[meta[0]];
+  const double h = res / 2;
+  out[slot[i]] = make_float4((float)(((double)cx + 0.5) * res + ((double)p0.x - h)), (float)(((double)cy + 0.5) * res + ((double)p0.y - h)),
+                             (float)(((double)cz + 0.5) * res + ((double)p0.z - h)), 0.f);
+}
+void launch_map_first_finite(hipStream_t s, const float4* pts, int n, int* meta) {
+  if (n > 0) hipLaunchKernelGGL(k_map_first_finite, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, meta);
+}
+void launch_map_cell_bbox(hipStream_t s, const float4* pts, int n, double res, int* meta) {
+  if (n > 0) hipLaunchKernelGGL(k_map_cell_bbox, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, res, meta);
+}
+void launch_map_keys(hipStream_t s, const float4* pts, int n, double res, int* meta, unsigned long long* keys, unsigned* vals) {
+  if (n > 0) hipLaunchKernelGGL(k_map_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, res, meta, keys, vals);
+}
+void launch_map_centers(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* head, const unsigned* slot, int n, double res,
+                        const int* meta, float4* out, int* count_out) {
+  if (n > 0) hipLaunchKernelGGL(k_map_centers, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, keys, head, slot, n, res, meta, out, count_out);
+}
+
 // pack a resident float4 {x,y,z,intensity} array into a cloud: raw = {x,y,z,index}, intensity kept beside it
 __global__ __launch_bounds__(kBlock) void k_pf_to_cloud(const float4* __restrict__ in, int n, float4* __restrict__ raw, float* __restrict__ intensity) {
   const int i = blockIdx.x * kBlock + threadIdx.x;

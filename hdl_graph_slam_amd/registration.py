@@ -171,6 +171,15 @@ class RegistrationHIP:
         self._check(L.lib().hgs_prefilter(self._h, arr.ctypes.data_as(C.c_void_p), n, stride, C.byref(params), C.byref(h)))
         return DeviceCloud._adopt(self, h)
 
+    def map_cloud(self, keyframes, poses, resolution: float) -> DeviceCloud:
+        """MapCloudGenerator::generate (src/hdl_graph_slam/map_cloud_generator.cpp:13-51) over resident keyframe clouds."""
+        n = len(keyframes)
+        arr = (C.c_void_p * max(n, 1))(*[k._h for k in keyframes])
+        P = np.ascontiguousarray(np.stack([L.colmajor16(p) for p in poses]) if n else np.zeros((0, 16), np.float32))
+        h = C.c_void_p()
+        self._check(L.lib().hgs_map_cloud_generate(self._h, arr, P.ctypes.data_as(C.c_void_p), n, float(resolution), C.byref(h)))
+        return DeviceCloud._adopt(self, h)
+
     def loop_match_batch(self, candidates, guesses, max_range: float = L.DBL_MAX):
         """Register every candidate DeviceCloud against the current target; returns (records ndarray, best index)."""
         n = len(candidates)

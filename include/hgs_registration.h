@@ -164,6 +164,13 @@ int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes,
  * packed xyz(+w) otherwise.  Needs room for hgs_cloud_size(c) records. */
 int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_bytes);
 
+/* ---- "next" row f3: MapCloudGenerator::generate (src/hdl_graph_slam/map_cloud_generator.cpp:13-51) ------------------ */
+/* Every resident keyframe cloud transformed by its pose (float 4x4, column-major, 16 floats each) and concatenated; with
+ * resolution > 0 the centres of the occupied voxels of pcl::octree::OctreePointCloud(resolution) (lattice anchored on the
+ * first finite point, intensity 0) in ascending (z, y, x) cell order, else the transformed points with their intensity.
+ * The map stays resident (*out); fetch it with hgs_cloud_download. */
+int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes, const float* poses, size_t n_keyframes, double resolution, hgs_cloud** out);
+
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 enum hgs_stage {
   HGS_STAGE_UPLOAD = 0,     /* H2D + pack                                            */

@@ -10,6 +10,7 @@
 #include "ndt.hpp"
 #include "vgicp.hpp"
 #include "prefilter.hpp"
+#include "mapcloud.hpp"
 
 using namespace hgso;
 
@@ -234,6 +235,27 @@ long hgso_prefilter(const void* pts, size_t n, size_t stride, const PrefilterPar
     in[i] = {f[0], f[1], f[2], stride >= 20 ? f[4] : 0.f};
   }
   if (!prefilter(in, *prm, out)) return -1;
+  for (size_t i = 0; i < out.size() && i < cap; i++) out4[4 * i] = out[i].x, out4[4 * i + 1] = out[i].y, out4[4 * i + 2] = out[i].z, out4[4 * i + 3] = out[i].intensity;
+  return (long)out.size();
+}
+
+// MapCloudGenerator::generate: n_kf clouds given as one concatenated record array + per-keyframe sizes; poses: 16
+// column-major floats each.  Returns the number of output points ({x,y,z,intensity} float4 records) or -1.
+long hgso_map_cloud(const void* pts, const size_t* sizes, size_t n_kf, size_t stride, const float* poses16, double resolution, float* out4, size_t cap) {
+  std::vector<std::vector<PfPoint>> kfs(n_kf);
+  std::vector<std::array<float, 16>> poses(n_kf);
+  const char* base = (const char*)pts;
+  size_t off = 0;
+  for (size_t k = 0; k < n_kf; k++) {
+    for (size_t i = 0; i < sizes[k]; i++) {
+      const float* f = (const float*)(base + (off + i) * stride);
+      kfs[k].push_back({f[0], f[1], f[2], stride >= 20 ? f[4] : 0.f});
+    }
+    off += sizes[k];
+    for (int j = 0; j < 16; j++) poses[k][j] = poses16[16 * k + j];
+  }
+  std::vector<PfPoint> out;
+  if (!map_cloud_generate(kfs, poses, resolution, out)) return -1;
   for (size_t i = 0; i < out.size() && i < cap; i++) out4[4 * i] = out[i].x, out4[4 * i + 1] = out[i].y, out4[4 * i + 2] = out[i].z, out4[4 * i + 3] = out[i].intensity;
   return (long)out.size();
 }

@@ -100,6 +100,8 @@ def lib():
         L.hgso_gicp_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_prefilter.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.hgso_prefilter.restype = C.c_long
+        L.hgso_map_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]
+        L.hgso_map_cloud.restype = C.c_long
         L.hgso_ndt_cells.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
@@ -270,6 +272,30 @@ def prefilter(cloud: np.ndarray, params) -> np.ndarray:
     if m < 0:
         raise ValueError("voxel grid index overflow")
     return out[:m].copy()
+
+
+def map_cloud(clouds, poses, resolution: float) -> np.ndarray:
+    """MapCloudGenerator::generate (map_cloud_generator.cpp:13-51): clouds = list of PointXYZI record arrays, poses = list of
+    4x4; returns [m, 4] float32 {x, y, z, intensity}."""
+    allpts = np.ascontiguousarray(np.concatenate(clouds)) if len(clouds) else np.zeros(0, clouds_dtype())
+    arr, n, stride = _cloud_args(allpts) if n_total(clouds) else (np.zeros(1, np.float32), 0, 32)
+    sizes = np.array([len(c) for c in clouds], np.uint64)
+    P = np.ascontiguousarray(np.stack([np.asarray(p, np.float32).reshape(4, 4).T.reshape(16) for p in poses]) if len(poses) else np.zeros((0, 16), np.float32))
+    cap = max(n, 1)
+    out = np.zeros((cap, 4), np.float32)
+    m = lib().hgso_map_cloud(_ptr(arr), _ptr(sizes), len(clouds), stride, _ptr(P), float(resolution), _ptr(out), cap)
+    if m < 0:
+        raise ValueError("map cloud: cell index overflow")
+    return out[:m].copy()
+
+
+def n_total(clouds) -> int:
+    return int(sum(len(c) for c in clouds))
+
+
+def clouds_dtype():
+    from hdl_graph_slam_amd import synth
+    return synth.POINT_XYZI_DTYPE
 
 
 def se3_exp(d6) -> np.ndarray:
