@@ -86,19 +86,20 @@ void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals);
 void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int max_slots, const unsigned* sorted_vals);
 void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int max_P);
-void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k);
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw);
 
 void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog);
-void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B);
+void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B,
+                           int qpw /* queries per wave: 64, or 16 for launches too small to fill the chip */);
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
-                       int tile_points /* kTileNN after k_gicp_linearize, kBlock after k_vgicp_linearize */);
+                       int tile_points /* points per block of the linearize kernel that filled `partials` */);
 void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B);
 void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B, Progress prog);
 void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out, int B);
 
 void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks, int B,
-                    int use_seed);
-void launch_fitness_final(hipStream_t s, const CloudDesc* descs, const double* partials, int max_blocks, DevResult* out, int B);
+                    int use_seed, int qpw);
+void launch_fitness_final(hipStream_t s, const CloudDesc* descs, const double* partials, int max_blocks, DevResult* out, int B, int tile_pts);
 void launch_nn_query(hipStream_t s, TargetView tgt, const float4* q, int nq, int* idx, float* d2);
 void launch_transform(hipStream_t s, const float4* raw, int n, const float* T16_colmajor_dev, float4* out);
 

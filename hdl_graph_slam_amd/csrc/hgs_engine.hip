@@ -281,6 +281,12 @@ int upload_descs(hgs_handle* h, const std::vector<hgs_cloud*>& clouds, bool with
   return HGS_OK;
 }
 
+// Queries per wave of the kNN covariance kernel.  A launch with few queries cannot fill 1024 SIMDs with 64-query packets
+// (one 120 k-point cloud is 1.8 waves per SIMD) and is bound by the dependent-load chain of a single walk; 32-query
+// packets walk fewer nodes and put more waves in flight (0.91 -> 0.66 ms for one 120 k-point cloud).  Large batches keep
+// 64 (least total work); the 1-NN kernels always do (no measurable gain from shorter packets there).
+int queries_per_wave(size_t total_queries, int small) { return total_queries >= (size_t)600000 ? 64 : small; }
+
 // Build the search index (Hilbert sort + implicit tree) of every cloud in the list that lacks one — one
 // batched kernel sequence and ONE radix sort for the whole list.
 int ensure_index(hgs_handle* h, const std::vector<hgs_cloud*>& all) {
@@ -344,7 +350,9 @@ int ensure_cov(hgs_handle* h, const std::vector<hgs_cloud*>& all, int k) {
   HGS_TRY(upload_descs(h, todo, false, &d_descs, nullptr));
   int max_n = 0;
   for (hgs_cloud* c : todo) max_n = std::max(max_n, (int)c->n_input);
-  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k);
+  size_t total_q = 0;
+  for (hgs_cloud* c : todo) total_q += c->n_input;
+  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, queries_per_wave(total_q, 32));  // >= k points in the pre-fill window
   HGS_HIP(h, hipGetLastError());
   HGS_HIP(h, hipStreamSynchronize(h->stream));
   for (hgs_cloud* c : todo) c->has_cov = true, c->cov_k = k;
@@ -555,7 +563,12 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   }
   int max_n = 0;
   for (hgs_cloud* c : sources) max_n = std::max(max_n, (int)c->n_input);
-  const int max_blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
+  size_t total_q = 0;
+  for (hgs_cloud* c : sources) total_q += c->n_input;
+  (void)total_q;
+  const int qpw = 64;  // measured: 16- or 32-query packets do not shorten a single registration's linearize (97 -> 90 us) and cost the batch
+  const int nn_tile = (kBlock / 64) * qpw;                       // points per block of k_gicp_linearize
+  const int max_blocks = std::max(1, (max_n + nn_tile - 1) / nn_tile);  // >= the tile count of every kernel of the loop
   const CloudDesc* d_descs = nullptr;
   HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
   HGS_HIP(h, h->guesses.reserve((size_t)B * 16 * sizeof(float)));
@@ -581,11 +594,11 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       {
         StageTimer tm(h, HGS_STAGE_LINEARIZE);
         if (voxel) launch_vgicp_linearize(h->stream, d_descs, vtv, st, vc, h->partials.as<double>(), max_blocks, B);
-        else launch_gicp_linearize(h->stream, d_descs, tv, st, c, h->partials.as<double>(), max_blocks, B);
+        else launch_gicp_linearize(h->stream, d_descs, tv, st, c, h->partials.as<double>(), max_blocks, B, qpw);
       }
       {
         StageTimer tm(h, HGS_STAGE_SOLVE);
-        launch_gicp_solve(h->stream, d_descs, st, c, h->partials.as<double>(), max_blocks, B, voxel ? kBlock : kTileNN);
+        launch_gicp_solve(h->stream, d_descs, st, c, h->partials.as<double>(), max_blocks, B, voxel ? kBlock : nn_tile);
       }
       {
         StageTimer tm(h, HGS_STAGE_ERROR);
@@ -638,14 +651,16 @@ int run_fitness(hgs_handle* h, const std::vector<hgs_cloud*>& sources, double ma
   HGS_TRY(ensure_index(h, all));
   int max_n = 0;
   for (hgs_cloud* c : sources) max_n = std::max(max_n, (int)c->n_input);
-  const int max_blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
+  const int qpw = 64;
+  const int nn_tile = (kBlock / 64) * qpw;
+  const int max_blocks = std::max(1, (max_n + nn_tile - 1) / nn_tile);
   const CloudDesc* d_descs = nullptr;
   HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
   HGS_HIP(h, h->partials_err.reserve((size_t)B * max_blocks * 2 * sizeof(double)));
   StageTimer tm(h, HGS_STAGE_FITNESS);
   launch_fitness(h->stream, d_descs, target_view(h->target), h->results.as<DevResult>(), max_range, h->partials_err.as<double>(), max_blocks, B,
-                 h->prm.method == HGS_FAST_GICP ? 1 : 0);
-  launch_fitness_final(h->stream, d_descs, h->partials_err.as<double>(), max_blocks, h->results.as<DevResult>(), B);
+                 h->prm.method == HGS_FAST_GICP ? 1 : 0, qpw);
+  launch_fitness_final(h->stream, d_descs, h->partials_err.as<double>(), max_blocks, h->results.as<DevResult>(), B, nn_tile);
   HGS_HIP(h, hipGetLastError());
   return HGS_OK;
 }
@@ -1356,7 +1371,7 @@ int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, d
   HGS_HIP(h, hipMemcpyAsync(h->misc.p, T12, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   launch_gicp_debug_state(h->stream, h->states.as<GicpState>(), h->misc.as<double>());
   if (voxel) launch_vgicp_linearize(h->stream, d_descs, vgicp_target_view(t), h->states.as<GicpState>(), vgicp_consts(h->prm), h->partials.as<double>(), max_blocks, 1);
-  else launch_gicp_linearize(h->stream, d_descs, target_view(t), h->states.as<GicpState>(), gicp_consts(h->prm), h->partials.as<double>(), max_blocks, 1);
+  else launch_gicp_linearize(h->stream, d_descs, target_view(t), h->states.as<GicpState>(), gicp_consts(h->prm), h->partials.as<double>(), max_blocks, 1, 64);
   double* d_out = h->misc.as<double>() + 16;
   launch_reduce_partials(h->stream, h->partials.as<double>(), max_blocks, kAcc, d_out);
   double acc[kAcc];

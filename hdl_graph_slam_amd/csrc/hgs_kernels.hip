@@ -291,16 +291,21 @@ void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 //      slot and insertion; keeping the positions sorted alongside costs 4x as many instructions and this kernel is
 //      VALU bound, see profiles/),
 //   2. a second walk bounded by r2 that sums (p - q) and (p - q)(p - q)^T over exactly the k nearest points (those
-//      closer than r2 plus as many at exactly r2 as the list held) — the covariance needs the set, not its order.
+//      closer than r2 plus, of those at exactly r2, as many as the list held, lowest original index first like a
+//      kd-tree k-NN orders equal distances) — the covariance needs the set, not its order.
 // Algorithmic bytes per point: 16 (query) + k*16 (neighbours) + 24 (cov).
+// qpw = queries per wave (64, or fewer — a multiple of 8 — when the whole launch is too small to fill the chip: shorter
+// packets walk fewer nodes, so the dependent-load chain that bounds a small launch gets shorter; lanes >= qpw idle).
 template <int KMAX>
-__global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int k) {
+__global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int k, int qpw) {
   const CloudDesc d = descs[blockIdx.y];
   const int n = d.meta->nvalid;
-  const int ntiles = (n + kBlock - 1) / kBlock;
+  const int tile_pts = (kBlock / 64) * qpw;
+  const int ntiles = (n + tile_pts - 1) / tile_pts;
   if ((int)blockIdx.x >= ntiles) return;
-  const int i = xcd_tile(blockIdx.x, ntiles) * kBlock + threadIdx.x;
-  const bool active = i < n;
+  const int lane = (int)(threadIdx.x & 63);
+  const int i = xcd_tile(blockIdx.x, ntiles) * tile_pts + (int)(threadIdx.x >> 6) * qpw + lane;
+  const bool active = lane < qpw && i < n;
   BvhView tv;
   tv.nodes = d.nodes, tv.pts = d.pts, tv.lpts = d.lpts, tv.P = d.P, tv.n = n;
   const int height = 31 - __clz(tv.P);
@@ -318,17 +323,18 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
     // The wave's own 64 points (8 whole leaves of the Hilbert order) are every lane's first candidates: all-pairs
     // through v_readlane, no memory traffic — the walk then starts with every list full and a bound within ~1.2x of
     // the final radius instead of +inf, which is what keeps it from wandering (3x fewer insertions and leaves).
-    const int i0 = i - (int)(threadIdx.x & 63);
-    const int own = min(64, n - i0);
+    const int i0 = i - lane;
+    const int own = min(qpw, n - i0);
     for (int jj = 0; jj < own; jj++) {
       const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), jj)), py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), jj)),
                   pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), jj));
       const float dd = dist2f(q, px, py, pz);
       if (dd < L.worst()) L.insert(dd);
     }
-    if (n > 64) {  // otherwise the own window was the whole cloud
+    if (n > qpw) {  // otherwise the own window was the whole cloud
       w[0].start(tv, q, height);
-      w[0].skip_lo = (unsigned)(tv.P + (i0 >> 3)), w[0].skip_n = 8u;
+      w[0].order_lane = qpw >> 1;
+      w[0].skip_lo = (unsigned)(tv.P + (i0 >> 3)), w[0].skip_n = (unsigned)(qpw >> 3);
       wave_walk_multi<KnnRadiusLane<KMAX>, 1>(tv, w, slot);
     }
     r2 = w[0].lane.worst();
@@ -337,32 +343,45 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
     for (int j = 0; j < KMAX; j++) n_lt += (w[0].lane.d[j] >= 0.f && w[0].lane.d[j] < r2) ? 1 : 0;
     ties = live - n_lt;
   }
-  PacketWalk<KnnGatherLane> g[1];
-  {
-    KnnGatherLane& L = g[0].lane;
-    L.r2 = active ? r2 : -1.f, L.ties_left = ties, L.found = 0;
-    L.s1[0] = L.s1[1] = L.s1[2] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; j++) L.s2[j] = 0.0;
-    L.qx0 = q.x, L.qy0 = q.y, L.qz0 = q.z;
+  // pass 2 (TIES = 1 unless some lane of this wave needs several points at exactly its k-th distance)
+  double s1[3];
+  Sym3 s2;
+  int found;
+  if (__ballot(active && ties > 1) == 0ull) {
+    PacketWalk<KnnGatherLane<1>> g[1];
+    g[0].lane.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
     g[0].start(tv, q, height);
+    g[0].order_lane = qpw >> 1;
+    wave_walk_multi<KnnGatherLane<1>, 1>(tv, g, slot);
+    g[0].lane.finish(d.pts);
+    const KnnGatherLane<1>& L = g[0].lane;
+    s1[0] = L.s1[0], s1[1] = L.s1[1], s1[2] = L.s1[2], found = L.found;
+    s2 = Sym3{L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
+  } else {
+    PacketWalk<KnnGatherLane<4>> g[1];
+    g[0].lane.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
+    g[0].start(tv, q, height);
+    g[0].order_lane = qpw >> 1;
+    wave_walk_multi<KnnGatherLane<4>, 1>(tv, g, slot);
+    g[0].lane.finish(d.pts);
+    const KnnGatherLane<4>& L = g[0].lane;
+    s1[0] = L.s1[0], s1[1] = L.s1[1], s1[2] = L.s1[2], found = L.found;
+    s2 = Sym3{L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
   }
-  wave_walk_multi<KnnGatherLane, 1>(tv, g, slot);
   if (!active) return;
-  const KnnGatherLane& L = g[0].lane;
-  const Sym3 s2 = {L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
-  const Sym3 c = gicp_regularized_cov(L.s1, s2, L.found, k);
+  const Sym3 c = gicp_regularized_cov(s1, s2, found, k);
   d.cov[2 * i] = make_float4((float)c.xx, (float)c.xy, (float)c.xz, (float)c.yy);
   d.cov[2 * i + 1] = make_float4((float)c.yz, (float)c.zz, 0.f, 0.f);
 }
-void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k) {
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw) {
   if (max_n <= 0) return;
-  const dim3 grid((max_n + kBlock - 1) / kBlock, ncloud), block(kBlock);
-  if (k <= 8) hipLaunchKernelGGL(k_knn_cov<8>, grid, block, 0, s, descs, k);
-  else if (k <= 16) hipLaunchKernelGGL(k_knn_cov<16>, grid, block, 0, s, descs, k);
-  else if (k <= 20) hipLaunchKernelGGL(k_knn_cov<20>, grid, block, 0, s, descs, k);
-  else if (k <= 32) hipLaunchKernelGGL(k_knn_cov<32>, grid, block, 0, s, descs, k);
-  else hipLaunchKernelGGL(k_knn_cov<64>, grid, block, 0, s, descs, k < 64 ? k : 64);
+  const int tile_pts = (kBlock / 64) * qpw;
+  const dim3 grid((max_n + tile_pts - 1) / tile_pts, ncloud), block(kBlock);
+  if (k <= 8) hipLaunchKernelGGL(k_knn_cov<8>, grid, block, 0, s, descs, k, qpw);
+  else if (k <= 16) hipLaunchKernelGGL(k_knn_cov<16>, grid, block, 0, s, descs, k, qpw);
+  else if (k <= 20) hipLaunchKernelGGL(k_knn_cov<20>, grid, block, 0, s, descs, k, qpw);
+  else if (k <= 32) hipLaunchKernelGGL(k_knn_cov<32>, grid, block, 0, s, descs, k, qpw);
+  else hipLaunchKernelGGL(k_knn_cov<64>, grid, block, 0, s, descs, k < 64 ? k : 64, qpw);
 }
 
 // ------------------------------------------------------------------------------------------------ GICP iteration
@@ -397,12 +416,13 @@ __device__ __forceinline__ Sym3 load_cov_stream(const float4* cov, int i) {
 // 6x6 normal-equation terms; wave shuffle + LDS reduction to one 28-double partial per block.
 // Algorithmic bytes per source point: 16 (a_i) + 24 (C_A) + 4 (corr) + 16 (b_j) + 24 (C_B) = 84.
 __global__ __launch_bounds__(kBlock) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
-                                                           double* __restrict__ partials, int max_blocks) {
+                                                           double* __restrict__ partials, int max_blocks, int qpw) {
   const int b = blockIdx.y;
   if (states[b].phase != GICP_LINEARIZE) return;
   const CloudDesc d = descs[b];
   const int n = d.meta->nvalid;
-  const int ntiles = (n + kTileNN - 1) / kTileNN;
+  const int tile_pts = (kBlock / 64) * qpw * kNW;
+  const int ntiles = (n + tile_pts - 1) / tile_pts;
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = xcd_tile(blockIdx.x, ntiles);
   __shared__ double lds[4 * kAcc];
@@ -421,14 +441,14 @@ __global__ __launch_bounds__(kBlock) void k_gicp_linearize(const CloudDesc* desc
   float d2[kNW];
 #pragma unroll
   for (int w = 0; w < kNW; w++) {
-    idx[w] = tile * kTileNN + (int)(threadIdx.x >> 6) * (64 * kNW) + w * 64 + (int)(threadIdx.x & 63);
-    active[w] = idx[w] < n;
+    idx[w] = tile * tile_pts + (int)(threadIdx.x >> 6) * (qpw * kNW) + w * qpw + (int)(threadIdx.x & 63);
+    active[w] = (int)(threadIdx.x & 63) < qpw && idx[w] < n;
     a[w] = active[w] ? load_stream(d.pts + idx[w]) : make_float4(0.f, 0.f, 0.f, 0.f);
     q[w] = transform_point_f(Tf, a[w].x, a[w].y, a[w].z);
     // seed: the correspondence of the previous linearisation (or of an earlier align; -1 / stale values are harmless)
     seed[w] = active[w] ? __builtin_nontemporal_load(d.corr + idx[w]) : -1;
   }
-  wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, c.search_bound2, seed, d2, j, orig);
+  wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, c.search_bound2, seed, d2, j, orig, qpw);
   const double R[9] = {T.m[0], T.m[1], T.m[2], T.m[4], T.m[5], T.m[6], T.m[8], T.m[9], T.m[10]};
 #pragma unroll
   for (int w = 0; w < kNW; w++) {
@@ -446,8 +466,8 @@ __global__ __launch_bounds__(kBlock) void k_gicp_linearize(const CloudDesc* desc
   block_reduce_store<kAcc>(acc, partials + ((size_t)b * max_blocks + tile) * kAcc, lds);
 }
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
-                           int max_blocks, int B) {
-  hipLaunchKernelGGL(k_gicp_linearize, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks);
+                           int max_blocks, int B, int qpw) {
+  hipLaunchKernelGGL(k_gicp_linearize, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw);
 }
 
 __global__ __launch_bounds__(kSolveBlock) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
@@ -537,11 +557,12 @@ void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out,
 // getFitnessScore: per source point exact (unbounded) 1-NN in the target; sum d2 over d2 <= max_range.
 // Algorithmic bytes per source point: 16 + 16 = 32.
 __global__ __launch_bounds__(kBlock) void k_fitness(const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range,
-                                                    double* __restrict__ partials, int max_blocks, int use_seed) {
+                                                    double* __restrict__ partials, int max_blocks, int use_seed, int qpw) {
   const int b = blockIdx.y;
   const CloudDesc d = descs[b];
   const int n = d.meta->nvalid;
-  const int ntiles = (n + kTileNN - 1) / kTileNN;
+  const int tile_pts = (kBlock / 64) * qpw * kNW;
+  const int ntiles = (n + tile_pts - 1) / tile_pts;
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = xcd_tile(blockIdx.x, ntiles);
   __shared__ double lds[4 * 2];
@@ -559,26 +580,26 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const CloudDesc* descs, Targ
   float d2[kNW];
 #pragma unroll
   for (int w = 0; w < kNW; w++) {
-    idx[w] = tile * kTileNN + (int)(threadIdx.x >> 6) * (64 * kNW) + w * 64 + (int)(threadIdx.x & 63);
-    active[w] = idx[w] < n;
+    idx[w] = tile * tile_pts + (int)(threadIdx.x >> 6) * (qpw * kNW) + w * qpw + (int)(threadIdx.x & 63);
+    active[w] = (int)(threadIdx.x & 63) < qpw && idx[w] < n;
     const float4 a = active[w] ? load_stream(d.pts + idx[w]) : make_float4(0.f, 0.f, 0.f, 0.f);
     q[w] = transform_point_f(Tf, a.x, a.y, a.z);
     // use_seed: corr[] holds this cloud's last GICP correspondences against this target — a tight starting bound
     seed[w] = (active[w] && use_seed) ? __builtin_nontemporal_load(d.corr + idx[w]) : -1;
   }
-  wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, FLT_MAX, seed, d2, j, orig);
+  wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, FLT_MAX, seed, d2, j, orig, qpw);
 #pragma unroll
   for (int w = 0; w < kNW; w++)
     if (active[w] && j[w] >= 0 && (double)d2[w] <= max_range) acc[0] += (double)d2[w], acc[1] += 1.0;
   block_reduce_store<2>(acc, partials + ((size_t)b * max_blocks + tile) * 2, lds);
 }
 void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks,
-                    int B, int use_seed) {
-  hipLaunchKernelGGL(k_fitness, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, poses, max_range, partials, max_blocks, use_seed);
+                    int B, int use_seed, int qpw) {
+  hipLaunchKernelGGL(k_fitness, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, poses, max_range, partials, max_blocks, use_seed, qpw);
 }
-__global__ __launch_bounds__(64) void k_fitness_final(const CloudDesc* descs, const double* __restrict__ partials, int max_blocks, DevResult* out) {
+__global__ __launch_bounds__(64) void k_fitness_final(const CloudDesc* descs, const double* __restrict__ partials, int max_blocks, DevResult* out, int tile_pts) {
   const int b = blockIdx.x;
-  const int ntiles = (descs[b].meta->nvalid + kTileNN - 1) / kTileNN;  // tiles of k_fitness
+  const int ntiles = (descs[b].meta->nvalid + tile_pts - 1) / tile_pts;  // tiles of k_fitness
   double s = 0, c = 0;
   for (int t = threadIdx.x; t < ntiles; t += 64) {
     s += partials[((size_t)b * max_blocks + t) * 2];
@@ -587,8 +608,8 @@ __global__ __launch_bounds__(64) void k_fitness_final(const CloudDesc* descs, co
   s = wave_sum(s), c = wave_sum(c);
   if (threadIdx.x == 0) out[b].fit_sum = s, out[b].fit_count = (unsigned)(c + 0.5);
 }
-void launch_fitness_final(hipStream_t s, const CloudDesc* descs, const double* partials, int max_blocks, DevResult* out, int B) {
-  hipLaunchKernelGGL(k_fitness_final, dim3(B), dim3(64), 0, s, descs, partials, max_blocks, out);
+void launch_fitness_final(hipStream_t s, const CloudDesc* descs, const double* partials, int max_blocks, DevResult* out, int B, int tile_pts) {
+  hipLaunchKernelGGL(k_fitness_final, dim3(B), dim3(64), 0, s, descs, partials, max_blocks, out, tile_pts);
 }
 
 __global__ __launch_bounds__(kBlock) void k_nn_query(TargetView tgt, const float4* __restrict__ q, int nq, int* __restrict__ idx, float* __restrict__ d2out) {

@@ -61,6 +61,7 @@ struct PacketWalk {
   int kind;
   unsigned ldnode;          // WALK_LEAF: the leaf node to visit next
   unsigned skip_lo, skip_n; // leaf nodes [skip_lo, skip_lo + skip_n) are never visited (the caller has handled them)
+  int order_lane;           // the lane whose preference orders the children (middle of the packet's active lanes)
   // per lane
   float d[4];
   hgs_f2 qx, qy, qz;
@@ -68,7 +69,7 @@ struct PacketWalk {
 
   __device__ __forceinline__ void start(const BvhView& t, const F3& q, int k) {
     qx = hgs_f2{q.x, q.x}, qy = hgs_f2{q.y, q.y}, qz = hgs_f2{q.z, q.z};
-    pend = 0, todo = 0, lbase = 0, nextc = 0, ldnode = 1, skip_lo = 0, skip_n = 0;
+    pend = 0, todo = 0, lbase = 0, nextc = 0, ldnode = 1, skip_lo = 0, skip_n = 0, order_lane = 32;
     d[0] = d[1] = d[2] = d[3] = 0.f;
     if (t.n <= 0) {
       kind = WALK_DONE, node = 1, bd = 0;
@@ -107,7 +108,7 @@ struct PacketWalk {
       const int pref = dmin == INFINITY ? -1 : (dw[0] == dmin ? 0 : (dw[1] == dmin ? 1 : (dw[2] == dmin ? 2 : 3)));
       if (any) {
         // order: the nearest child the middle lane of the packet wants (else the lowest wanted slot)
-        int cstar = __builtin_amdgcn_readlane(pref, 32);
+        int cstar = __builtin_amdgcn_readlane(pref, order_lane);
         if (cstar < 0) cstar = __builtin_ctz(any);
         const int cd = bd + 2;
         if (cd == k) {
@@ -221,7 +222,7 @@ struct Nn1Lane {
 // to cover shrinks from max_correspondence_distance to about the true NN distance.
 template <int NW>
 __device__ __forceinline__ void wave_nn1(const BvhView& t, float* slots, const F3 (&q)[NW], const bool (&active)[NW], float bound2, const int (&seed)[NW],
-                                         float (&best)[NW], int (&best_pos)[NW], int (&best_orig)[NW]) {
+                                         float (&best)[NW], int (&best_pos)[NW], int (&best_orig)[NW], int qpw = 64) {
   PacketWalk<Nn1Lane> w[NW];
   const int k = 31 - __clz(t.P);
 #pragma unroll
@@ -237,6 +238,7 @@ __device__ __forceinline__ void wave_nn1(const BvhView& t, float* slots, const F
       if (d <= bound2) lane.key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w), lane.pos = seed[i];
     }
     w[i].start(t, qq, k);
+    w[i].order_lane = qpw >> 1;
   }
   wave_walk_multi<Nn1Lane, NW>(t, w, slots);
 #pragma unroll
@@ -269,32 +271,70 @@ struct KnnRadiusLane {
   }
 };
 
-// ---- k-NN gather: all points with d2 < r2, plus `ties_left` of those with d2 == r2, summed for the covariance -------
+// ---- k-NN gather: all points with d2 < r2 summed for the covariance; of those at exactly r2 the `ties_left` with the
+// lowest original indices (the order a kd-tree k-NN returns equal distances in) are remembered and added afterwards.
+// Every lane has at least one such point — its k-th neighbour — and almost never a second one, so the common
+// instantiation (TIES = 1) tracks a single minimum branch-free; TIES = 4 keeps a sorted list and is only run by waves in
+// which some lane needs more than one point at the k-th distance (duplicates / exactly equidistant points).
+template <int TIES>
 struct KnnGatherLane {
   float r2;       // squared distance of the k-th neighbour (-1: no query)
-  int ties_left;  // how many points at exactly r2 belong to the k nearest
+  int ties_left;  // how many points at exactly r2 belong to the k nearest (more than TIES: the first TIES by index)
   int found;
   double s1[3];   // sum (p - q)
   double s2[6];   // sum (p - q)(p - q)^T  xx,xy,xz,yy,yz,zz
   float qx0, qy0, qz0;
+  int tie_orig[TIES], tie_pos[TIES];  // ascending by original index
+  __device__ __forceinline__ void init(float r2_, int ties, float qx, float qy, float qz) {
+    r2 = r2_, ties_left = ties, found = 0;
+    s1[0] = s1[1] = s1[2] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) s2[j] = 0.0;
+    qx0 = qx, qy0 = qy, qz0 = qz;
+#pragma unroll
+    for (int t = 0; t < TIES; t++) tie_orig[t] = 0x7fffffff, tie_pos[t] = -1;
+  }
   __device__ __forceinline__ bool wants(float box_d2) const { return box_d2 <= r2; }
-  __device__ __forceinline__ void take(float dd, float px, float py, float pz) {
-    bool in = dd < r2;
-    if (dd == r2 && ties_left > 0) in = true, ties_left--;
-    if (in) {
-      const double dx = (double)px - (double)qx0, dy = (double)py - (double)qy0, dz = (double)pz - (double)qz0;
-      s1[0] += dx, s1[1] += dy, s1[2] += dz;
-      s2[0] += dx * dx, s2[1] += dx * dy, s2[2] += dx * dz, s2[3] += dy * dy, s2[4] += dy * dz, s2[5] += dz * dz;
-      found++;
+  __device__ __forceinline__ void add(float px, float py, float pz) {
+    const double dx = (double)px - (double)qx0, dy = (double)py - (double)qy0, dz = (double)pz - (double)qz0;
+    s1[0] += dx, s1[1] += dy, s1[2] += dz;
+    s2[0] += dx * dx, s2[1] += dx * dy, s2[2] += dx * dz, s2[3] += dy * dy, s2[4] += dy * dz, s2[5] += dz * dz;
+    found++;
+  }
+  __device__ __forceinline__ void take(float dd, float px, float py, float pz, int orig, int pos) {
+    if (dd < r2) add(px, py, pz);
+    if (TIES == 1) {
+      const bool sw = (dd == r2) & (orig < tie_orig[0]);
+      tie_orig[0] = sw ? orig : tie_orig[0], tie_pos[0] = sw ? pos : tie_pos[0];
+    } else if (__ballot(dd == r2) != 0ull) {
+      if (dd == r2) {
+        int o = orig, p = pos;
+#pragma unroll
+        for (int t = 0; t < TIES; t++) {
+          const bool sw = o < tie_orig[t];
+          const int to = tie_orig[t], tp = tie_pos[t];
+          tie_orig[t] = sw ? o : to, tie_pos[t] = sw ? p : tp;
+          o = sw ? to : o, p = sw ? tp : p;
+        }
+      }
     }
   }
   __device__ __forceinline__ void visit_leaf(const hgs_f16v& xy, const hgs_f16v& zw, hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, int base) {
 #pragma unroll
     for (int l = 0; l < 8; l += 2) {
       const hgs_f2 dd = pk_dist2(qx, qy, qz, hgs_f2{xy[l], xy[l + 1]}, hgs_f2{xy[8 + l], xy[9 + l]}, hgs_f2{zw[l], zw[l + 1]});
-      take(dd.x, xy[l], xy[8 + l], zw[l]);
-      take(dd.y, xy[l + 1], xy[9 + l], zw[l + 1]);
+      take(dd.x, xy[l], xy[8 + l], zw[l], __float_as_int(zw[8 + l]), base + l);
+      take(dd.y, xy[l + 1], xy[9 + l], zw[l + 1], __float_as_int(zw[9 + l]), base + l + 1);
     }
+  }
+  // after the walk: the remembered equidistant points, lowest original index first
+  __device__ __forceinline__ void finish(const float4* pts) {
+#pragma unroll
+    for (int t = 0; t < TIES; t++)
+      if (t < ties_left && tie_pos[t] >= 0) {
+        const float4 p = pts[tie_pos[t]];
+        add(p.x, p.y, p.z);
+      }
   }
 };
 
