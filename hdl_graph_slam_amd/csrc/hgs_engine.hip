@@ -1000,6 +1000,15 @@ int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_c
   std::vector<hgs_cloud*> src(candidates, candidates + n_candidates);
   for (hgs_cloud* c : src)
     if (!c || c->owner != h) return HGS_ERR_INVALID_ARGUMENT;
+  {
+    // every candidate carries its own correspondence scratch: the same cloud twice in one batch would race on it
+    std::vector<hgs_cloud*> sorted(src);
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) {
+      h->err = "hgs_loop_match_batch: candidate clouds must be distinct";
+      return HGS_ERR_INVALID_ARGUMENT;
+    }
+  }
   HGS_TRY(run_batch(h, src, guesses));
   HGS_TRY(run_fitness(h, src, max_range));
   std::vector<DevResult> r;

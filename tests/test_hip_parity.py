@@ -236,3 +236,20 @@ def test_two_engines_run_concurrently(gicp_case):
     ta.join(), tb.join()
     assert all(np.array_equal(m, ref_a) for m in out["a"]) and all(np.array_equal(m, ref_b) for m in out["b"])
     e2.close()
+
+
+def test_batch_rejects_duplicate_candidates_and_foreign_clouds(gicp_case):
+    """Every candidate owns its correspondence scratch and every cloud belongs to one engine's stream."""
+    e, o, tgt, src, T = gicp_case
+    from hdl_graph_slam_amd.registration import HgsError
+    c = e.upload(src)
+    with pytest.raises(HgsError):
+        e.loop_match_batch([c, c], [np.eye(4, dtype=np.float32)] * 2)
+    p = O.default_params(O.HGS_FAST_GICP)
+    other = _hip(p)
+    with pytest.raises(HgsError):
+        other.setInputSource(c)            # created by `e`
+    other.close()
+    rec, best = e.loop_match_batch([c], [np.eye(4, dtype=np.float32)])
+    assert len(rec) == 1 and best in (0, -1)
+    c.close()
