@@ -64,3 +64,51 @@ class CandidateShard:
         local["candidate_id"] = np.asarray(mine, np.int32)
         records = self.gather_records(local, n)
         return records, select_best(records)
+
+
+class MultiDeviceLoopMatcher:
+    """Single-process variant for hosts that are one process by construction (the ROS nodelet manager): one engine handle
+    per local GPU, candidate c -> engine c mod N (the partition of CandidateShard), every shard matched from its own host
+    thread (hgs handles are independent: own stream, own buffers), results merged on the host with the sequential selection
+    rule.  No collective is needed: the per-candidate records already live in host memory of the one process."""
+
+    def __init__(self, pnh: dict, device_ids):
+        from .registrations import select_registration_method
+        self.engines = [select_registration_method(pnh, device_id=d) for d in device_ids]
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def upload(self, candidate_index: int, cloud):
+        """Keyframe clouds live on the device of the engine that will match them."""
+        return self.engines[owner_of(candidate_index, len(self.engines))].upload(cloud)
+
+    def match(self, target, candidates: Sequence, guesses: Sequence[np.ndarray], max_range: float = L.DBL_MAX):
+        """candidates[i]: DeviceCloud created by upload(i, ...). Returns (records of all candidates in order, best)."""
+        import threading
+        n, W = len(candidates), len(self.engines)
+        out = np.zeros(n, dtype=L.RESULT_DTYPE)
+        errors = []
+
+        def work(r):
+            try:
+                mine = [i for i in range(n) if owner_of(i, W) == r]
+                if not mine:
+                    return
+                eng = self.engines[r]
+                eng.setInputTarget(target)       # host cloud: every engine builds its own copy (cheaper than a broadcast)
+                rec, _ = eng.loop_match_batch([candidates[i] for i in mine], [guesses[i] for i in mine], max_range)
+                rec["candidate_id"] = np.asarray(mine, np.int32)
+                out[mine] = rec
+            except Exception as exc:   # surfaced after join
+                errors.append(exc)
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(W)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return out, select_best(out)

@@ -71,3 +71,27 @@ def test_all_gather_of_candidate_records_world2(n):
 def test_owner_is_interleaved():
     from hdl_graph_slam_amd.distributed import owner_of
     assert [owner_of(c, 4) for c in range(9)] == [0, 1, 2, 3, 0, 1, 2, 3, 0]
+
+
+@pytest.mark.gpu
+def test_multi_device_matcher_equals_single_batch():
+    """The single-process multi-GPU path (one handle per device, host threads) on two handles of device 0 gives the records
+    of one batch on one handle, candidate for candidate."""
+    sys.path.insert(0, ROOT)
+    from hdl_graph_slam_amd import workloads, _lib as L
+    from hdl_graph_slam_amd.distributed import MultiDeviceLoopMatcher
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    wl = workloads.make_loop_closure_set("VLP-16", scene_seed=3, n_candidates=5, n_distinct=3, downsample=0.2)
+    pnh = {"registration_method": "FAST_GICP"}
+    mm = MultiDeviceLoopMatcher(pnh, [0, 0])
+    cands = [mm.upload(i, c) for i, c in enumerate(wl.candidates)]
+    rec_m, best_m = mm.match(wl.target, cands, wl.guesses)
+    one = select_registration_method(pnh, device_id=0)
+    one.setInputTarget(wl.target)
+    rec_1, best_1 = one.loop_match_batch([one.upload(c) for c in wl.candidates], wl.guesses)
+    assert best_m == best_1
+    for a, b in zip(rec_m, rec_1):
+        assert a["converged"] == b["converged"] and a["iterations"] == b["iterations"]
+        assert np.abs(np.array(a["final_transformation"]) - np.array(b["final_transformation"])).max() < 1e-6
+        assert abs(a["fitness_score"] - b["fitness_score"]) <= 1e-9 * abs(b["fitness_score"])
+    mm.close(), one.close()
