@@ -50,5 +50,5 @@ def test_adapter_matches_python_mirror(tmp_path, method):
     reg.setInputSource(src)
     r = reg.align(np.eye(4))
     assert np.array_equal(Tc, r.matrix())                       # same library, same inputs: identical bits
-    assert abs(float(out[2].split()[1]) - reg.getFitnessScore()) < 1e-12
+    assert abs(float(out[2].split()[1]) - reg.getFitnessScore()) < 1e-9      # printed with 12 significant digits
     reg.close()
