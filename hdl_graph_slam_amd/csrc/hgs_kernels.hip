@@ -415,7 +415,8 @@ __device__ __forceinline__ Sym3 load_cov_stream(const float4* cov, int i) {
 // update_correspondences + linearize fused: per source point 1-NN in the target tree, Mahalanobis matrix,
 // 6x6 normal-equation terms; wave shuffle + LDS reduction to one 28-double partial per block.
 // Algorithmic bytes per source point: 16 (a_i) + 24 (C_A) + 4 (corr) + 16 (b_j) + 24 (C_B) = 84.
-__global__ __launch_bounds__(kBlock) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
+// 7 waves per SIMD (72 VGPRs, 8 of the 28 fp64 accumulators spill around the search): measured best of 5 / 6 / 7 / 8.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
                                                            double* __restrict__ partials, int max_blocks, int qpw) {
   const int b = blockIdx.y;
   if (states[b].phase != GICP_LINEARIZE) return;
