@@ -141,3 +141,35 @@ def ndt_score(src, cells, p, res, direct7=True, freeze_p=None):
                 continue
             score += -d1 * e
     return score
+
+
+def vgicp_linearize(src, tgt, cov_s, cov_t, T, resolution, offsets=((0, 0, 0),)):
+    """fast_gicp::FastVGICP (ADDITIVE voxels, SURVEY Appendix A.3): voxel = {n, mean of the points, mean of their
+    covariances}, key floor(p / res - 0.5); every source point is matched against the voxel(s) of T a_i with weight
+    sqrt(n).  Returns H, b, error and the number of voxel correspondences per source point."""
+    src, tgt = np.asarray(src, np.float64), np.asarray(tgt, np.float64)
+    key_t = np.floor(tgt / resolution - 0.5).astype(np.int64)
+    vox = {}
+    for k, p, c in zip(map(tuple, key_t), tgt, cov_t):
+        v = vox.setdefault(k, [0, np.zeros(3), np.zeros((3, 3))])
+        v[0] += 1
+        v[1] += p
+        v[2] += c
+    R, t = T[:3, :3], T[:3, 3]
+    q = src @ R.T + t
+    key_s = np.floor(q / resolution - 0.5).astype(np.int64)
+    H, b, err, hits = np.zeros((6, 6)), np.zeros(6), 0.0, np.zeros(len(src), np.int32)
+    for i in range(len(src)):
+        for o in offsets:
+            v = vox.get((key_s[i, 0] + o[0], key_s[i, 1] + o[1], key_s[i, 2] + o[2]))
+            if v is None:
+                continue
+            hits[i] += 1
+            n, mean, cov = v[0], v[1] / v[0], v[2] / v[0]
+            M = np.sqrt(n) * np.linalg.inv(cov + R @ cov_s[i] @ R.T)
+            e = mean - q[i]
+            J = np.hstack([skew(q[i]), -np.eye(3)])
+            H += J.T @ M @ J
+            b += J.T @ M @ e
+            err += e @ M @ e
+    return H, b, err, hits

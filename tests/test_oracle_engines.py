@@ -100,6 +100,34 @@ def test_vgicp_align(medium_pair):
     assert cnt.max() <= 1 and cnt.sum() > 0.5 * len(src)     # DIRECT1: at most one voxel per point
 
 
+@pytest.mark.parametrize("search", [O.HGS_DIRECT1, O.HGS_DIRECT7])
+def test_vgicp_linearize_matches_numpy_and_finite_differences(medium_pair, search):
+    """The VGICP oracle against an independent numpy restatement (voxel hits exact, H / b / error to rounding), and its
+    b = J^T M e against the central difference of the error it reports for perturbed poses."""
+    tgt, src, T = medium_pair
+    xs, xt = synth.xyz_of(src)[::7].copy(), synth.xyz_of(tgt)
+    p = O.default_params(O.HGS_FAST_VGICP)
+    p.neighbor_search = search
+    r = O.OracleRegistration(p)
+    r.setInputTarget(xt)
+    r.setInputSource(xs)
+    T0 = (T @ NP.se3_exp([0.004, -0.003, 0.005, 0.03, -0.02, 0.01])).astype(np.float32).astype(np.float64)
+    H, b, err, hits = r.gicp_linearize(T0)
+    offs = ((0, 0, 0),) if search == O.HGS_DIRECT1 else ((0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1))
+    Hn, bn, en, hn = NP.vgicp_linearize(xs, xt, NP.gicp_covariances(xs), NP.gicp_covariances(xt), T0, p.resolution, offs)
+    assert np.array_equal(hits, hn)
+    assert np.allclose(H, Hn, rtol=1e-9, atol=1e-9 * np.abs(Hn).max()) and np.allclose(b, bn, rtol=1e-9, atol=1e-9 * np.abs(bn).max())
+    assert np.isclose(err, en, rtol=1e-10)
+    # gradient of sum w e^T M e w.r.t. a left perturbation exp(d) T0 with the correspondences frozen: 2 b
+    eps = 1e-6
+    g = np.zeros(6)
+    for k in range(6):
+        d = np.zeros(6)
+        d[k] = eps
+        g[k] = (r.gicp_error(NP.se3_exp(d) @ T0) - r.gicp_error(NP.se3_exp(-d) @ T0)) / (2 * eps)
+    assert np.allclose(g, 2 * b, rtol=2e-4, atol=2e-4 * np.abs(b).max())
+
+
 def _ndt(tgt, src, **kw):
     p = O.default_params(O.HGS_NDT_OMP)
     p.resolution = 1.0
