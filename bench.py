@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--candidates", type=int, default=16, help="candidate keyframes per GPU per step")
     ap.add_argument("--sensor", default="HDL-64E")
     ap.add_argument("--distinct", type=int, default=8, help="distinct ray-cast scans behind the candidates")
