@@ -51,12 +51,21 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    # test hooks (not used by the driver): HGS_BENCH_BACKEND=gloo + HGS_BENCH_ONE_DEVICE=1 exercise the N > 1 code path on a
+    # 1-GPU box (all ranks on device 0, records exchanged over gloo)
+    backend = os.environ.get("HGS_BENCH_BACKEND", "nccl")
+    if os.environ.get("HGS_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=coll_device)
+        else:
+            dist.init_process_group(backend)
 
     from hdl_graph_slam_amd import synth, workloads, _lib as L
     from hdl_graph_slam_amd.registrations import select_registration_method
@@ -79,7 +88,7 @@ def main():
     d_target = reg.upload(wl.target)
     d_cands = [reg.upload(c) for c in wl.candidates]
     n_pts = [len(c) for c in wl.candidates]
-    shard = CandidateShard(rank, world, device=torch.device("cuda", local_rank)) if world > 1 else None
+    shard = CandidateShard(rank, world, device=coll_device) if world > 1 else None
 
     def step(cold=True):
         d_target.invalidate()           # the query keyframe is new in every detection
@@ -109,7 +118,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
