@@ -9,7 +9,7 @@
 // Layout in HBM (per cloud):
 //   pts   : float4[P*LEAF]   sorted along a 48-bit Hilbert curve; .w = original index (int bits); padding = +inf
 //   lpts  : float[P*32]      the same points leaf by leaf in SoA form {x[8], y[8], z[8], w[8]} (128 bytes per leaf):
-//                            what the wave-cooperative walk reads (scalar loads, adjacent lanes of packed-fp32 math)
+//                            what the wave-cooperative walk reads (one coalesced record fetch per wave, packed-fp32 math)
 //   nodes : float[(P/2)*32]  heap-ordered tree, node n (1 <= n < 2P), children 2n, 2n+1, leaves P..2P-1 (leaf l owns
 //                            pts[l*LEAF .. l*LEAF+LEAF)).  Boxes are stored in GROUPS of four siblings-of-siblings:
 //                            group G holds nodes 4G..4G+3 — exactly the four grandchildren of node G — as one aligned

@@ -6,10 +6,14 @@
 //                     on-device 6x6 solve / LM control (fast_gicp::FastGICP, registrations.cpp:27-36)
 //   * NDT           : Gaussian voxel table build, DIRECT1/7 derivative pass, on-device Newton control
 //                     (pclomp::NormalDistributionsTransform, registrations.cpp:101-120)
+//   * VGICP         : Gaussian voxel map of the target, voxel-lookup linearize / trial error on the GICP LM state machine
+//                     (fast_gicp::FastVGICP, registrations.cpp:48-56)
 //   * fitness score : pcl::Registration::getFitnessScore (information_matrix_calculator.cpp:49-80)
+//   * next rows     : prefilter (apps/prefiltering_nodelet.cpp:131-182), map cloud (map_cloud_generator.cpp:13-51)
 // All kernels are batched: blockIdx.y selects the problem (loop-closure candidate, loop_detector.hpp:135-154);
-// the odometry path is the batch of one.  Work is HBM/L2-latency bound pointer chasing plus small fp64 algebra:
-// no MFMA (the contraction is 6x6), coalesced float4 loads, wave64 shuffle reductions, deterministic two-stage sums.
+// the odometry path is the batch of one.  The NN-based stages are bound by the instruction issue of the exact tree walk
+// (hgs_wave_bvh.h), the per-point algebra by HBM: no MFMA (the contraction is 6x6), coalesced float4 loads, wave64
+// shuffle reductions, deterministic two-stage sums.
 #include <hip/hip_runtime.h>
 #include "hgs_device.h"
 #include "hgs_wave_bvh.h"
@@ -401,7 +405,7 @@ __device__ __forceinline__ Sym3 load_cov(const float4* cov, int i) {
 }
 // Streamed-once data (the source side of a registration: points, covariances, correspondences) is read and written
 // with the non-temporal policy so that it does not evict the target's tree / leaves / covariances, which every wave
-// of every candidate re-reads, from the 4 MiB L2 of its XCD.
+// of every candidate re-reads, from the L2 (measured neutral on this workload; kept).
 __device__ __forceinline__ float4 load_stream(const float4* p) {
   typedef float v4 __attribute__((ext_vector_type(4)));
   const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
