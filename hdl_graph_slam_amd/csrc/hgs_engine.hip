@@ -530,7 +530,7 @@ int make_progress(hgs_handle* h, int B, Progress* out) {
 // Keeps the queue `kRunAhead` rounds ahead of the device without synchronising: returns true when another round should
 // be enqueued, false when every problem has finished.  Falls back to a blocking read if the mirror stops advancing
 // although the stream has drained (a launch failed): the caller then sees the error from hipGetLastError.
-constexpr long kRunAhead = 3;
+constexpr long kRunAhead = 2;  // one round executing, one queued behind it (a round is >= 100 us, enqueueing one ~20 us)
 bool want_another_round(hgs_handle* h, const Progress& prog, long rounds_enqueued) {
   long spins = 0;
   for (;;) {
