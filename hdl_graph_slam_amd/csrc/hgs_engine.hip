@@ -509,7 +509,9 @@ NdtConsts ndt_consts(const hgs_params& p) {
   c.step_size = p.ndt_step_size;
   c.trans_eps = p.transformation_epsilon;
   c.max_iterations = p.max_iterations;
-  c.search = p.neighbor_search == HGS_DIRECT1 ? 1 : 2;
+  c.search = p.neighbor_search == HGS_DIRECT1 ? 1 : (p.neighbor_search == HGS_KDTREE ? 0 : 2);
+  c.kdtree_radius2 = (float)(p.resolution * p.resolution);
+  c.pad2 = 0.f;
   c.upstream_hd1_sign = p.ndt_upstream_hd1_sign;
   c.pad = std::getenv("HGS_TRACE") ? 1 : 0;  // device-side per-iteration trace (parity debugging)
   return c;

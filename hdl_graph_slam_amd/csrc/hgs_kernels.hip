@@ -774,12 +774,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_derivatives(const CloudDesc* 
       const int cx = (int)floorf(xt.x * g.inv_leaf), cy = (int)floorf(xt.y * g.inv_leaf), cz = (int)floorf(xt.z * g.inv_leaf);
       NdtPointDeriv pd;
       ndt_point_derivatives(ang, x.x, x.y, x.z, pd);
-      const int nn = c.search == 1 ? 1 : 7;
+      const int nn = ndt_num_offsets(c.search);
       for (int o = 0; o < nn; o++) {
-        const int ox = (o == 1) - (o == 2), oy = (o == 3) - (o == 4), oz = (o == 5) - (o == 6);
+        int ox, oy, oz;
+        ndt_offset(c.search, o, &ox, &oy, &oz);
         const int ci = ndt_lookup(g, cx + ox, cy + oy, cz + oz);
         if (ci < 0) continue;
         const NdtCellRec rec = g.cells[ci];
+        if (!ndt_cell_in_reach(c, xt, rec.mean)) continue;
         const float icov[6] = {rec.v0.x, rec.v0.y, rec.v0.z, rec.v0.w, rec.v1.x, rec.v1.y};
         ndt_cell_terms(c, pd, (float)((double)xt.x - rec.mean[0]), (float)((double)xt.y - rec.mean[1]), (float)((double)xt.z - rec.mean[2]), icov, acc);
       }

@@ -84,10 +84,28 @@ struct NdtConsts {
   double gauss_d1, gauss_d2;
   double step_size, trans_eps;
   int max_iterations;
-  int search;  // HGS_DIRECT1 = 1 / HGS_DIRECT7 = 2
+  int search;  // HGS_KDTREE = 0 / HGS_DIRECT1 = 1 / HGS_DIRECT7 = 2 (the hgs_neighbor_search values)
   int upstream_hd1_sign;
   int pad;
+  float kdtree_radius2;  // KDTREE: (float)(resolution^2), the radius of VoxelGridCovariance::radiusSearch
+  float pad2;
 };
+
+// Neighbourhood of a transformed point (getNeighborhoodAtPoint1 / 7, or the KDTREE search of ndt_omp: a radius search of
+// `resolution` around the point on the kd-tree of the valid cells' centroids).  A centroid lies inside its own cell, so
+// every centroid within one resolution of the point belongs to one of the 27 cells around the point's cell: KDTREE is
+// the 27-neighbourhood filtered by the float distance to the (float) centroid — no second search structure.
+HGS_HD int ndt_num_offsets(int search) { return search == 1 ? 1 : (search == 2 ? 7 : 27); }
+HGS_HD void ndt_offset(int search, int o, int* ox, int* oy, int* oz) {
+  if (search == 0) {
+    *ox = o / 9 - 1, *oy = (o / 3) % 3 - 1, *oz = o % 3 - 1;
+  } else {  // centre, +x, -x, +y, -y, +z, -z
+    *ox = (o == 1) - (o == 2), *oy = (o == 3) - (o == 4), *oz = (o == 5) - (o == 6);
+  }
+}
+HGS_HD bool ndt_cell_in_reach(const NdtConsts& c, const F3& xt, const double* mean) {
+  return c.search != 0 || dist2f(xt, (float)mean[0], (float)mean[1], (float)mean[2]) <= c.kdtree_radius2;
+}
 
 // Angular derivative tables (computeAngleDerivatives): 8 j_ang rows and 15 h_ang rows as float triples.
 struct NdtAngles {

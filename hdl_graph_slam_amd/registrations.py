@@ -41,9 +41,7 @@ def params_from_rosparams(pnh) -> L.HgsParams:
     p.transformation_epsilon = float(get("reg_transformation_epsilon", 0.01))
     p.max_iterations = int(get("reg_maximum_iterations", 64))
     nn = str(get("reg_nn_search_method", "DIRECT7"))
-    if nn == "KDTREE":
-        raise NotImplementedError("reg_nn_search_method=KDTREE is not implemented on the device (DIRECT1 / DIRECT7 are)")
-    p.neighbor_search = L.HGS_DIRECT1 if nn == "DIRECT1" else L.HGS_DIRECT7
+    p.neighbor_search = {"KDTREE": L.HGS_KDTREE, "DIRECT1": L.HGS_DIRECT1}.get(nn, L.HGS_DIRECT7)      # registrations.cpp:112-118
     return p
 
 

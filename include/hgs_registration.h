@@ -47,7 +47,7 @@ enum hgs_method {
 
 /* reg_nn_search_method (registrations.cpp:103,112-118) / FastVGICP neighbour search. */
 enum hgs_neighbor_search {
-  HGS_KDTREE = 0,
+  HGS_KDTREE = 0,  /* NDT_OMP only: radius search (resolution) over the centroids of the valid cells */
   HGS_DIRECT1 = 1,
   HGS_DIRECT7 = 2,
   HGS_DIRECT27 = 3

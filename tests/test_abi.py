@@ -60,6 +60,7 @@ def test_rosparam_mapping_follows_registrations_cpp(L):
     assert (p.method, p.max_correspondence_distance, p.transformation_epsilon, p.correspondence_randomness) == (L.HGS_FAST_GICP, 2.0, 0.1, 20)
     p = params_from_rosparams({"registration_method": "NDT_OMP", "reg_nn_search_method": "DIRECT1", "reg_resolution": 1.0})
     assert (p.neighbor_search, p.resolution) == (L.HGS_DIRECT1, 1.0)
+    assert params_from_rosparams({"reg_nn_search_method": "KDTREE"}).neighbor_search == L.HGS_KDTREE
     p = params_from_rosparams({"registration_method": "bogus"})      # unknown -> NDT with a warning (registrations.cpp:88-91)
     assert p.method == L.HGS_NDT_OMP
     with pytest.raises(NotImplementedError):

@@ -98,7 +98,8 @@ def test_vgicp_align(vgicp_case, guess_kind):
     PC.check_align(e, o, guess, tol_m=1e-5, tol_rad=2e-5)
 
 
-@pytest.fixture(scope="module", params=[("hdl32", 1.0, O.HGS_DIRECT7), ("hdl32", 0.5, O.HGS_DIRECT1), ("vlp16", 1.0, O.HGS_DIRECT7)])
+@pytest.fixture(scope="module", params=[("hdl32", 1.0, O.HGS_DIRECT7), ("hdl32", 0.5, O.HGS_DIRECT1), ("vlp16", 1.0, O.HGS_DIRECT7),
+                                        ("hdl32", 1.0, O.HGS_KDTREE)])
 def ndt_case(request):
     kind, res, search = request.param
     tgt, src, T = _pair(kind)

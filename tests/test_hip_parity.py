@@ -135,7 +135,8 @@ def test_vgicp_align(vgicp_case, guess_kind):
     assert bytes(a.final_transformation) == bytes(re.final_transformation)   # run-to-run determinism
 
 
-@pytest.fixture(scope="module", params=[("hdl32", 1.0, O.HGS_DIRECT7), ("hdl32", 0.5, O.HGS_DIRECT1), ("vlp16", 1.0, O.HGS_DIRECT7), ("hdl32_raw", 1.0, O.HGS_DIRECT7)])
+@pytest.fixture(scope="module", params=[("hdl32", 1.0, O.HGS_DIRECT7), ("hdl32", 0.5, O.HGS_DIRECT1), ("vlp16", 1.0, O.HGS_DIRECT7), ("hdl32_raw", 1.0, O.HGS_DIRECT7),
+                                        ("hdl32", 1.0, O.HGS_KDTREE)])
 def ndt_case(request):
     kind, res, search = request.param
     tgt, src, T = _pair(kind)
