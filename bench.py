@@ -178,7 +178,9 @@ def main():
                 traffic_src = os.path.relpath(pmc_path, ROOT)
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if traffic is None else round(traffic, 1), "traffic_source": traffic_src,
-                "limiter": "instruction issue (VALU+SALU) of the exact tree search, not HBM: see DESIGN.md section 4",
+                "limiter": {"FAST_GICP": "instruction issue (VALU+SALU) of the exact tree search, not HBM: see DESIGN.md section 4",
+                            "FAST_VGICP": "VALU + dependent L2 round trips of the voxel hash probes, not HBM: see DESIGN.md section 4",
+                            "NDT_OMP": "VALU of the per-cell float derivative terms at 2 waves/SIMD (256 VGPRs), not HBM: see DESIGN.md section 4"}[args.method],
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches": launches,
                 "algorithmic_bytes_per_launch": round(units[dom] * bytes_per_unit / max(launches, 1), 1),
                 "stage_ms_per_step": {s: round(prof[s][0] / prof_steps, 3) for s in prof}}

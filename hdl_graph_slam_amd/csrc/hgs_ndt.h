@@ -47,18 +47,19 @@ HGS_HD bool ndt_finalize_cell(int n, const double* sum, const Sym3& sq, int min_
   const double dn = (double)n;
   mean[0] = sum[0] / dn, mean[1] = sum[1] / dn, mean[2] = sum[2] / dn;
   if (n < min_points) return false;
-  // cov = (sum pp^T - 2 sum_p mean^T)/n + mean mean^T, then *(n-1)/n  (upstream's single-pass form)
+  // cov = (sum pp^T - 2 sum_p mean^T)/n + mean mean^T, then *(n-1)/n  (upstream's single-pass form).  sum_p mean^T is not
+  // symmetric in floating point: the eigen-solver reads the LOWER triangle (as SelfAdjointEigenSolver does), the inverse
+  // below takes the full matrix.  Only the sign of a ~0 eigenvalue of a degenerate cell (6 collinear returns of one
+  // vertical structure) depends on this, but that sign decides whether the cell exists.
   const double f = (dn - 1.0) / dn;
-  double C[9];
-  C[0] = ((sq.xx - 2.0 * (sum[0] * mean[0])) / dn + mean[0] * mean[0]) * f;
-  C[1] = ((sq.xy - 2.0 * (sum[0] * mean[1])) / dn + mean[0] * mean[1]) * f;
-  C[2] = ((sq.xz - 2.0 * (sum[0] * mean[2])) / dn + mean[0] * mean[2]) * f;
-  C[4] = ((sq.yy - 2.0 * (sum[1] * mean[1])) / dn + mean[1] * mean[1]) * f;
-  C[5] = ((sq.yz - 2.0 * (sum[1] * mean[2])) / dn + mean[1] * mean[2]) * f;
-  C[8] = ((sq.zz - 2.0 * (sum[2] * mean[2])) / dn + mean[2] * mean[2]) * f;
-  C[3] = C[1], C[6] = C[2], C[7] = C[5];
+  const double q[9] = {sq.xx, sq.xy, sq.xz, sq.xy, sq.yy, sq.yz, sq.xz, sq.yz, sq.zz};
+  double C[9], S[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) C[r * 3 + c] = ((q[r * 3 + c] - 2.0 * (sum[r] * mean[c])) / dn + mean[r] * mean[c]) * f;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) S[r * 3 + c] = r >= c ? C[r * 3 + c] : C[c * 3 + r];
   double w[3], V[9];
-  eig_sym3(C, w, V);
+  eig_sym3(S, w, V);
   if (w[0] < 0 || w[1] < 0 || w[2] <= 0) return false;
   const double mn = 0.01 * w[2];
   if (w[0] < mn) {

@@ -79,7 +79,9 @@ public:
       NdtCell& c = kv.second;
       const double n = (double)c.n;
       const V3 pt_sum{c.sum[0], c.sum[1], c.sum[2]};
-      c.mean = (1.0 / n) * pt_sum;
+      // leaf.mean_ /= leaf.nr_points: a true division per component in the Eigen 3.3 of the ROS distributions
+      // hdl_graph_slam builds on (Eigen 3.2 multiplied by the reciprocal, an ulp apart)
+      c.mean = V3{pt_sum.x / n, pt_sum.y / n, pt_sum.z / n};
       if (c.n < min_points) continue;
       const double ps[3] = {pt_sum.x, pt_sum.y, pt_sum.z}, mu[3] = {c.mean.x, c.mean.y, c.mean.z};
       for (int r = 0; r < 3; r++)
