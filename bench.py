@@ -52,14 +52,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
     # test hooks (not used by the driver): HGS_BENCH_BACKEND=gloo + HGS_BENCH_ONE_DEVICE=1 exercise the N > 1 code path on a
-    # 1-GPU box (all ranks on device 0, records exchanged over gloo)
+    # 1-GPU box (all ranks on device 0, records exchanged over gloo); HGS_BENCH_FORCE_DIST=1 takes the process-group path at
+    # world size 1, i.e. the RCCL all-gather / all-reduce / barrier on device tensors with a single rank
     backend = os.environ.get("HGS_BENCH_BACKEND", "nccl")
     if os.environ.get("HGS_BENCH_ONE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
-    if world > 1:
+    sharded = world > 1 or bool(os.environ.get("HGS_BENCH_FORCE_DIST"))
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -88,7 +90,7 @@ def main():
     d_target = reg.upload(wl.target)
     d_cands = [reg.upload(c) for c in wl.candidates]
     n_pts = [len(c) for c in wl.candidates]
-    shard = CandidateShard(rank, world, device=coll_device) if world > 1 else None
+    shard = CandidateShard(rank, world, device=coll_device) if sharded else None
 
     def step(cold=True):
         d_target.invalidate()           # the query keyframe is new in every detection

@@ -124,6 +124,11 @@ struct hgs_handle {
   hgs_params prm{};
   int device = 0;
   hipStream_t stream = nullptr;
+  // extra streams of a batch (run_batch): the problems are split into lanes whose launch chains are independent, so the
+  // block-per-problem solve / decide kernels of one lane run under the point kernels of the others
+  hipStream_t lane_stream[7] = {};
+  hipEvent_t lane_event[8] = {};
+  int batch_lanes = 4;  // measured on the 16 x 120 k-point loop batch: 1 -> 2 -> 4 lanes = 2850 -> 2935 -> 2975 GICP reg/s, 735 -> 772 -> 797 NDT
   std::string err;
   hgs_cloud* target = nullptr;
   hgs_cloud* source = nullptr;
@@ -131,6 +136,7 @@ struct hgs_handle {
   float final_T[16];
 
   DeviceBuffer staging, sort_keys[2], sort_vals[2], sort_tmp, descs, states, angles, partials, partials_err, results, guesses, done, misc;
+  DeviceBuffer lane_partials[7], lane_partials_err[7];
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_descs, h_results, h_small, h_flags;  // h_flags: host-mapped progress mirror (Progress)
 
@@ -517,32 +523,106 @@ NdtConsts ndt_consts(const hgs_params& p) {
   return c;
 }
 
-// Progress mirror of a batch: device counters + two ints of host-mapped pinned memory the kernels write into.
-int make_progress(hgs_handle* h, int B, Progress* out) {
+constexpr int kMaxLanes = 8;  // 2 ints of the 64-byte progress blocks per lane
+
+// Progress mirror of one lane of a batch: device counters + two ints of host-mapped pinned memory the kernels write into.
+int make_progress(hgs_handle* h, int lane, int B, Progress* out) {
   HGS_HIP(h, h->done.reserve(64));
   HGS_HIP(h, h->h_flags.reserve(64));
-  volatile int* hf = h->h_flags.as<volatile int>();
-  hf[0] = 0, hf[1] = 0;  // everything enqueued earlier on this stream has completed (results were fetched with a sync)
-  out->dev = h->done.as<int>();
+  volatile int* hf = h->h_flags.as<volatile int>() + 2 * lane;
+  hf[0] = 0, hf[1] = 0;  // everything enqueued earlier on these streams has completed (results were fetched with a sync)
+  out->dev = h->done.as<int>() + 2 * lane;
   out->host_done = hf, out->host_rounds = hf + 1;
   out->B = B, out->pad = 0;
   return HGS_OK;
 }
 
-// Keeps the queue `kRunAhead` rounds ahead of the device without synchronising: returns true when another round should
-// be enqueued, false when every problem has finished.  Falls back to a blocking read if the mirror stops advancing
-// although the stream has drained (a launch failed): the caller then sees the error from hipGetLastError.
+// One lane of a batch: problems [b0, b0 + B) on their own stream with their own progress mirror and partial-sum buffers.
+struct BatchLane {
+  hipStream_t stream = nullptr;
+  int b0 = 0, B = 0;
+  Progress prog{};
+  double* partials = nullptr;
+  double* partials_err = nullptr;
+  long round = 0;
+  bool finished = false;
+};
+
+// Splits B problems into lanes (contiguous ranges) and makes the extra streams wait for what the main stream has enqueued
+// so far (indices, covariances, descriptors, guesses).  Profiling keeps one lane: the stage timers bracket launches on the
+// main stream and are meant to time kernels that have the device to themselves.
+int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t partial_err_bytes_per_problem, std::vector<BatchLane>& lanes) {
+  const int n = h->profiling ? 1 : std::max(1, std::min(std::min(h->batch_lanes, kMaxLanes), B));
+  lanes.assign(n, BatchLane{});
+  for (int i = 0, b0 = 0; i < n; i++) {
+    BatchLane& L = lanes[i];
+    L.b0 = b0, L.B = (B - b0) / (n - i);
+    b0 += L.B;
+    HGS_TRY(make_progress(h, i, L.B, &L.prog));
+    if (i == 0) {
+      L.stream = h->stream;
+      L.partials = h->partials.as<double>(), L.partials_err = h->partials_err.as<double>();
+      continue;
+    }
+    if (!h->lane_stream[i - 1]) HGS_HIP(h, hipStreamCreateWithFlags(&h->lane_stream[i - 1], hipStreamNonBlocking));
+    L.stream = h->lane_stream[i - 1];
+    HGS_HIP(h, h->lane_partials[i - 1].reserve((size_t)L.B * partial_bytes_per_problem));
+    HGS_HIP(h, h->lane_partials_err[i - 1].reserve((size_t)L.B * partial_err_bytes_per_problem));
+    L.partials = h->lane_partials[i - 1].as<double>(), L.partials_err = h->lane_partials_err[i - 1].as<double>();
+  }
+  if (n > 1) {
+    if (!h->lane_event[0]) HGS_HIP(h, hipEventCreateWithFlags(&h->lane_event[0], hipEventDisableTiming));
+    HGS_HIP(h, hipEventRecord(h->lane_event[0], h->stream));
+    for (int i = 1; i < n; i++) HGS_HIP(h, hipStreamWaitEvent(lanes[i].stream, h->lane_event[0], 0));
+  }
+  return HGS_OK;
+}
+
+// The main stream continues after every lane has finished.
+int close_lanes(hgs_handle* h, std::vector<BatchLane>& lanes) {
+  for (size_t i = 1; i < lanes.size(); i++) {
+    if (!h->lane_event[i]) HGS_HIP(h, hipEventCreateWithFlags(&h->lane_event[i], hipEventDisableTiming));
+    HGS_HIP(h, hipEventRecord(h->lane_event[i], lanes[i].stream));
+    HGS_HIP(h, hipStreamWaitEvent(h->stream, h->lane_event[i], 0));
+  }
+  return HGS_OK;
+}
+
+// Keeps every lane's queue `kRunAhead` rounds ahead of the device without synchronising: enqueue_round(lane) is called
+// whenever a lane that still has unfinished problems has fewer than kRunAhead rounds in flight; returns once every lane
+// has finished (or exhausted max_rounds).  If the mirrors stop advancing although the streams have drained (a launch
+// failed) the loop keeps enqueueing up to max_rounds: the caller then sees the error from hipGetLastError.
 constexpr long kRunAhead = 2;  // one round executing, one queued behind it (a round is >= 100 us, enqueueing one ~20 us)
-bool want_another_round(hgs_handle* h, const Progress& prog, long rounds_enqueued) {
+template <typename F>
+void drive_lanes(std::vector<BatchLane>& lanes, long max_rounds, F&& enqueue_round) {
   long spins = 0;
   for (;;) {
-    if (*prog.host_done) return false;
-    if (rounds_enqueued - (long)*prog.host_rounds < kRunAhead) return true;
-    if ((++spins & 0x3ff) == 0 && hipStreamQuery(h->stream) == hipSuccess) {
-      // drained: either the mirror has just been updated or something went wrong
-      if (*prog.host_done) return false;
-      if (rounds_enqueued - (long)*prog.host_rounds < kRunAhead) return true;
-      return true;  // do not spin forever; max_rounds bounds the loop
+    bool all_finished = true, enqueued = false;
+    for (BatchLane& L : lanes) {
+      if (L.finished) continue;
+      if (*L.prog.host_done || L.round >= max_rounds) {
+        L.finished = true;
+        continue;
+      }
+      all_finished = false;
+      if (L.round - (long)*L.prog.host_rounds < kRunAhead) {
+        enqueue_round(L);
+        L.round++;
+        enqueued = true;
+      }
+    }
+    if (all_finished) return;
+    if (enqueued) {
+      spins = 0;
+      continue;
+    }
+    if ((++spins & 0x3ff) == 0) {
+      for (BatchLane& L : lanes)
+        if (!L.finished && !*L.prog.host_done && hipStreamQuery(L.stream) == hipSuccess && !*L.prog.host_done &&
+            L.round - (long)*L.prog.host_rounds >= kRunAhead) {
+          enqueue_round(L);  // drained without the mirror advancing: do not spin forever, max_rounds bounds the loop
+          L.round++;
+        }
     }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
@@ -585,61 +665,61 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     const VgicpConsts vc = vgicp_consts(h->prm);
     HGS_HIP(h, h->states.reserve((size_t)B * sizeof(GicpState)));
     GicpState* st = h->states.as<GicpState>();
-    Progress prog;
-    HGS_TRY(make_progress(h, B, &prog));
-    launch_gicp_init(h->stream, st, h->guesses.as<float>(), B, prog);
     const TargetView tv = target_view(tgt);
     const NdtTargetView vtv = voxel ? vgicp_target_view(tgt) : NdtTargetView{};
     const long max_rounds = (long)std::max(1, c.max_iterations) * std::max(1, c.lm_max_iterations) + 2;
-    long round = 0;
-    while (round < max_rounds && want_another_round(h, prog, round)) {
+    std::vector<BatchLane> lanes;
+    HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
+    for (BatchLane& L : lanes) launch_gicp_init(L.stream, st + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, L.B, L.prog);
+    drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
+      const CloudDesc* dd = d_descs + L.b0;
+      GicpState* ls = st + L.b0;
       {
         StageTimer tm(h, HGS_STAGE_LINEARIZE);
-        if (voxel) launch_vgicp_linearize(h->stream, d_descs, vtv, st, vc, h->partials.as<double>(), max_blocks, B);
-        else launch_gicp_linearize(h->stream, d_descs, tv, st, c, h->partials.as<double>(), max_blocks, B, qpw);
+        if (voxel) launch_vgicp_linearize(L.stream, dd, vtv, ls, vc, L.partials, max_blocks, L.B);
+        else launch_gicp_linearize(L.stream, dd, tv, ls, c, L.partials, max_blocks, L.B, qpw);
       }
       {
         StageTimer tm(h, HGS_STAGE_SOLVE);
-        launch_gicp_solve(h->stream, d_descs, st, c, h->partials.as<double>(), max_blocks, B, voxel ? kBlock : nn_tile);
+        launch_gicp_solve(L.stream, dd, ls, c, L.partials, max_blocks, L.B, voxel ? kBlock : nn_tile);
       }
       {
         StageTimer tm(h, HGS_STAGE_ERROR);
-        if (voxel) launch_vgicp_error(h->stream, d_descs, vtv, st, vc, h->partials_err.as<double>(), max_blocks, B);
-        else launch_gicp_error(h->stream, d_descs, tv, st, h->partials_err.as<double>(), max_blocks, B);
+        if (voxel) launch_vgicp_error(L.stream, dd, vtv, ls, vc, L.partials_err, max_blocks, L.B);
+        else launch_gicp_error(L.stream, dd, tv, ls, L.partials_err, max_blocks, L.B);
       }
       {
         StageTimer tm(h, HGS_STAGE_SOLVE);
-        launch_gicp_decide(h->stream, d_descs, st, c, h->partials_err.as<double>(), max_blocks, B, prog);
+        launch_gicp_decide(L.stream, dd, ls, c, L.partials_err, max_blocks, L.B, L.prog);
       }
-      round++;
-    }
-    launch_gicp_results(h->stream, st, h->results.as<DevResult>(), B);
+    });
+    for (BatchLane& L : lanes) launch_gicp_results(L.stream, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
+    HGS_TRY(close_lanes(h, lanes));
   } else {
     const NdtConsts c = ndt_consts(h->prm);
     HGS_HIP(h, h->states.reserve((size_t)B * sizeof(NdtState)));
     HGS_HIP(h, h->angles.reserve((size_t)B * sizeof(NdtAngles)));
     NdtState* st = h->states.as<NdtState>();
     NdtAngles* ang = h->angles.as<NdtAngles>();
-    Progress prog;
-    HGS_TRY(make_progress(h, B, &prog));
-    launch_ndt_init(h->stream, st, ang, h->guesses.as<float>(), c, B, prog);
     NdtTargetView tv;
     tv.hash_keys = tgt->ndt_hash_keys, tv.hash_vals = tgt->ndt_hash_vals, tv.cells = tgt->ndt_cells, tv.meta = tgt->desc.meta;
     tv.hash_mask = tgt->ndt_hash_cap - 1, tv.inv_leaf = 1.0f / (float)h->prm.resolution;
     const long max_rounds = (long)c.max_iterations + 4;
-    long round = 0;
-    while (round < max_rounds && want_another_round(h, prog, round)) {
+    std::vector<BatchLane> lanes;
+    HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
+    for (BatchLane& L : lanes) launch_ndt_init(L.stream, st + L.b0, ang + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, c, L.B, L.prog);
+    drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       {
         StageTimer tm(h, HGS_STAGE_LINEARIZE);
-        launch_ndt_derivatives(h->stream, d_descs, tv, st, ang, c, h->partials.as<double>(), max_blocks, B);
+        launch_ndt_derivatives(L.stream, d_descs + L.b0, tv, st + L.b0, ang + L.b0, c, L.partials, max_blocks, L.B);
       }
       {
         StageTimer tm(h, HGS_STAGE_SOLVE);
-        launch_ndt_solve(h->stream, d_descs, st, ang, c, h->partials.as<double>(), max_blocks, B, prog);
+        launch_ndt_solve(L.stream, d_descs + L.b0, st + L.b0, ang + L.b0, c, L.partials, max_blocks, L.B, L.prog);
       }
-      round++;
-    }
-    launch_ndt_results(h->stream, d_descs, st, h->results.as<DevResult>(), B);
+    });
+    for (BatchLane& L : lanes) launch_ndt_results(L.stream, d_descs + L.b0, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
+    HGS_TRY(close_lanes(h, lanes));
   }
   HGS_HIP(h, hipGetLastError());
   return HGS_OK;
@@ -748,6 +828,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) {
   h->device = p->device_id;
   for (int i = 0; i < 16; i++) h->final_T[i] = (i % 5 == 0) ? 1.f : 0.f;
   for (int i = 0; i < HGS_STAGE_COUNT; i++) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
+  if (const char* e = std::getenv("HGS_BATCH_LANES")) h->batch_lanes = std::max(1, std::min(kMaxLanes, std::atoi(e)));  // A/B measurements
   if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     g_create_error = "hipSetDevice / hipStreamCreate failed";
     delete h;
@@ -761,12 +842,19 @@ int hgs_destroy(hgs_handle* h) {
   if (!h) return HGS_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (hipStream_t ls : h->lane_stream)
+    if (ls) (void)hipStreamSynchronize(ls);
   if (h->own_target) cloud_free(h->target);
   if (h->own_source) cloud_free(h->source);
   DeviceBuffer* bufs[] = {&h->staging, &h->sort_keys[0], &h->sort_keys[1], &h->sort_vals[0], &h->sort_vals[1], &h->sort_tmp, &h->descs, &h->states,
                           &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc,
                           &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist};
   for (DeviceBuffer* b : bufs) b->release();
+  for (int i = 0; i < 7; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
+  for (hipEvent_t ev : h->lane_event)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipStream_t ls : h->lane_stream)
+    if (ls) (void)hipStreamDestroy(ls);
   for (auto& blk : h->block_pool) (void)hipFree(blk.first);
   h->block_pool.clear();
   h->h_descs.release();

@@ -95,3 +95,19 @@ def test_multi_device_matcher_equals_single_batch():
         assert np.abs(np.array(a["final_transformation"]) - np.array(b["final_transformation"])).max() < 1e-6
         assert abs(a["fitness_score"] - b["fitness_score"]) <= 1e-9 * abs(b["fitness_score"])
     mm.close(), one.close()
+
+
+@pytest.mark.gpu
+def test_bench_process_group_path_over_rccl():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, backend nccl = RCCL), with one
+    rank: the all-gather of the candidate records, the max-over-ranks all-reduce and the barriers run on device tensors."""
+    import json
+    import subprocess
+    env = dict(os.environ, HGS_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29731",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--candidates", "4", "--sensor", "HDL-32E", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["converged"] == 4 and rec["roofline"]["frac"] > 0
