@@ -126,9 +126,11 @@ struct hgs_handle {
   hipStream_t stream = nullptr;
   // extra streams of a batch (run_batch): the problems are split into lanes whose launch chains are independent, so the
   // block-per-problem solve / decide kernels of one lane run under the point kernels of the others
-  hipStream_t lane_stream[7] = {};
-  hipEvent_t lane_event[8] = {};
-  int batch_lanes = 4;  // measured on the 16 x 120 k-point loop batch: 1 -> 2 -> 4 lanes = 2850 -> 2935 -> 2975 GICP reg/s, 735 -> 772 -> 797 NDT
+  hipStream_t lane_stream[3] = {};
+  hipEvent_t lane_event[4] = {};
+  // measured on the 16 x 120 k-point loop batch: 1 -> 2 -> 4 lanes = 2850 -> 2935 -> 2975 GICP reg/s, 735 -> 772 -> 797 NDT;
+  // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default)
+  int batch_lanes = 4;
   std::string err;
   hgs_cloud* target = nullptr;
   hgs_cloud* source = nullptr;
@@ -136,7 +138,7 @@ struct hgs_handle {
   float final_T[16];
 
   DeviceBuffer staging, sort_keys[2], sort_vals[2], sort_tmp, descs, states, angles, partials, partials_err, results, guesses, done, misc;
-  DeviceBuffer lane_partials[7], lane_partials_err[7];
+  DeviceBuffer lane_partials[3], lane_partials_err[3];
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_descs, h_results, h_small, h_flags;  // h_flags: host-mapped progress mirror (Progress)
 
@@ -523,7 +525,7 @@ NdtConsts ndt_consts(const hgs_params& p) {
   return c;
 }
 
-constexpr int kMaxLanes = 8;  // 2 ints of the 64-byte progress blocks per lane
+constexpr int kMaxLanes = 4;  // one per hardware queue the HIP runtime uses by default
 
 // Progress mirror of one lane of a batch: device counters + two ints of host-mapped pinned memory the kernels write into.
 int make_progress(hgs_handle* h, int lane, int B, Progress* out) {
@@ -589,12 +591,13 @@ int close_lanes(hgs_handle* h, std::vector<BatchLane>& lanes) {
 }
 
 // Keeps every lane's queue `kRunAhead` rounds ahead of the device without synchronising: enqueue_round(lane) is called
-// whenever a lane that still has unfinished problems has fewer than kRunAhead rounds in flight; returns once every lane
-// has finished (or exhausted max_rounds).  If the mirrors stop advancing although the streams have drained (a launch
+// whenever a lane that still has unfinished problems has fewer than kRunAhead rounds in flight, on_finished(lane) once
+// when the lane's problems have all finished (or max_rounds is exhausted) — what it enqueues runs behind the lane's
+// last rounds while the other lanes are still iterating; returns once every lane has finished.  If the mirrors stop advancing although the streams have drained (a launch
 // failed) the loop keeps enqueueing up to max_rounds: the caller then sees the error from hipGetLastError.
 constexpr long kRunAhead = 2;  // one round executing, one queued behind it (a round is >= 100 us, enqueueing one ~20 us)
-template <typename F>
-void drive_lanes(std::vector<BatchLane>& lanes, long max_rounds, F&& enqueue_round) {
+template <typename F, typename G>
+void drive_lanes(std::vector<BatchLane>& lanes, long max_rounds, F&& enqueue_round, G&& on_finished) {
   long spins = 0;
   for (;;) {
     bool all_finished = true, enqueued = false;
@@ -602,6 +605,7 @@ void drive_lanes(std::vector<BatchLane>& lanes, long max_rounds, F&& enqueue_rou
       if (L.finished) continue;
       if (*L.prog.host_done || L.round >= max_rounds) {
         L.finished = true;
+        on_finished(L);
         continue;
       }
       all_finished = false;
@@ -630,12 +634,28 @@ void drive_lanes(std::vector<BatchLane>& lanes, long max_rounds, F&& enqueue_rou
   }
 }
 
+// getFitnessScore of one lane's problems at the poses stored in h->results (exact 1-NN of every transformed source point
+// in the target; FAST_GICP seeds the search with the final correspondences).
+void lane_fitness(hgs_handle* h, BatchLane& L, const CloudDesc* d_descs, double max_range, int max_blocks, int qpw, int nn_tile) {
+  StageTimer tm(h, HGS_STAGE_FITNESS);
+  DevResult* res = h->results.as<DevResult>() + L.b0;
+  launch_fitness(L.stream, d_descs + L.b0, target_view(h->target), res, max_range, L.partials_err, max_blocks, L.B, h->prm.method == HGS_FAST_GICP ? 1 : 0, qpw);
+  launch_fitness_final(L.stream, d_descs + L.b0, L.partials_err, max_blocks, res, L.B, nn_tile);
+}
+
 // Run all B registrations (sources vs the handle's target) to completion; results land in h->results (device).
-int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float* guesses_host) {
+// With fit_max_range the getFitnessScore pass of every problem (fit_sum / fit_count of its result record) is enqueued on
+// the problem's lane as soon as the lane has converged, i.e. under the remaining iterations of the other lanes.
+int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float* guesses_host, const double* fit_max_range = nullptr) {
   const int B = (int)sources.size();
   hgs_cloud* tgt = h->target;
   const int method = h->prm.method;
   std::vector<hgs_cloud*> all(sources);
+  if (fit_max_range) {
+    std::vector<hgs_cloud*> searched(sources);
+    searched.push_back(tgt);
+    HGS_TRY(ensure_index(h, searched));
+  }
   if (method == HGS_FAST_GICP || method == HGS_FAST_VGICP) {
     all.push_back(tgt);
     HGS_TRY(ensure_cov(h, all, h->prm.correspondence_randomness));
@@ -670,6 +690,10 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     const long max_rounds = (long)std::max(1, c.max_iterations) * std::max(1, c.lm_max_iterations) + 2;
     std::vector<BatchLane> lanes;
     HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
+    auto finish_lane = [&](BatchLane& L) {
+      launch_gicp_results(L.stream, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
+      if (fit_max_range) lane_fitness(h, L, d_descs, *fit_max_range, max_blocks, qpw, nn_tile);
+    };
     for (BatchLane& L : lanes) launch_gicp_init(L.stream, st + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, L.B, L.prog);
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       const CloudDesc* dd = d_descs + L.b0;
@@ -692,8 +716,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
         StageTimer tm(h, HGS_STAGE_SOLVE);
         launch_gicp_decide(L.stream, dd, ls, c, L.partials_err, max_blocks, L.B, L.prog);
       }
-    });
-    for (BatchLane& L : lanes) launch_gicp_results(L.stream, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
+    }, finish_lane);
     HGS_TRY(close_lanes(h, lanes));
   } else {
     const NdtConsts c = ndt_consts(h->prm);
@@ -707,6 +730,10 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     const long max_rounds = (long)c.max_iterations + 4;
     std::vector<BatchLane> lanes;
     HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
+    auto finish_lane = [&](BatchLane& L) {
+      launch_ndt_results(L.stream, d_descs + L.b0, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
+      if (fit_max_range) lane_fitness(h, L, d_descs, *fit_max_range, max_blocks, qpw, nn_tile);
+    };
     for (BatchLane& L : lanes) launch_ndt_init(L.stream, st + L.b0, ang + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, c, L.B, L.prog);
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       {
@@ -717,8 +744,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
         StageTimer tm(h, HGS_STAGE_SOLVE);
         launch_ndt_solve(L.stream, d_descs + L.b0, st + L.b0, ang + L.b0, c, L.partials, max_blocks, L.B, L.prog);
       }
-    });
-    for (BatchLane& L : lanes) launch_ndt_results(L.stream, d_descs + L.b0, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
+    }, finish_lane);
     HGS_TRY(close_lanes(h, lanes));
   }
   HGS_HIP(h, hipGetLastError());
@@ -850,7 +876,7 @@ int hgs_destroy(hgs_handle* h) {
                           &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc,
                           &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist};
   for (DeviceBuffer* b : bufs) b->release();
-  for (int i = 0; i < 7; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
+  for (int i = 0; i < 3; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
   for (hipEvent_t ev : h->lane_event)
     if (ev) (void)hipEventDestroy(ev);
   for (hipStream_t ls : h->lane_stream)
@@ -1099,8 +1125,7 @@ int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_c
       return HGS_ERR_INVALID_ARGUMENT;
     }
   }
-  HGS_TRY(run_batch(h, src, guesses));
-  HGS_TRY(run_fitness(h, src, max_range));
+  HGS_TRY(run_batch(h, src, guesses, &max_range));
   std::vector<DevResult> r;
   HGS_TRY(fetch_results(h, (int)n_candidates, r));
   for (size_t i = 0; i < n_candidates; i++) to_public(r[i], (int)i, true, &out[i]);
