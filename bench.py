@@ -183,6 +183,8 @@ def main():
                 "limiter": {"FAST_GICP": "instruction issue (VALU+SALU) of the exact tree search, not HBM: see DESIGN.md section 4",
                             "FAST_VGICP": "VALU + dependent L2 round trips of the voxel hash probes, not HBM: see DESIGN.md section 4",
                             "NDT_OMP": "VALU of the per-cell float derivative terms at 2 waves/SIMD (256 VGPRs), not HBM: see DESIGN.md section 4"}[args.method],
+                "launch_config": "whole-device launches (all candidates of the rank in one launch, HIP events on the engine's stream); the timed region "
+                                 "runs the same kernels split over 4 concurrent lanes, whose launches overlap each other",
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches": launches,
                 "algorithmic_bytes_per_launch": round(units[dom] * bytes_per_unit / max(launches, 1), 1),
                 "stage_ms_per_step": {s: round(prof[s][0] / prof_steps, 3) for s in prof}}

@@ -368,6 +368,14 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
     g[0].order_lane = qpw >> 1;
     wave_walk_multi<KnnGatherLane<4>, 1>(tv, g, slot);
     g[0].lane.finish(d.pts);
+    for (int taken = 4; __ballot(active && ties > taken) != 0ull; taken += 4) {  // more than 4 at the k-th distance
+      const bool more = active && ties > taken;
+      g[0].lane.rearm_ties(more ? r2 : -1.f, more ? ties - taken : 0);
+      g[0].start(tv, q, height);
+      g[0].order_lane = qpw >> 1;
+      wave_walk_multi<KnnGatherLane<4>, 1>(tv, g, slot);
+      g[0].lane.finish(d.pts);
+    }
     const KnnGatherLane<4>& L = g[0].lane;
     s1[0] = L.s1[0], s1[1] = L.s1[1], s1[2] = L.s1[2], found = L.found;
     s2 = Sym3{L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};

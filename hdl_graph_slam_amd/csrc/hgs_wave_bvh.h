@@ -275,7 +275,9 @@ struct KnnRadiusLane {
 // lowest original indices (the order a kd-tree k-NN returns equal distances in) are remembered and added afterwards.
 // Every lane has at least one such point — its k-th neighbour — and almost never a second one, so the common
 // instantiation (TIES = 1) tracks a single minimum branch-free; TIES = 4 keeps a sorted list and is only run by waves in
-// which some lane needs more than one point at the k-th distance (duplicates / exactly equidistant points).
+// which some lane needs more than one point at the k-th distance (duplicates / exactly equidistant points); a lane that
+// needs more than four (regular grids) gets them four at a time from further walks that only look at the points at
+// exactly r2 with an original index above the last one taken (rearm_ties).
 template <int TIES>
 struct KnnGatherLane {
   float r2;       // squared distance of the k-th neighbour (-1: no query)
@@ -285,12 +287,21 @@ struct KnnGatherLane {
   double s2[6];   // sum (p - q)(p - q)^T  xx,xy,xz,yy,yz,zz
   float qx0, qy0, qz0;
   int tie_orig[TIES], tie_pos[TIES];  // ascending by original index
+  int min_orig;    // TIES > 1: only points at r2 with an original index >= min_orig are candidates
+  bool ties_only;  // TIES > 1: a further walk — the points closer than r2 have been summed already
   __device__ __forceinline__ void init(float r2_, int ties, float qx, float qy, float qz) {
-    r2 = r2_, ties_left = ties, found = 0;
+    r2 = r2_, ties_left = ties, found = 0, min_orig = 0, ties_only = false;
     s1[0] = s1[1] = s1[2] = 0.0;
 #pragma unroll
     for (int j = 0; j < 6; j++) s2[j] = 0.0;
     qx0 = qx, qy0 = qy, qz0 = qz;
+#pragma unroll
+    for (int t = 0; t < TIES; t++) tie_orig[t] = 0x7fffffff, tie_pos[t] = -1;
+  }
+  // after finish(): arm another walk for the next TIES equidistant points (r2_ < 0: this lane is complete)
+  __device__ __forceinline__ void rearm_ties(float r2_, int ties) {
+    min_orig = tie_orig[TIES - 1] + 1;
+    r2 = r2_, ties_left = ties, ties_only = true;
 #pragma unroll
     for (int t = 0; t < TIES; t++) tie_orig[t] = 0x7fffffff, tie_pos[t] = -1;
   }
@@ -302,12 +313,15 @@ struct KnnGatherLane {
     found++;
   }
   __device__ __forceinline__ void take(float dd, float px, float py, float pz, int orig, int pos) {
-    if (dd < r2) add(px, py, pz);
     if (TIES == 1) {
+      if (dd < r2) add(px, py, pz);
       const bool sw = (dd == r2) & (orig < tie_orig[0]);
       tie_orig[0] = sw ? orig : tie_orig[0], tie_pos[0] = sw ? pos : tie_pos[0];
-    } else if (__ballot(dd == r2) != 0ull) {
-      if (dd == r2) {
+      return;
+    }
+    if (!ties_only && dd < r2) add(px, py, pz);
+    if (__ballot(dd == r2) != 0ull) {
+      if (dd == r2 && orig >= min_orig) {
         int o = orig, p = pos;
 #pragma unroll
         for (int t = 0; t < TIES; t++) {

@@ -93,26 +93,51 @@ static void build_cloud(ECloud& c, const float* xyz, int n, size_t stride_floats
   c.corr.assign((size_t)c.P * kLeaf, -1);
 }
 
+// Models k_knn_cov's two passes per query: (1) r2 = distance of the k-th neighbour and how many points at exactly r2
+// belong to the k nearest; (2) every point closer than r2 plus that many points at r2, lowest original index first.
 template <int KMAX>
 static void knn_cov_t(ECloud& c, int k) {
   c.cov.assign((size_t)2 * c.P * kLeaf, Float4{0, 0, 0, 0});
   const BvhView tv = c.view();
+  std::vector<std::pair<int, int>> tied;  // (original index, position)
   for (int i = 0; i < c.nvalid; i++) {
     const Float4 qp = c.pts[i];
     const F3 q = {qp.x, qp.y, qp.z};
     KnnList<KMAX> list;
     bvh_knn<KMAX>(tv, q, k, list);
+    const float r2 = list.worst();
+    int n_lt = 0, live = 0;
+    for (int j = 0; j < KMAX; j++) live += list.d[j] >= 0.f ? 1 : 0, n_lt += (list.d[j] >= 0.f && list.d[j] < r2) ? 1 : 0;
+    const int ties = live - n_lt;
     double s1[3] = {0, 0, 0};
     Sym3 s2 = {0, 0, 0, 0, 0, 0};
     int found = 0;
-    for (int j = 0; j < KMAX; j++)
-      if (list.pos[j] >= 0) {
-        const Float4 p = c.pts[list.pos[j]];
-        const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
-        s1[0] += dx, s1[1] += dy, s1[2] += dz;
-        s2.xx += dx * dx, s2.xy += dx * dy, s2.xz += dx * dz, s2.yy += dy * dy, s2.yz += dy * dz, s2.zz += dz * dz;
-        found++;
+    auto add = [&](const Float4& p) {
+      const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
+      s1[0] += dx, s1[1] += dy, s1[2] += dz;
+      s2.xx += dx * dx, s2.xy += dx * dy, s2.xz += dx * dz, s2.yy += dy * dy, s2.yz += dy * dz, s2.zz += dz * dz;
+      found++;
+    };
+    tied.clear();
+    std::vector<uint32_t> stack{1u};
+    while (!stack.empty()) {
+      const uint32_t node = stack.back();
+      stack.pop_back();
+      if (!(bvh_box_dist2(tv.nodes, node, q) <= r2)) continue;
+      if ((int)node < tv.P) {
+        stack.push_back(2 * node + 1), stack.push_back(2 * node);
+        continue;
       }
+      const int base = ((int)node - tv.P) * kLeaf;
+      for (int l = 0; l < kLeaf; l++) {
+        const Float4 p = tv.pts[base + l];
+        const float d = dist2f(q, p.x, p.y, p.z);
+        if (d < r2) add(p);
+        else if (d == r2) tied.emplace_back(float_as_int_hd(p.w), base + l);
+      }
+    }
+    std::sort(tied.begin(), tied.end());
+    for (int t = 0; t < ties && t < (int)tied.size(); t++) add(tv.pts[tied[t].second]);
     const Sym3 cv = gicp_regularized_cov(s1, s2, found, k);
     c.cov[2 * i] = Float4{(float)cv.xx, (float)cv.xy, (float)cv.xz, (float)cv.yy};
     c.cov[2 * i + 1] = Float4{(float)cv.yz, (float)cv.zz, 0, 0};

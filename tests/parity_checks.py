@@ -93,3 +93,19 @@ def check_ndt_derivatives(engine, oracle, p6, rel=2e-5):
     assert abs(se - so) <= rel * abs(so)
     assert np.abs(ge - go).max() <= rel * np.abs(go).max()
     assert np.abs(He - Ho).max() <= rel * np.abs(Ho).max()
+
+
+def tie_heavy_cloud(seed: int = 0) -> np.ndarray:
+    """Exactly equidistant neighbours at every rank of the k-NN: a regular 0.25 m grid plane (for k = 20 the k-th distance
+    is shared by 8 points of which 7 belong to the 20 nearest), the same plane once more (every point duplicated), a
+    3-fold duplicated lattice block, vertical collinear runs, plus ordinary random points; shuffled."""
+    rng = np.random.default_rng(seed)
+    g = np.stack(np.meshgrid(np.arange(-4, 4, 0.25, dtype=np.float32), np.arange(-4, 4, 0.25, dtype=np.float32)), -1).reshape(-1, 2)
+    single = np.concatenate([g + np.float32([20.0, 0.0]), np.full((len(g), 1), 0.5, np.float32)], 1)
+    double = np.concatenate([g, np.full((len(g), 1), 0.5, np.float32)], 1)
+    lat = np.stack(np.meshgrid(*[np.arange(0, 2, 0.5, dtype=np.float32)] * 3), -1).reshape(-1, 3) + np.float32([-20.0, 5.0, 0.0])
+    t = np.linspace(0, 1, 40, dtype=np.float32)[:, None]
+    lines = np.concatenate([np.float32([x0, y0, -1.0]) + t * np.float32([0.0, 0.0, 2.5]) for x0, y0 in rng.uniform(-15, 15, (20, 2)).astype(np.float32)])
+    rnd = rng.normal(0, 6, (3000, 3)).astype(np.float32)
+    out = np.concatenate([single, double, double, lat, lat, lat, lines.astype(np.float32), rnd])
+    return synth.to_xyzi(out[rng.permutation(len(out))])

@@ -46,6 +46,17 @@ def test_covariances(gicp_case):
     PC.check_covariances(e, tgt)
 
 
+def test_covariances_with_equidistant_neighbours():
+    """Ties at the k-th distance go to the lowest original indices, however many of them there are."""
+    cloud = PC.tie_heavy_cloud()
+    for k in (20, 10):
+        p = O.default_params(O.HGS_FAST_GICP)
+        p.correspondence_randomness = k
+        e = emul.EmulRegistration(p)
+        e.setInputTarget(cloud)
+        PC.check_covariances(e, cloud, k)
+
+
 def test_gicp_linearize(gicp_case):
     e, o, tgt, src, T = gicp_case
     PC.check_gicp_linearize(e, o, T.astype(np.float32).astype(np.float64))

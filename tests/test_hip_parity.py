@@ -56,6 +56,19 @@ def test_covariances(gicp_case):
     PC.check_covariances(e, tgt)
 
 
+def test_covariances_with_equidistant_neighbours():
+    """Regular grids and duplicated points: the k-th distance is shared by up to 8 points of which up to 7 belong to the k
+    nearest; the set the covariance is summed over must be the oracle's (ties -> lowest original index)."""
+    cloud = PC.tie_heavy_cloud()
+    for k in (20, 10):
+        p = O.default_params(O.HGS_FAST_GICP)
+        p.correspondence_randomness = k
+        e = _hip(p)
+        e.setInputTarget(cloud)
+        PC.check_covariances(e, cloud, k)
+        e.close()
+
+
 def test_gicp_linearize(gicp_case):
     e, o, tgt, src, T = gicp_case
     PC.check_gicp_linearize(e, o, T.astype(np.float32).astype(np.float64))
