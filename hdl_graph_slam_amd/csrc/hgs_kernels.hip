@@ -802,6 +802,27 @@ void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView
   hipLaunchKernelGGL(k_ndt_derivatives, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, angles, c, partials, max_blocks);
 }
 
+// SVD-solve(A, b) by the calling wave: the three rotations of a Jacobi round on lanes 0..2, U and V (36 doubles each) in
+// LDS.  Same arithmetic and the same pair order as solve_svd6 (hgs_math.h) => same bits; x is valid on lane 0.
+// LDS accesses of one wave are performed in program order, and the volatile qualifier keeps the compiler from caching a
+// column across rounds, so a lane reads the columns the other lanes rotated in the round before without a barrier.
+__device__ __forceinline__ void solve_svd6_wave(const double* A, const double* b, volatile double* U, volatile double* V, double* x) {
+  const int lane = (int)(threadIdx.x & 63);
+  if (lane < 36) U[lane] = A[lane], V[lane] = (lane % 7 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    bool rotated = false;
+    for (int round = 0; round < 5; round++) {
+      if (lane < 3) {
+        int p, q;
+        svd6_pair(round, lane, &p, &q);
+        if (svd6_rotate<volatile double*>(U, V, p, q)) rotated = true;
+      }
+    }
+    if (__ballot(rotated) == 0ull) break;
+  }
+  if (lane == 0) svd6_backsolve<volatile double*>(U, V, b, x);
+}
+
 __global__ __launch_bounds__(kNdtSolveBlock) void k_ndt_solve(const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c,
                                                      const double* __restrict__ partials, int max_blocks, Progress prog) {
   const int b = blockIdx.x;
@@ -814,8 +835,15 @@ __global__ __launch_bounds__(kNdtSolveBlock) void k_ndt_solve(const CloudDesc* d
   __shared__ double scratch[kNdtSolveBlock];
   const int ntiles = (descs[b].n_input + kBlock - 1) / kBlock;
   reduce_tiles<kAccNdt, kNdtSolveBlock>(partials + (size_t)b * max_blocks * kAccNdt, ntiles, acc, scratch);
+  if (threadIdx.x >= 64) return;
+  double dp_newton[6] = {0, 0, 0, 0, 0, 0};
+  if (!ndt_pass_is_last(st, c)) {  // wave-uniform
+    double ng[6];
+    for (int i = 0; i < 6; i++) ng[i] = -acc[36 + i];
+    solve_svd6_wave(acc, ng, scratch, scratch + 36, dp_newton);
+  }
   if (threadIdx.x == 0) {
-    ndt_after_derivatives(st, acc, c);
+    ndt_after_derivatives(st, acc, c, dp_newton);
     if (c.pad)  // HGS_TRACE=1: per-iteration trace for parity debugging
       printf("hgs ndt b=%d it=%d passes=%d p=%.9f %.9f %.9f %.9f %.9f %.9f score=%.9f a_t=%.9f phase=%d\n", b, st.iterations, st.passes, st.p[0], st.p[1],
              st.p[2], st.p[3], st.p[4], st.p[5], st.score, st.a_t, st.phase);

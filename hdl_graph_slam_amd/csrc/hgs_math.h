@@ -226,36 +226,52 @@ HGS_HD void solve_ldlt6(const double* A_in, const double* b_in, double* x) {
 
 // x = pinv(A) b via one-sided Jacobi SVD, singular values <= 6 eps sigma_max dropped (role of Eigen::JacobiSVD
 // .solve in ndt_omp's Newton step).
-HGS_HD void solve_svd6(const double* A, const double* b, double* x) {
+//
+// The 15 column pairs of a sweep are visited as a round-robin tournament, 5 rounds of 3 disjoint pairs:
+//   (0,5)(1,4)(2,3) | (0,4)(3,5)(1,2) | (0,3)(2,4)(1,5) | (0,2)(1,3)(4,5) | (0,1)(2,5)(3,4)
+// Rotations of disjoint pairs touch disjoint columns, so the three of a round commute exactly: this serial code (host,
+// tests/emul; the oracle uses the same order) and the device version that runs a round on three lanes (hgs_kernels.hip,
+// solve_svd6_wave) produce the same bits.  The rotation chain (3 divisions + 2 square roots in fp64) is the latency of
+// ndt_omp's per-iteration solve; in lock-step it is paid 5 instead of 15 times per sweep.
+HGS_HD void svd6_pair(int round, int j, int* p, int* q) {
+  const int t = round * 3 + j;
+  // packed (p << 4 | q), 15 entries
+  const unsigned char pq = t == 0 ? 0x05 : t == 1 ? 0x14 : t == 2 ? 0x23 : t == 3 ? 0x04 : t == 4 ? 0x35 : t == 5 ? 0x12 : t == 6 ? 0x03 : t == 7 ? 0x24
+                         : t == 8 ? 0x15 : t == 9 ? 0x02 : t == 10 ? 0x13 : t == 11 ? 0x45 : t == 12 ? 0x01 : t == 13 ? 0x25 : 0x34;
+  *p = pq >> 4, *q = pq & 15;
+}
+
+// One Hestenes rotation of columns p < q of U (and V); false if the pair is already orthogonal to working precision.
+// P is `double*` (local arrays on the host) or `volatile double*` (LDS shared by the lanes of a wave on the device).
+template <typename P>
+HGS_HD bool svd6_rotate(P U, P V, int p, int q) {
   HGS_FP_STRICT
-  double U[36], V[36];
-  for (int i = 0; i < 36; i++) U[i] = A[i], V[i] = (i % 7 == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; sweep++) {
-    bool rotated = false;
-    for (int p = 0; p < 5; p++)
-      for (int q = p + 1; q < 6; q++) {
-        double alpha = 0, beta = 0, gamma = 0;
-        for (int k = 0; k < 6; k++) {
-          alpha += U[k * 6 + p] * U[k * 6 + p];
-          beta += U[k * 6 + q] * U[k * 6 + q];
-          gamma += U[k * 6 + p] * U[k * 6 + q];
-        }
-        if (gamma == 0.0 || fabs(gamma) <= DBL_EPSILON * sqrt(alpha * beta)) continue;
-        rotated = true;
-        const double zeta = (beta - alpha) / (2.0 * gamma);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-        for (int k = 0; k < 6; k++) {
-          const double up = U[k * 6 + p], uq = U[k * 6 + q];
-          U[k * 6 + p] = c * up - s * uq;
-          U[k * 6 + q] = s * up + c * uq;
-          const double vp = V[k * 6 + p], vq = V[k * 6 + q];
-          V[k * 6 + p] = c * vp - s * vq;
-          V[k * 6 + q] = s * vp + c * vq;
-        }
-      }
-    if (!rotated) break;
+  double up[6], uq[6];
+  for (int k = 0; k < 6; k++) up[k] = U[k * 6 + p], uq[k] = U[k * 6 + q];
+  double alpha = 0, beta = 0, gamma = 0;
+  for (int k = 0; k < 6; k++) {
+    alpha += up[k] * up[k];
+    beta += uq[k] * uq[k];
+    gamma += up[k] * uq[k];
   }
+  if (gamma == 0.0 || fabs(gamma) <= DBL_EPSILON * sqrt(alpha * beta)) return false;
+  const double zeta = (beta - alpha) / (2.0 * gamma);
+  const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+  for (int k = 0; k < 6; k++) {
+    U[k * 6 + p] = c * up[k] - s * uq[k];
+    U[k * 6 + q] = s * up[k] + c * uq[k];
+    const double vp = V[k * 6 + p], vq = V[k * 6 + q];
+    V[k * 6 + p] = c * vp - s * vq;
+    V[k * 6 + q] = s * vp + c * vq;
+  }
+  return true;
+}
+
+// x = V diag(1/sigma_j) U_j^T b over the singular values above the threshold (U holds A V = U_unit * sigma).
+template <typename P>
+HGS_HD void svd6_backsolve(P U, P V, const double* b, double* x) {
+  HGS_FP_STRICT
   double sig2[6], smax2 = 0;
   for (int j = 0; j < 6; j++) {
     double s = 0;
@@ -273,6 +289,22 @@ HGS_HD void solve_svd6(const double* A, const double* b, double* x) {
     const double coef = ub / sig2[j];
     for (int k = 0; k < 6; k++) x[k] += coef * V[k * 6 + j];
   }
+}
+
+HGS_HD void solve_svd6(const double* A, const double* b, double* x) {
+  double U[36], V[36];
+  for (int i = 0; i < 36; i++) U[i] = A[i], V[i] = (i % 7 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    bool rotated = false;
+    for (int round = 0; round < 5; round++)
+      for (int j = 0; j < 3; j++) {
+        int p, q;
+        svd6_pair(round, j, &p, &q);
+        if (svd6_rotate<double*>(U, V, p, q)) rotated = true;
+      }
+    if (!rotated) break;
+  }
+  svd6_backsolve<const double*>(U, V, b, x);
 }
 
 // ---- symmetric 3x3 eigen decomposition (cyclic Jacobi), eigenvalues ascending, eigenvectors in columns of V ----

@@ -290,11 +290,17 @@ HGS_HD void ndt_state_init(NdtState& s, const float* guess_colmajor) {
   s.iterations = 0, s.passes = 0, s.converged = 0, s.first = 1, s.pad = 0;
 }
 
+// True if the pass that has just been reduced completes the final iteration (no Newton direction is needed any more).
+HGS_HD bool ndt_pass_is_last(const NdtState& s, const NdtConsts& c) {
+  return !s.first && ((s.iterations > c.max_iterations) || (s.iterations && fabs(s.a_t) < c.trans_eps));
+}
+
 // Consumes the reduced {H, g, score} of a derivative pass evaluated at s.p and prepares the next evaluation point.
-HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConsts& c) {
+// dp_newton = SVD-solve(H, -g) of this pass (unused if ndt_pass_is_last): computed by the caller because the device runs it
+// on three lanes (solve_svd6_wave) while this control path is one thread's.
+HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConsts& c, const double* dp_newton) {
   HGS_FP_STRICT
-  double H[36], g[6];
-  for (int i = 0; i < 36; i++) H[i] = acc[i];
+  double g[6];
   for (int i = 0; i < 6; i++) g[i] = acc[36 + i];
   s.score = acc[42];
   s.passes++;
@@ -313,9 +319,8 @@ HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConst
   s.first = 0;
   for (;;) {
     // Newton direction: dp = SVD-solve(H, -g)
-    double ng[6], dp[6];
-    for (int i = 0; i < 6; i++) ng[i] = -g[i];
-    solve_svd6(H, ng, dp);
+    double dp[6];
+    for (int i = 0; i < 6; i++) dp[i] = dp_newton[i];
     double nrm = 0;
     for (int i = 0; i < 6; i++) nrm += dp[i] * dp[i];
     nrm = sqrt(nrm);
@@ -352,6 +357,14 @@ HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConst
     s.phase = NDT_DERIV;
     return;
   }
+}
+
+// Serial form (host execution in tests/emul).
+HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConsts& c) {
+  double ng[6], dp[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 6; i++) ng[i] = -acc[36 + i];
+  if (!ndt_pass_is_last(s, c)) solve_svd6(acc, ng, dp);
+  ndt_after_derivatives(s, acc, c, dp);
 }
 
 }  // namespace hgs

@@ -221,8 +221,12 @@ inline V6 solve_svd6(const M6& A, const V6& b) {
     for (int j = 0; j < 6; j++) U[i][j] = A.m[i][j], V[i][j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; sweep++) {
     bool rotated = false;
-    for (int p = 0; p < 5; p++)
-      for (int q = p + 1; q < 6; q++) {
+    // pair order: a round-robin tournament (5 rounds of 3 disjoint pairs) instead of the row-cyclic order — any order that
+    // visits every pair once per sweep is a valid Jacobi sweep; this one lets the device run a round's three rotations in
+    // lock-step (they commute exactly), see hgs_math.h
+    static const int kPairs[15][2] = {{0, 5}, {1, 4}, {2, 3}, {0, 4}, {3, 5}, {1, 2}, {0, 3}, {2, 4}, {1, 5}, {0, 2}, {1, 3}, {4, 5}, {0, 1}, {2, 5}, {3, 4}};
+    for (int pi = 0; pi < 15; pi++) {
+        const int p = kPairs[pi][0], q = kPairs[pi][1];
         double alpha = 0, beta = 0, gamma = 0;
         for (int k = 0; k < 6; k++) alpha += U[k][p] * U[k][p], beta += U[k][q] * U[k][q], gamma += U[k][p] * U[k][q];
         if (gamma == 0.0 || std::fabs(gamma) <= DBL_EPSILON * std::sqrt(alpha * beta)) continue;
