@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhgs_hip.so")
 HGS_OK = 0
 HGS_FAST_GICP, HGS_FAST_VGICP, HGS_NDT_OMP = 0, 1, 2
 HGS_KDTREE, HGS_DIRECT1, HGS_DIRECT7, HGS_DIRECT27 = 0, 1, 2, 3
+HGS_REG_FROBENIUS, HGS_REG_PLANE, HGS_REG_MIN_EIG, HGS_REG_NORMALIZED_MIN_EIG, HGS_REG_NONE = 0, 1, 2, 3, 4
 STAGES = ["upload", "index", "covariance", "voxelize", "linearize", "error", "solve", "fitness", "prefilter"]
 DBL_MAX = float(np.finfo(np.float64).max)
 
@@ -30,7 +31,7 @@ class HgsParams(C.Structure):
         ("resolution", C.c_double), ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double),
         ("ndt_min_points_per_voxel", C.c_int32), ("ndt_upstream_hd1_sign", C.c_int32),
         ("lm_max_iterations", C.c_int32), ("lm_init_lambda_factor", C.c_double),
-        ("device_id", C.c_int32), ("reserved", C.c_int32),
+        ("device_id", C.c_int32), ("regularization_method", C.c_int32),
     ]
 
 

@@ -347,11 +347,15 @@ int ensure_index(hgs_handle* h, const std::vector<hgs_cloud*>& all) {
   return HGS_OK;
 }
 
+// what a cloud's cached covariances depend on besides its points
+int cov_cache_key(const hgs_handle* h, int k) { return k | (h->prm.regularization_method << 16); }
+
 int ensure_cov(hgs_handle* h, const std::vector<hgs_cloud*>& all, int k) {
   HGS_TRY(ensure_index(h, all));
+  const int key = cov_cache_key(h, k);
   std::vector<hgs_cloud*> todo;
   for (hgs_cloud* c : all)
-    if ((!c->has_cov || c->cov_k != k) && std::find(todo.begin(), todo.end(), c) == todo.end()) todo.push_back(c);
+    if ((!c->has_cov || c->cov_k != key) && std::find(todo.begin(), todo.end(), c) == todo.end()) todo.push_back(c);
   if (todo.empty()) return HGS_OK;
   StageTimer tm(h, HGS_STAGE_COVARIANCE);
   const CloudDesc* d_descs = nullptr;
@@ -360,10 +364,11 @@ int ensure_cov(hgs_handle* h, const std::vector<hgs_cloud*>& all, int k) {
   for (hgs_cloud* c : todo) max_n = std::max(max_n, (int)c->n_input);
   size_t total_q = 0;
   for (hgs_cloud* c : todo) total_q += c->n_input;
-  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, queries_per_wave(total_q, 32));  // >= k points in the pre-fill window
+  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, queries_per_wave(total_q, 32),  // >= k points in the pre-fill window
+                 h->prm.regularization_method);
   HGS_HIP(h, hipGetLastError());
   HGS_HIP(h, hipStreamSynchronize(h->stream));
-  for (hgs_cloud* c : todo) c->has_cov = true, c->cov_k = k;
+  for (hgs_cloud* c : todo) c->has_cov = true, c->cov_k = key;
   return HGS_OK;
 }
 
@@ -424,7 +429,7 @@ int ensure_ndt_target(hgs_handle* h, hgs_cloud* c) {
 int ensure_vgicp_target(hgs_handle* h, hgs_cloud* c) {
   const double res = h->prm.resolution;
   const int k = h->prm.correspondence_randomness;
-  if (c->has_vg && c->vg_resolution == res && c->vg_cov_k == k) return HGS_OK;
+  if (c->has_vg && c->vg_resolution == res && c->vg_cov_k == cov_cache_key(h, k)) return HGS_OK;
   StageTimer tm(h, HGS_STAGE_VOXELIZE);
   const size_t n = c->n_input;
   const int max_cells = (int)n + 1;
@@ -468,7 +473,7 @@ int ensure_vgicp_target(hgs_handle* h, hgs_cloud* c) {
   HGS_HIP(h, hipGetLastError());
   c->has_vg = true;
   c->vg_resolution = res;
-  c->vg_cov_k = k;
+  c->vg_cov_k = cov_cache_key(h, k);
   return HGS_OK;
 }
 
@@ -833,13 +838,15 @@ int hgs_params_default(int32_t method, hgs_params* p) {
   p->lm_max_iterations = 10;
   p->lm_init_lambda_factor = 1e-9;
   p->device_id = 0;
+  p->regularization_method = HGS_REG_FROBENIUS;  // fast_gicp constructor default; hdl never calls the setter
   return HGS_OK;
 }
 
 int hgs_create(const hgs_params* p, hgs_handle** out) {
   if (!p || !out) return HGS_ERR_INVALID_ARGUMENT;
   *out = nullptr;
-  if (p->method < HGS_FAST_GICP || p->method > HGS_NDT_OMP || p->max_iterations < 0 || p->correspondence_randomness < 1 || !(p->resolution > 0)) {
+  if (p->method < HGS_FAST_GICP || p->method > HGS_NDT_OMP || p->max_iterations < 0 || p->correspondence_randomness < 1 || !(p->resolution > 0) ||
+      p->regularization_method < HGS_REG_FROBENIUS || p->regularization_method > HGS_REG_NONE) {
     g_create_error = "invalid hgs_params";
     return HGS_ERR_INVALID_ARGUMENT;
   }

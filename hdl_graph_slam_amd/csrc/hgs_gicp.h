@@ -23,21 +23,53 @@ struct GicpConsts {
 // Regularised covariance of one point from its k nearest neighbours (fast_gicp calculate_covariances, FROBENIUS):
 //   C = sum (p-mean)(p-mean)^T / k ; C' = ||(C + 1e-3 I)^-1||_F * (C + 1e-3 I)   (== ((C+1e-3I)^-1 / ||.||_F)^-1)
 // s1 = sum (p - q), s2 = sum (p - q)(p - q)^T over the `found` neighbours (shifted by the query for conditioning).
-HGS_HD Sym3 gicp_regularized_cov(const double* s1, const Sym3& s2, int found, int k) {
+HGS_HD Sym3 gicp_neighbour_cov(const double* s1, const Sym3& s2, int found, int k, double lambda) {
   const double inv_f = 1.0 / (double)found, inv_k = 1.0 / (double)k;
   const double mx = s1[0] * inv_f, my = s1[1] * inv_f, mz = s1[2] * inv_f;
   // sum (d-m)(d-m)^T = s2 - found * m m^T
   Sym3 c;
-  c.xx = (s2.xx - found * mx * mx) * inv_k + 1e-3;
+  c.xx = (s2.xx - found * mx * mx) * inv_k + lambda;
   c.xy = (s2.xy - found * mx * my) * inv_k;
   c.xz = (s2.xz - found * mx * mz) * inv_k;
-  c.yy = (s2.yy - found * my * my) * inv_k + 1e-3;
+  c.yy = (s2.yy - found * my * my) * inv_k + lambda;
   c.yz = (s2.yz - found * my * mz) * inv_k;
-  c.zz = (s2.zz - found * mz * mz) * inv_k + 1e-3;
+  c.zz = (s2.zz - found * mz * mz) * inv_k + lambda;
+  return c;
+}
+HGS_HD Sym3 gicp_regularized_cov(const double* s1, const Sym3& s2, int found, int k) {
+  const Sym3 c = gicp_neighbour_cov(s1, s2, found, k, 1e-3);
   const Sym3 ci = sym3_inverse(c);
   const double f = sqrt(ci.xx * ci.xx + ci.yy * ci.yy + ci.zz * ci.zz + 2.0 * (ci.xy * ci.xy + ci.xz * ci.xz + ci.yz * ci.yz));
   Sym3 o;
   o.xx = f * c.xx, o.xy = f * c.xy, o.xz = f * c.xz, o.yy = f * c.yy, o.yz = f * c.yz, o.zz = f * c.zz;
+  return o;
+}
+// The other fast_gicp::RegularizationMethod values (method = hgs_regularization): NONE keeps C; PLANE / MIN_EIG /
+// NORMALIZED_MIN_EIG replace the singular values of C (JacobiSVD upstream; C is symmetric positive semi-definite, so U = V
+// = its eigenvectors and the singular values are its eigenvalues) by (1, 1, 1e-3) in descending order / max(sigma, 1e-3) /
+// max(sigma / sigma_max, 1e-3) and rebuild U diag(values) V^T.
+HGS_HD Sym3 gicp_regularized_cov(const double* s1, const Sym3& s2, int found, int k, int method) {
+  if (method == 0) return gicp_regularized_cov(s1, s2, found, k);
+  const Sym3 c = gicp_neighbour_cov(s1, s2, found, k, 0.0);
+  if (method == 4) return c;
+  const double A[9] = {c.xx, c.xy, c.xz, c.xy, c.yy, c.yz, c.xz, c.yz, c.zz};
+  double w[3], V[9];
+  eig_sym3(A, w, V);  // ascending
+  double v[3];
+  if (method == 1) {
+    v[0] = 1e-3, v[1] = 1.0, v[2] = 1.0;
+  } else {
+    const double scale = method == 3 ? w[2] : 1.0;
+    for (int i = 0; i < 3; i++) {
+      const double sv = fabs(w[i]) / scale;  // a singular value
+      v[i] = sv > 1e-3 ? sv : 1e-3;
+    }
+  }
+  Sym3 o = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 3; i++) {
+    const double x = V[0 * 3 + i], y = V[1 * 3 + i], z = V[2 * 3 + i];
+    o.xx += v[i] * x * x, o.xy += v[i] * x * y, o.xz += v[i] * x * z, o.yy += v[i] * y * y, o.yz += v[i] * y * z, o.zz += v[i] * z * z;
+  }
   return o;
 }
 

@@ -300,8 +300,10 @@ void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 // Algorithmic bytes per point: 16 (query) + k*16 (neighbours) + 24 (cov).
 // qpw = queries per wave (64, or fewer — a multiple of 8 — when the whole launch is too small to fill the chip: shorter
 // packets walk fewer nodes, so the dependent-load chain that bounds a small launch gets shorter; lanes >= qpw idle).
-template <int KMAX>
-__global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int k, int qpw) {
+// REG_GENERAL = false: FROBENIUS (the mode hdl_graph_slam runs); true: any hgs_regularization (3x3 eigen-decomposition per
+// point), a separate instantiation so that the default kernel carries none of it.
+template <int KMAX, bool REG_GENERAL>
+__global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int k, int qpw, int reg_method) {
   const CloudDesc d = descs[blockIdx.y];
   const int n = d.meta->nvalid;
   const int tile_pts = (kBlock / 64) * qpw;
@@ -381,19 +383,24 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
     s2 = Sym3{L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
   }
   if (!active) return;
-  const Sym3 c = gicp_regularized_cov(s1, s2, found, k);
+  const Sym3 c = REG_GENERAL ? gicp_regularized_cov(s1, s2, found, k, reg_method) : gicp_regularized_cov(s1, s2, found, k);
   d.cov[2 * i] = make_float4((float)c.xx, (float)c.xy, (float)c.xz, (float)c.yy);
   d.cov[2 * i + 1] = make_float4((float)c.yz, (float)c.zz, 0.f, 0.f);
 }
-void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw) {
-  if (max_n <= 0) return;
+template <bool REG_GENERAL>
+static void launch_knn_cov_t(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method) {
   const int tile_pts = (kBlock / 64) * qpw;
   const dim3 grid((max_n + tile_pts - 1) / tile_pts, ncloud), block(kBlock);
-  if (k <= 8) hipLaunchKernelGGL(k_knn_cov<8>, grid, block, 0, s, descs, k, qpw);
-  else if (k <= 16) hipLaunchKernelGGL(k_knn_cov<16>, grid, block, 0, s, descs, k, qpw);
-  else if (k <= 20) hipLaunchKernelGGL(k_knn_cov<20>, grid, block, 0, s, descs, k, qpw);
-  else if (k <= 32) hipLaunchKernelGGL(k_knn_cov<32>, grid, block, 0, s, descs, k, qpw);
-  else hipLaunchKernelGGL(k_knn_cov<64>, grid, block, 0, s, descs, k < 64 ? k : 64, qpw);
+  if (k <= 8) hipLaunchKernelGGL((k_knn_cov<8, REG_GENERAL>), grid, block, 0, s, descs, k, qpw, reg_method);
+  else if (k <= 16) hipLaunchKernelGGL((k_knn_cov<16, REG_GENERAL>), grid, block, 0, s, descs, k, qpw, reg_method);
+  else if (k <= 20) hipLaunchKernelGGL((k_knn_cov<20, REG_GENERAL>), grid, block, 0, s, descs, k, qpw, reg_method);
+  else if (k <= 32) hipLaunchKernelGGL((k_knn_cov<32, REG_GENERAL>), grid, block, 0, s, descs, k, qpw, reg_method);
+  else hipLaunchKernelGGL((k_knn_cov<64, REG_GENERAL>), grid, block, 0, s, descs, k < 64 ? k : 64, qpw, reg_method);
+}
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method) {
+  if (max_n <= 0) return;
+  if (reg_method == 0) launch_knn_cov_t<false>(s, descs, ncloud, max_n, k, qpw, reg_method);
+  else launch_knn_cov_t<true>(s, descs, ncloud, max_n, k, qpw, reg_method);
 }
 
 // ------------------------------------------------------------------------------------------------ GICP iteration

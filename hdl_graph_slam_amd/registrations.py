@@ -14,6 +14,20 @@ from .registration import RegistrationHIP
 _CPU_ONLY = ("ICP", "GICP", "GICP_OMP", "NDT")
 
 
+_REGULARIZATION = {"FROBENIUS": L.HGS_REG_FROBENIUS, "PLANE": L.HGS_REG_PLANE, "MIN_EIG": L.HGS_REG_MIN_EIG,
+                   "NORMALIZED_MIN_EIG": L.HGS_REG_NORMALIZED_MIN_EIG, "NONE": L.HGS_REG_NONE}
+
+
+def _regularization(pnh) -> int:
+    """Not a rosparam of the reference: registrations.cpp never calls fast_gicp's setRegularizationMethod, so the fast_gicp
+    constructor default applies (FROBENIUS).  `reg_regularization_method` lets a deployment whose fast_gicp
+    checkout defaults to another method (PLANE) match it without recompiling."""
+    name = str(pnh.get("reg_regularization_method", "FROBENIUS")).upper()
+    if name not in _REGULARIZATION:
+        raise ValueError(f"reg_regularization_method={name}: expected one of {sorted(_REGULARIZATION)}")
+    return _REGULARIZATION[name]
+
+
 def params_from_rosparams(pnh) -> L.HgsParams:
     get = pnh.get
     method = str(get("registration_method", "NDT_OMP"))                            # registrations.cpp:26
@@ -23,6 +37,7 @@ def params_from_rosparams(pnh) -> L.HgsParams:
         p.max_iterations = int(get("reg_maximum_iterations", 64))
         p.max_correspondence_distance = float(get("reg_max_correspondence_distance", 2.5))
         p.correspondence_randomness = int(get("reg_correspondence_randomness", 20))
+        p.regularization_method = _regularization(pnh)
         return p
     if method in ("FAST_VGICP", "FAST_VGICP_CUDA", "FAST_VGICP_HIP"):              # registrations.cpp:37-56
         p = L.default_params(L.HGS_FAST_VGICP)
@@ -30,6 +45,7 @@ def params_from_rosparams(pnh) -> L.HgsParams:
         p.transformation_epsilon = float(get("reg_transformation_epsilon", 0.01))
         p.max_iterations = int(get("reg_maximum_iterations", 64))
         p.correspondence_randomness = int(get("reg_correspondence_randomness", 20))
+        p.regularization_method = _regularization(pnh)
         return p
     if method in _CPU_ONLY:
         raise NotImplementedError(f"registration_method={method} stays on the reference's CPU engine (pcl / pclomp); "

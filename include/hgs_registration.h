@@ -53,6 +53,17 @@ enum hgs_neighbor_search {
   HGS_DIRECT27 = 3
 };
 
+/* fast_gicp::RegularizationMethod of the k-NN covariances (FastGICP / FastVGICP::setRegularizationMethod).  hdl_graph_slam
+ * never calls the setter, so the constructor default of the fast_gicp checkout applies: FROBENIUS per SURVEY.md A.2; a
+ * checkout whose FastGICP constructor selects PLANE is matched by setting HGS_REG_PLANE. */
+enum hgs_regularization {
+  HGS_REG_FROBENIUS = 0,          /* ((C + 1e-3 I)^-1 / ||.||_F)^-1                         */
+  HGS_REG_PLANE = 1,              /* U diag(1, 1, 1e-3) V^T                                 */
+  HGS_REG_MIN_EIG = 2,            /* U diag(max(sigma_i, 1e-3)) V^T                         */
+  HGS_REG_NORMALIZED_MIN_EIG = 3, /* U diag(max(sigma_i / sigma_max, 1e-3)) V^T             */
+  HGS_REG_NONE = 4                /* C itself                                               */
+};
+
 typedef struct hgs_params {
   int32_t method;                     /* hgs_method                                                        */
   int32_t max_iterations;             /* reg_maximum_iterations           (64)                             */
@@ -69,7 +80,7 @@ typedef struct hgs_params {
   int32_t lm_max_iterations;          /* fast_gicp LM inner tries         (10)                             */
   double lm_init_lambda_factor;       /* fast_gicp                        (1e-9)                           */
   int32_t device_id;                  /* HIP device ordinal                                                */
-  int32_t reserved;
+  int32_t regularization_method;      /* hgs_regularization               (FROBENIUS), FAST_GICP / FAST_VGICP  */
 } hgs_params;
 
 typedef struct hgs_result {

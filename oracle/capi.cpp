@@ -134,10 +134,10 @@ int hgso_knn(const void* pts, size_t n, size_t stride, const void* queries, size
 }
 
 // GICP covariances of a cloud: out_cov[n][6] = xx,xy,xz,yy,yz,zz (double), rows for non-finite points are 0
-int hgso_covariances(const void* pts, size_t n, size_t stride, int k, double* out_cov6) {
+int hgso_covariances(const void* pts, size_t n, size_t stride, int k, int method, double* out_cov6) {
   OCloud c;
   c.assign(pts, n, stride);
-  calculate_covariances(c, k);
+  calculate_covariances(c, k, method);
   for (size_t i = 0; i < n * 6; i++) out_cov6[i] = 0;
   for (size_t i = 0; i < c.pts.size(); i++) {
     double* o = out_cov6 + (size_t)c.orig[i] * 6;

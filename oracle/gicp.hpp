@@ -62,8 +62,10 @@ struct OCloud {
   }
 };
 
-// fast_gicp::FastGICP::calculate_covariances (FROBENIUS mode).
-inline void calculate_covariances(OCloud& c, int k) {
+// fast_gicp::FastGICP::calculate_covariances.  `method` = hgs_regularization (fast_gicp::RegularizationMethod):
+// FROBENIUS ((C + 1e-3 I)^-1 / ||.||_F)^-1 ; NONE ; PLANE / MIN_EIG / NORMALIZED_MIN_EIG rebuild U diag(values) V^T from
+// the JacobiSVD of C — C is symmetric positive semi-definite, so its SVD is its eigen-decomposition (U = V).
+inline void calculate_covariances(OCloud& c, int k, int method = HGS_REG_FROBENIUS) {
   const int n = (int)c.pts.size();
   c.covs.assign(n, M3::zero());
 #pragma omp parallel for schedule(guided, 8)
@@ -85,9 +87,29 @@ inline void calculate_covariances(OCloud& c, int k) {
     }
     // upstream divides by k_correspondences_ (== found whenever the cloud has >= k points)
     C = (1.0 / k) * C;
-    for (int r = 0; r < 3; r++) C.m[r][r] += 1e-3;
-    const M3 Cinv = inverse(C);
-    c.covs[i] = inverse((1.0 / frobenius(Cinv)) * Cinv);
+    if (method == HGS_REG_NONE) {
+      c.covs[i] = C;
+    } else if (method == HGS_REG_FROBENIUS) {
+      for (int r = 0; r < 3; r++) C.m[r][r] += 1e-3;
+      const M3 Cinv = inverse(C);
+      c.covs[i] = inverse((1.0 / frobenius(Cinv)) * Cinv);
+    } else {
+      double ev[3];  // ascending
+      M3 evec;
+      eig_sym3(C, ev, evec);
+      double values[3];
+      if (method == HGS_REG_PLANE) {
+        values[0] = 1e-3, values[1] = 1.0, values[2] = 1.0;  // (1, 1, 1e-3) against singular values in descending order
+      } else {
+        const double scale = method == HGS_REG_NORMALIZED_MIN_EIG ? ev[2] : 1.0;
+        for (int a = 0; a < 3; a++) values[a] = std::max(std::fabs(ev[a]) / scale, 1e-3);
+      }
+      M3 out = M3::zero();
+      for (int a = 0; a < 3; a++)
+        for (int r = 0; r < 3; r++)
+          for (int s = 0; s < 3; s++) out.m[r][s] += values[a] * evec.m[r][a] * evec.m[s][a];
+      c.covs[i] = out;
+    }
   }
 }
 
@@ -110,8 +132,8 @@ public:
   M6 final_hessian = M6::zero();
 
   void ensure_covs() {
-    if (source && source->covs.size() != source->pts.size()) calculate_covariances(*source, prm.correspondence_randomness);
-    if (target && target->covs.size() != target->pts.size()) calculate_covariances(*target, prm.correspondence_randomness);
+    if (source && source->covs.size() != source->pts.size()) calculate_covariances(*source, prm.correspondence_randomness, prm.regularization_method);
+    if (target && target->covs.size() != target->pts.size()) calculate_covariances(*target, prm.correspondence_randomness, prm.regularization_method);
   }
 
   void update_correspondences(const Iso& T) {

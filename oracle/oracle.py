@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libhgs_oracle.so")
 
 HGS_FAST_GICP, HGS_FAST_VGICP, HGS_NDT_OMP = 0, 1, 2
 HGS_KDTREE, HGS_DIRECT1, HGS_DIRECT7, HGS_DIRECT27 = 0, 1, 2, 3
+HGS_REG_FROBENIUS, HGS_REG_PLANE, HGS_REG_MIN_EIG, HGS_REG_NORMALIZED_MIN_EIG, HGS_REG_NONE = 0, 1, 2, 3, 4
 
 
 class HgsParams(C.Structure):
@@ -28,7 +29,7 @@ class HgsParams(C.Structure):
         ("resolution", C.c_double), ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double),
         ("ndt_min_points_per_voxel", C.c_int32), ("ndt_upstream_hd1_sign", C.c_int32),
         ("lm_max_iterations", C.c_int32), ("lm_init_lambda_factor", C.c_double),
-        ("device_id", C.c_int32), ("reserved", C.c_int32),
+        ("device_id", C.c_int32), ("regularization_method", C.c_int32),
     ]
 
 
@@ -95,7 +96,7 @@ def lib():
         L.hgso_trace_len.argtypes = [C.c_void_p]
         L.hgso_trace_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hgso_knn.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.hgso_covariances.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+        L.hgso_covariances.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.hgso_gicp_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_gicp_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_prefilter.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -238,10 +239,10 @@ def knn(points: np.ndarray, queries: np.ndarray, k: int, brute: bool = False):
     return idx, d2
 
 
-def covariances(points: np.ndarray, k: int = 20) -> np.ndarray:
+def covariances(points: np.ndarray, k: int = 20, method: int = HGS_REG_FROBENIUS) -> np.ndarray:
     p, n, s = _cloud_args(points)
     out = np.zeros((n, 6))
-    lib().hgso_covariances(_ptr(p), n, s, k, _ptr(out))
+    lib().hgso_covariances(_ptr(p), n, s, k, int(method), _ptr(out))
     return out
 
 

@@ -47,8 +47,8 @@ public:
   }
   void ensure_covs() {
     const int k = prm.correspondence_randomness;
-    if (source && source->covs.size() != source->pts.size()) calculate_covariances(*source, k);
-    if (target && target->covs.size() != target->pts.size()) calculate_covariances(*target, k);
+    if (source && source->covs.size() != source->pts.size()) calculate_covariances(*source, k, prm.regularization_method);
+    if (target && target->covs.size() != target->pts.size()) calculate_covariances(*target, k, prm.regularization_method);
   }
   VoxelKey coord_of(V3 p) const {
     return {(int)std::floor(p.x / prm.resolution - 0.5), (int)std::floor(p.y / prm.resolution - 0.5), (int)std::floor(p.z / prm.resolution - 0.5)};

@@ -96,7 +96,7 @@ static void build_cloud(ECloud& c, const float* xyz, int n, size_t stride_floats
 // Models k_knn_cov's two passes per query: (1) r2 = distance of the k-th neighbour and how many points at exactly r2
 // belong to the k nearest; (2) every point closer than r2 plus that many points at r2, lowest original index first.
 template <int KMAX>
-static void knn_cov_t(ECloud& c, int k) {
+static void knn_cov_t(ECloud& c, int k, int reg_method) {
   c.cov.assign((size_t)2 * c.P * kLeaf, Float4{0, 0, 0, 0});
   const BvhView tv = c.view();
   std::vector<std::pair<int, int>> tied;  // (original index, position)
@@ -138,16 +138,16 @@ static void knn_cov_t(ECloud& c, int k) {
     }
     std::sort(tied.begin(), tied.end());
     for (int t = 0; t < ties && t < (int)tied.size(); t++) add(tv.pts[tied[t].second]);
-    const Sym3 cv = gicp_regularized_cov(s1, s2, found, k);
+    const Sym3 cv = gicp_regularized_cov(s1, s2, found, k, reg_method);
     c.cov[2 * i] = Float4{(float)cv.xx, (float)cv.xy, (float)cv.xz, (float)cv.yy};
     c.cov[2 * i + 1] = Float4{(float)cv.yz, (float)cv.zz, 0, 0};
   }
 }
-static void knn_cov(ECloud& c, int k) {
-  if (k <= 8) knn_cov_t<8>(c, k);
-  else if (k <= 16) knn_cov_t<16>(c, k);
-  else if (k <= 20) knn_cov_t<20>(c, k);
-  else knn_cov_t<32>(c, k);
+static void knn_cov(ECloud& c, int k, int reg_method) {
+  if (k <= 8) knn_cov_t<8>(c, k, reg_method);
+  else if (k <= 16) knn_cov_t<16>(c, k, reg_method);
+  else if (k <= 20) knn_cov_t<20>(c, k, reg_method);
+  else knn_cov_t<32>(c, k, reg_method);
 }
 static Sym3 load_cov(const std::vector<Float4>& cov, int i) {
   const Float4 a = cov[2 * i], b = cov[2 * i + 1];
@@ -420,7 +420,7 @@ void emul_destroy(EmulHandle* h) { delete h; }
 
 static void prep(EmulHandle* h, ECloud& c, const void* pts, size_t n, size_t stride, bool is_target) {
   build_cloud(c, (const float*)pts, (int)n, stride / 4);
-  if (h->prm.method == HGS_FAST_GICP || h->prm.method == HGS_FAST_VGICP) knn_cov(c, h->prm.correspondence_randomness);
+  if (h->prm.method == HGS_FAST_GICP || h->prm.method == HGS_FAST_VGICP) knn_cov(c, h->prm.correspondence_randomness, h->prm.regularization_method);
   if (h->prm.method == HGS_FAST_VGICP && is_target) vgicp_build(h->vg, c, h->prm.resolution);
   if (h->prm.method == HGS_NDT_OMP && is_target) ndt_build(h->ndt, c, h->prm.resolution, h->prm.ndt_min_points_per_voxel);
 }

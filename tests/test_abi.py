@@ -61,6 +61,10 @@ def test_rosparam_mapping_follows_registrations_cpp(L):
     p = params_from_rosparams({"registration_method": "NDT_OMP", "reg_nn_search_method": "DIRECT1", "reg_resolution": 1.0})
     assert (p.neighbor_search, p.resolution) == (L.HGS_DIRECT1, 1.0)
     assert params_from_rosparams({"reg_nn_search_method": "KDTREE"}).neighbor_search == L.HGS_KDTREE
+    assert params_from_rosparams({"registration_method": "FAST_GICP"}).regularization_method == L.HGS_REG_FROBENIUS
+    assert params_from_rosparams({"registration_method": "FAST_VGICP", "reg_regularization_method": "plane"}).regularization_method == L.HGS_REG_PLANE
+    with pytest.raises(ValueError):
+        params_from_rosparams({"registration_method": "FAST_GICP", "reg_regularization_method": "bogus"})
     p = params_from_rosparams({"registration_method": "bogus"})      # unknown -> NDT with a warning (registrations.cpp:88-91)
     assert p.method == L.HGS_NDT_OMP
     with pytest.raises(NotImplementedError):

@@ -57,6 +57,21 @@ def test_covariances_with_equidistant_neighbours():
         PC.check_covariances(e, cloud, k)
 
 
+@pytest.mark.parametrize("method", [O.HGS_REG_PLANE, O.HGS_REG_MIN_EIG, O.HGS_REG_NORMALIZED_MIN_EIG, O.HGS_REG_NONE])
+def test_covariance_regularization_methods(method):
+    """fast_gicp::RegularizationMethod other than the FROBENIUS default (setRegularizationMethod)."""
+    tgt, src, T = _pair("vlp16")
+    p = O.default_params(O.HGS_FAST_GICP)
+    p.regularization_method = method
+    e, o = emul.EmulRegistration(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    PC.check_covariances(e, tgt, 20, method)
+    if method != O.HGS_REG_NONE:   # raw covariances of coplanar neighbourhoods are singular: not a usable GICP metric
+        # covariances with a 1e-3 : 1 spectrum stored as floats: the Mahalanobis sum carries their 6e-8 rounding amplified
+        PC.check_gicp_linearize(e, o, T.astype(np.float32).astype(np.float64), err_rel=2e-5)
+        PC.check_align(e, o, T @ synth.pose_matrix([0.2, -0.1, 0.02], [0.002, -0.003, 0.015]), tol_m=1e-6, tol_rad=2e-5)
+
+
 def test_gicp_linearize(gicp_case):
     e, o, tgt, src, T = gicp_case
     PC.check_gicp_linearize(e, o, T.astype(np.float32).astype(np.float64))
