@@ -48,7 +48,7 @@ class DeviceCloud:
 
     def close(self):
         if self._h:
-            L.lib().hgs_cloud_destroy(self._h)
+            self._reg._lib.hgs_cloud_destroy(self._h)   # the library that created it
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -79,7 +79,8 @@ class RegistrationHIP:
     def __init__(self, params: L.HgsParams):
         self.params = params
         self._h = C.c_void_p()
-        rc = L.lib().hgs_create(C.byref(params), C.byref(self._h))
+        self._lib = L.lib()
+        rc = self._lib.hgs_create(C.byref(params), C.byref(self._h))
         if rc != L.HGS_OK:
             msg = L.lib().hgs_last_error(None)
             raise HgsError(f"hgs_create failed: {L.STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
@@ -91,7 +92,7 @@ class RegistrationHIP:
     # ---- life cycle
     def close(self):
         if self._h:
-            L.lib().hgs_destroy(self._h)
+            self._lib.hgs_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

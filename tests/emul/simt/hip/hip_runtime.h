@@ -1,0 +1,222 @@
+// SIMT emulation shim — TEST INFRASTRUCTURE, never part of the product.
+//
+// A stand-in for <hip/hip_runtime.h> that lets the product sources (hdl_graph_slam_amd/csrc/*.hip, unchanged) be compiled
+// for the host CPU: every GPU thread of a launched block becomes a fiber (cooperative user-level context) inside one OS
+// thread, the 64 fibers of a wave meet in the cross-lane operations (__ballot, __shfl_down, readlane, wave barriers) and the
+// fibers of a block in __syncthreads, blocks run one after the other, `__shared__` becomes a function-local static.  The
+// HIP runtime API is mapped to malloc / memcpy; launches are synchronous.  tests/emul/simt_runtime.cpp holds the scheduler.
+// Built by tests/emul/simt.py into tests/emul/libhgs_simt.so, which exports the same C-ABI as libhgs_hip.so and is loaded by
+// tests only (tests/test_simt_kernels_host.py): the kernels' and the engine's logic is exercised without a GPU.
+#pragma once
+#ifndef __HIPCC__
+#define __HIPCC__ 1
+#endif
+#define HGS_SIMT_EMULATION 1
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+
+// ------------------------------------------------------------------------------------------------ language
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define amdgpu_waves_per_eu(...)  // __attribute__((amdgpu_waves_per_eu(n))) -> __attribute__(())
+
+struct alignas(16) float4 {
+  float x, y, z, w;
+};
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace simt {
+struct Idx {
+  unsigned x, y, z;
+};
+struct Thread {
+  Idx tid;
+  int lane, wave;
+};
+extern Thread* g_cur;
+extern Idx g_block, g_block_dim, g_grid_dim;
+
+// all-to-all exchange of one 64-bit value among the live lanes of the calling lane's wave; returns the mask of lanes that took
+// part, out[l] = value of lane l.  `kind` must agree among the participants (a mismatch means divergent collectives).
+unsigned long long wave_exchange(int kind, unsigned long long mine, unsigned long long out[64]);
+void block_barrier();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+
+template <typename T>
+static inline unsigned long long to_bits(T v) {
+  static_assert(sizeof(T) <= 8, "cross-lane operands are at most 64 bits");
+  unsigned long long b = 0;
+  memcpy(&b, &v, sizeof(T));
+  return b;
+}
+template <typename T>
+static inline T from_bits(unsigned long long b) {
+  T v;
+  memcpy(&v, &b, sizeof(T));
+  return v;
+}
+static inline unsigned long long ballot(bool p) {
+  unsigned long long all[64];
+  const unsigned long long live = wave_exchange(1, p ? 1ull : 0ull, all);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; l++)
+    if (((live >> l) & 1ull) && all[l]) m |= 1ull << l;
+  return m;
+}
+template <typename T>
+static inline T shfl_down(T v, unsigned delta) {
+  unsigned long long all[64];
+  const unsigned long long live = wave_exchange(2, to_bits(v), all);
+  const unsigned src = (unsigned)g_cur->lane + delta;
+  return (src < 64u && ((live >> src) & 1ull)) ? from_bits<T>(all[src]) : v;
+}
+template <typename T>
+static inline T readlane(T v, int lane) {
+  unsigned long long all[64];
+  wave_exchange(3, to_bits(v), all);
+  return from_bits<T>(all[lane & 63]);
+}
+static inline void wave_barrier() {
+  unsigned long long all[64];
+  wave_exchange(4, 0ull, all);
+}
+}  // namespace simt
+
+#define threadIdx (simt::g_cur->tid)
+#define blockIdx simt::g_block
+#define blockDim simt::g_block_dim
+#define gridDim simt::g_grid_dim
+
+#define __syncthreads() simt::block_barrier()
+#define __ballot(p) simt::ballot((p) != 0)
+#define __shfl_down(v, d, ...) simt::shfl_down((v), (unsigned)(d))
+#define __lane_id() ((unsigned)simt::g_cur->lane)
+#define __builtin_amdgcn_readlane(v, l) simt::readlane((v), (l))
+#define __builtin_amdgcn_wave_barrier() simt::wave_barrier()
+#define __builtin_amdgcn_fmed3f(a, b, c) fmaxf(fminf((a), (b)), fminf(fmaxf((a), (b)), (c)))
+#define __threadfence_system() ((void)0)
+
+template <typename T>
+static inline T min(T a, T b) {
+  return b < a ? b : a;
+}
+template <typename T>
+static inline T max(T a, T b) {
+  return a < b ? b : a;
+}
+static inline int __float_as_int(float f) { return simt::from_bits<int>(simt::to_bits(f)); }
+static inline unsigned __float_as_uint(float f) { return simt::from_bits<unsigned>(simt::to_bits(f)); }
+static inline float __int_as_float(int i) { return simt::from_bits<float>(simt::to_bits(i)); }
+static inline float __uint_as_float(unsigned u) { return simt::from_bits<float>(simt::to_bits(u)); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+
+// one OS thread runs every fiber: plain read-modify-write is atomic
+template <typename T>
+static inline T atomicAdd(T* p, T v) {
+  const T o = *p;
+  *p = o + v;
+  return o;
+}
+template <typename T>
+static inline T atomicMin(T* p, T v) {
+  const T o = *p;
+  *p = v < o ? v : o;
+  return o;
+}
+template <typename T>
+static inline T atomicMax(T* p, T v) {
+  const T o = *p;
+  *p = v > o ? v : o;
+  return o;
+}
+template <typename T>
+static inline T atomicCAS(T* p, T expected, T desired) {
+  const T o = *p;
+  if (o == expected) *p = desired;
+  return o;
+}
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) simt::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+
+// ------------------------------------------------------------------------------------------------ runtime API
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "simt emulation: allocation failed"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) {
+  *n = 1;
+  return hipSuccess;
+}
+template <typename T>
+static inline hipError_t hipMalloc(T** p, size_t bytes) {
+  *p = (T*)aligned_alloc(256, (bytes + 255) / 256 * 256 + 256);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipFree(void* p) {
+  free(p);
+  return hipSuccess;
+}
+template <typename T>
+static inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned = 0) {
+  return hipMalloc(p, bytes);
+}
+static inline hipError_t hipHostFree(void* p) { return hipFree(p); }
+static inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t = nullptr) {
+  memmove(dst, src, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind k) { return hipMemcpyAsync(dst, src, n, k); }
+static inline hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t = nullptr) {
+  memset(dst, v, n);
+  return hipSuccess;
+}
+static inline hipError_t hipStreamCreate(hipStream_t* s) {
+  *s = malloc(1);
+  return hipSuccess;
+}
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+static inline hipError_t hipStreamDestroy(hipStream_t s) {
+  free(s);
+  return hipSuccess;
+}
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = malloc(1);
+  return hipSuccess;
+}
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t e) {
+  free(e);
+  return hipSuccess;
+}
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) {
+  *ms = 0.f;
+  return hipSuccess;
+}

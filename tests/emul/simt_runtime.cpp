@@ -1,0 +1,255 @@
+// SIMT emulation runtime — TEST INFRASTRUCTURE (see tests/emul/simt/hip/hip_runtime.h).
+//
+// simt::launch runs the blocks of a grid one after the other; the threads of a block are fibers with their own stacks,
+// scheduled cooperatively from one OS thread.  A fiber runs until it finishes or reaches a cross-lane operation / barrier it
+// cannot complete yet; the last participant to arrive completes the operation for everybody and makes the others runnable.
+// A wave's participants are its lanes that have not returned yet (a returned lane contributes nothing, as on the hardware).
+// Divergent use (lanes of one wave meeting in different kinds of operations, or nobody runnable while threads are still
+// alive) aborts with a message: the product code is required to call the wave operations from wave-uniform control flow.
+//
+// Also here: the host versions of the two rocPRIM entry points of hgs_sort.h.
+#include <hip/hip_runtime.h>
+
+#include <stddef.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../hdl_graph_slam_amd/csrc/hgs_sort.h"
+
+extern "C" void simt_switch(void** save_sp, void* new_sp);
+// x86-64 SysV: callee-saved rbx, rbp, r12-r15 + the stack pointer make up a context
+asm(R"(
+.text
+.globl simt_switch
+.type simt_switch,@function
+simt_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size simt_switch,.-simt_switch
+)");
+
+namespace simt {
+
+Thread* g_cur = nullptr;
+Idx g_block = {0, 0, 0}, g_block_dim = {1, 1, 1}, g_grid_dim = {1, 1, 1};
+
+namespace {
+
+enum State { READY = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
+constexpr size_t kStackBytes = 256 * 1024;
+
+struct Fiber {
+  Thread th;
+  State state = DONE;
+  void* sp = nullptr;
+  char* stack = nullptr;
+};
+struct Wave {
+  int alive = 0, arrived = 0, kind = 0;
+  unsigned gen = 0;
+  unsigned long long live_mask = 0;
+  unsigned long long vals[2][64];
+  unsigned long long mask[2];
+};
+
+std::vector<Fiber> g_fibers;       // grown on demand, stacks reused between launches
+std::vector<Wave> g_waves;
+std::vector<int> g_ready;          // FIFO of runnable fibers
+size_t g_ready_head = 0;
+int g_nthreads = 0, g_block_alive = 0, g_block_arrived = 0;
+void* g_sched_sp = nullptr;
+const std::function<void()>* g_body = nullptr;
+
+void make_ready(int f) {
+  g_fibers[f].state = READY;
+  g_ready.push_back(f);
+}
+inline Fiber& cur_fiber() { return *reinterpret_cast<Fiber*>(reinterpret_cast<char*>(g_cur) - offsetof(Fiber, th)); }
+inline void yield_to_scheduler() {
+  Fiber& me = cur_fiber();
+  simt_switch(&me.sp, g_sched_sp);
+}
+
+// every live lane of the wave has arrived: publish who took part and release the waiting lanes
+void complete_wave(Wave& w, int wave_index, int completer_lane /* -1: triggered by a lane that returned */) {
+  unsigned long long took_part = completer_lane >= 0 ? 1ull << completer_lane : 0ull;
+  for (int l = 0; l < 64; l++) {
+    const int f = wave_index * 64 + l;
+    if (f < g_nthreads && g_fibers[f].state == WAIT_WAVE) {
+      took_part |= 1ull << l;
+      make_ready(f);
+    }
+  }
+  w.mask[w.gen & 1u] = took_part;
+  w.arrived = 0;
+  w.gen++;
+}
+void complete_block() {
+  g_block_arrived = 0;
+  for (int f = 0; f < g_nthreads; f++)
+    if (g_fibers[f].state == WAIT_BLOCK) make_ready(f);
+}
+
+void fiber_main() {
+  (*g_body)();
+  Fiber& me = cur_fiber();
+  me.state = DONE;
+  Wave& w = g_waves[me.th.wave];
+  w.alive--;
+  w.live_mask &= ~(1ull << me.th.lane);
+  g_block_alive--;
+  // the lanes still waiting may have been waiting for this one only
+  if (w.alive > 0 && w.arrived == w.alive) complete_wave(w, me.th.wave, -1);
+  if (g_block_alive > 0 && g_block_arrived == g_block_alive) complete_block();
+  simt_switch(&me.sp, g_sched_sp);
+  fprintf(stderr, "simt: a finished fiber was resumed\n");
+  abort();
+}
+
+void prepare(Fiber& f) {
+  if (!f.stack) f.stack = (char*)aligned_alloc(64, kStackBytes);
+  // top of stack: [.. r15 r14 r13 r12 rbx rbp | ret = fiber_main | fake return address]; fiber_main starts with rsp = 16n + 8
+  uintptr_t top = ((uintptr_t)f.stack + kStackBytes) & ~(uintptr_t)15;
+  void** p = (void**)top;
+  *--p = nullptr;               // fake return address of fiber_main (never used)
+  *--p = (void*)&fiber_main;    // popped by simt_switch's ret: this slot is 16-byte aligned
+  for (int i = 0; i < 6; i++) *--p = nullptr;
+  f.sp = p;
+  f.state = READY;
+}
+
+}  // namespace
+
+unsigned long long wave_exchange(int kind, unsigned long long mine, unsigned long long out[64]) {
+  Fiber& me = cur_fiber();
+  Wave& w = g_waves[me.th.wave];
+  const unsigned gen = w.gen, buf = gen & 1u;
+  if (w.arrived == 0) w.kind = kind;
+  if (w.kind != kind) {
+    fprintf(stderr, "simt: lanes of wave %d meet in different cross-lane operations (%d vs %d): divergent control flow around a wave operation\n",
+            me.th.wave, w.kind, kind);
+    abort();
+  }
+  w.vals[buf][me.th.lane] = mine;
+  w.arrived++;
+  if (w.arrived == w.alive) {
+    complete_wave(w, me.th.wave, me.th.lane);
+  } else {
+    me.state = WAIT_WAVE;
+    yield_to_scheduler();
+  }
+  memcpy(out, w.vals[buf], sizeof(w.vals[buf]));
+  return w.mask[buf];
+}
+
+void block_barrier() {
+  Fiber& me = cur_fiber();
+  g_block_arrived++;
+  if (g_block_arrived == g_block_alive) {
+    complete_block();
+    return;
+  }
+  me.state = WAIT_BLOCK;
+  yield_to_scheduler();
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  if (g_cur) {
+    fprintf(stderr, "simt: nested launch\n");
+    abort();
+  }
+  const int nthreads = (int)(block.x * block.y * block.z);
+  if ((int)g_fibers.size() < nthreads) g_fibers.resize(nthreads);
+  const int nwaves = (nthreads + 63) / 64;
+  g_waves.assign(nwaves, Wave{});
+  g_nthreads = nthreads;
+  g_body = &body;
+  g_block_dim = {block.x, block.y, block.z};
+  g_grid_dim = {grid.x, grid.y, grid.z};
+  for (unsigned bz = 0; bz < grid.z; bz++)
+    for (unsigned by = 0; by < grid.y; by++)
+      for (unsigned bx = 0; bx < grid.x; bx++) {
+        g_block = {bx, by, bz};
+        g_ready.clear();
+        g_ready_head = 0;
+        for (int wv = 0; wv < nwaves; wv++) {
+          Wave& w = g_waves[wv];
+          w = Wave{};
+          w.alive = std::min(64, nthreads - wv * 64);
+          w.live_mask = w.alive == 64 ? ~0ull : ((1ull << w.alive) - 1);
+        }
+        g_block_alive = nthreads, g_block_arrived = 0;
+        for (int t = 0; t < nthreads; t++) {
+          Fiber& f = g_fibers[t];
+          f.th.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+          f.th.lane = t & 63, f.th.wave = t >> 6;
+          prepare(f);
+          g_ready.push_back(t);
+        }
+        while (g_block_alive > 0) {
+          if (g_ready_head == g_ready.size()) {
+            fprintf(stderr, "simt: deadlock in block (%u,%u,%u): %d threads alive, none runnable (a barrier or wave operation inside divergent code?)\n", bx,
+                    by, bz, g_block_alive);
+            abort();
+          }
+          const int f = g_ready[g_ready_head++];
+          if (g_ready_head > 4096 && g_ready_head * 2 > g_ready.size()) {
+            g_ready.erase(g_ready.begin(), g_ready.begin() + (long)g_ready_head);
+            g_ready_head = 0;
+          }
+          if (g_fibers[f].state != READY) continue;
+          g_cur = &g_fibers[f].th;
+          simt_switch(&g_sched_sp, g_fibers[f].sp);
+          g_cur = nullptr;
+        }
+      }
+  g_body = nullptr;
+}
+
+}  // namespace simt
+
+// ------------------------------------------------------------------------------------------------ hgs_sort.h on the host
+extern "C" int hgs_sort_pairs_u64_u32(void* temp, size_t* temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
+                                      uint32_t* vals_out, size_t n, int begin_bit, int end_bit, void*) {
+  if (!temp) {
+    *temp_bytes = 256;
+    return 0;
+  }
+  const uint64_t mask = (end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1)) & ~((1ull << begin_bit) - 1);
+  std::vector<size_t> order(n);
+  for (size_t i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return (keys_in[a] & mask) < (keys_in[b] & mask); });
+  std::vector<uint64_t> k(n);
+  std::vector<uint32_t> v(n);
+  for (size_t i = 0; i < n; i++) k[i] = keys_in[order[i]], v[i] = vals_in[order[i]];
+  std::copy(k.begin(), k.end(), keys_out);
+  std::copy(v.begin(), v.end(), vals_out);
+  return 0;
+}
+extern "C" int hgs_exclusive_scan_u32(void* temp, size_t* temp_bytes, const uint32_t* in, uint32_t* out, size_t n, void*) {
+  if (!temp) {
+    *temp_bytes = 256;
+    return 0;
+  }
+  uint32_t s = 0;
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t v = in[i];
+    out[i] = s;
+    s += v;
+  }
+  return 0;
+}

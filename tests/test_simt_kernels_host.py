@@ -1,0 +1,217 @@
+"""The PRODUCT kernels and engine on the CPU: hdl_graph_slam_amd/csrc/hgs_kernels.hip and hgs_engine.hip, unchanged, compiled
+for the host against the SIMT emulation shim of tests/emul (GPU threads as fibers, the 64 lanes of a wave meeting in
+__ballot / __shfl_down / readlane / wave barriers, blocks one after the other, HIP runtime mapped to malloc / memcpy) and
+driven through the same C-ABI and the same Python mirror as on the GPU.  What the `-m gpu` parity tests assert on an MI355X
+is asserted here on small clouds without one: packet walks, the two-pass k-NN with its tie rule, tile reductions, the
+on-device LM state machine, the NDT voxel table and derivative pass, the batch lanes and the progress mirror of the
+host loop, prefilter and map-cloud kernels.  (Performance, and anything that depends on real concurrency, is not.)"""
+import numpy as np
+import pytest
+
+import oracle as O
+import parity_checks as PC
+from hdl_graph_slam_amd import synth
+
+simt = pytest.importorskip("emul.simt", reason="needs tests/emul")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def simt_library():
+    """Points the package's loader at tests/emul/libhgs_simt.so for the duration of this module (and back afterwards)."""
+    path = simt.build()
+    if path is None:
+        pytest.skip("clang++ not available: the emulation build needs ext_vector_type / elementwise builtins")
+    from hdl_graph_slam_amd import _lib as L
+    saved = (L.LIB_PATH, L._lib)
+    L.LIB_PATH, L._lib = path, None
+    yield path
+    L.LIB_PATH, L._lib = saved
+
+
+def _engine(params):
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    p = L.HgsParams()
+    for name, _ in L.HgsParams._fields_:
+        setattr(p, name, getattr(params, name))
+    return RegistrationHIP(p)
+
+
+def _pair(kind):
+    if kind == "vlp16":
+        return synth.make_pair("VLP-16", 1, downsample=0.3)     # ~7 k points
+    if kind == "hdl32":
+        return synth.make_pair("HDL-32E", 4, downsample=0.4)    # ~6 k points
+    raise KeyError(kind)
+
+
+@pytest.fixture(scope="module", params=["vlp16", "hdl32"])
+def gicp_case(request):
+    tgt, src, T = _pair(request.param)
+    p = O.default_params(O.HGS_FAST_GICP)
+    e, o = _engine(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    yield e, o, tgt, src, T
+    e.close()
+
+
+def test_emulation_library_is_not_the_product_library(simt_library):
+    from hdl_graph_slam_amd import _lib as L
+    assert simt_library.endswith("libhgs_simt.so") and L.LIB_PATH == simt_library
+    assert all(hasattr(L.lib(), name) for name in L.EXPORTS)
+
+
+def test_tree_search_is_exact(gicp_case):
+    e, o, tgt, src, T = gicp_case
+    PC.check_nn(e, o, synth.xyz_of(src)[::3])
+    PC.check_nn(e, o, np.array([[1e4, 0, 0], [0, -5e3, 30], [0, 0, 0], [1e-3, 1e-3, 1e-3]], np.float32))
+
+
+def test_covariances(gicp_case):
+    e, o, tgt, src, T = gicp_case
+    PC.check_covariances(e, tgt)
+
+
+@pytest.mark.parametrize("k", [20, 10])
+def test_covariances_with_equidistant_neighbours(k):
+    """k_knn_cov's tie handling, including the tie-only re-walks for lanes that need more than four equidistant points."""
+    cloud = PC.tie_heavy_cloud()
+    p = O.default_params(O.HGS_FAST_GICP)
+    p.correspondence_randomness = k
+    e = _engine(p)
+    e.setInputTarget(cloud)
+    PC.check_covariances(e, cloud, k)
+    e.close()
+
+
+def test_gicp_linearize_align_fitness(gicp_case):
+    e, o, tgt, src, T = gicp_case
+    PC.check_gicp_linearize(e, o, T.astype(np.float32).astype(np.float64))
+    PC.check_gicp_linearize(e, o, np.eye(4))
+    re, ro = PC.check_align(e, o, np.eye(4), tol_m=1e-6, tol_rad=2e-5)
+    PC.check_fitness(e, o, ro.matrix())
+    again = e.align(np.eye(4))
+    assert bytes(again.final_transformation) == bytes(re.final_transformation)      # deterministic reductions
+
+
+def test_gicp_lm_rejection_path(gicp_case):
+    e, o, tgt, src, T = gicp_case
+    p = O.default_params(O.HGS_FAST_GICP)
+    p.max_correspondence_distance = 1.0
+    p.transformation_epsilon, p.rotation_epsilon = 1e-5, 1e-6
+    p.lm_init_lambda_factor = 1e-12
+    e2, o2 = _engine(p), O.OracleRegistration(p)
+    PC.load_pair(e2, o2, tgt, src)
+    guess = T @ synth.pose_matrix([0.8, 0.5, 0.1], [0.01, 0.01, 0.08])
+    re, ro = PC.check_align(e2, o2, guess, tol_m=1e-5, tol_rad=2e-5)
+    assert ro.lm_tries >= ro.iterations
+    e2.close()
+
+
+@pytest.mark.parametrize("method", [O.HGS_REG_PLANE, O.HGS_REG_NORMALIZED_MIN_EIG])
+def test_covariance_regularization_methods(method):
+    tgt, src, T = _pair("vlp16")
+    p = O.default_params(O.HGS_FAST_GICP)
+    p.regularization_method = method
+    e, o = _engine(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    PC.check_covariances(e, tgt, 20, method)
+    PC.check_align(e, o, T @ synth.pose_matrix([0.2, -0.1, 0.02], [0.002, -0.003, 0.015]), tol_m=1e-5, tol_rad=2e-5)
+    e.close()
+
+
+@pytest.mark.parametrize("res,search", [(1.0, O.HGS_DIRECT1), (0.5, O.HGS_DIRECT7), (2.0, O.HGS_DIRECT27)])
+def test_vgicp(res, search):
+    tgt, src, T = _pair("hdl32")
+    p = O.default_params(O.HGS_FAST_VGICP)
+    p.resolution, p.neighbor_search = res, search
+    e, o = _engine(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    PC.check_gicp_linearize(e, o, T.astype(np.float32).astype(np.float64))
+    re, ro = PC.check_align(e, o, T @ synth.pose_matrix([0.2, -0.1, 0.02], [0.002, -0.003, 0.015]), tol_m=1e-5, tol_rad=2e-5)
+    PC.check_fitness(e, o, ro.matrix())
+    e.close()
+
+
+@pytest.mark.parametrize("kind,res,search", [("hdl32", 1.0, O.HGS_DIRECT7), ("hdl32", 0.5, O.HGS_DIRECT1), ("vlp16", 1.0, O.HGS_DIRECT7), ("hdl32", 1.0, O.HGS_KDTREE)])
+def test_ndt(kind, res, search):
+    """Voxel table build (hash insertion, stable per-cell accumulation, eigen floor), derivative kernel + tile reduction."""
+    tgt, src, T = _pair(kind)
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution, p.neighbor_search = res, search
+    e, o = _engine(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    PC.check_ndt_cells(e, o)
+    PC.check_ndt_derivatives(e, o, np.array([T[0, 3], T[1, 3], T[2, 3], 0.003, -0.004, 0.02]))
+    e.close()
+    # Not emulated: the Newton loop.  k_ndt_solve's three-lane Jacobi SVD (solve_svd6_wave) exchanges columns through volatile
+    # LDS between rounds WITHOUT a cross-lane operation, relying on the hardware executing the lanes of a wave in lock-step;
+    # fibers only meet in explicit wave operations, so lane 0 would run a whole sweep before lanes 1 and 2 start.  Covered on
+    # the GPU (tests/test_hip_parity.py::test_ndt_align, test_full_size.py) and, for the serial order, by tests/emul.
+
+
+@pytest.mark.parametrize("method", ["FAST_GICP", "FAST_VGICP"])
+def test_loop_batch_equals_the_sequential_loop(method):
+    """hgs_loop_match_batch on 4 lanes (run_batch / drive_lanes / the progress mirror) against one align + getFitnessScore per
+    candidate, bit for bit; 7 candidates so that the lanes are uneven."""
+    from hdl_graph_slam_amd import workloads
+    from hdl_graph_slam_amd.registration import select_best
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    wl = workloads.make_loop_closure_set("VLP-16", 3, n_candidates=7, n_distinct=3, downsample=0.4)
+    pnh = {"registration_method": method, "reg_resolution": 1.0}
+    reg = select_registration_method(pnh)
+    reg.setInputTarget(wl.target)
+    clouds = [reg.upload(c) for c in wl.candidates]
+    rec, best = reg.loop_match_batch(clouds, wl.guesses, 4.0)
+    assert best == select_best(rec)
+    for i, c in enumerate(clouds):
+        reg.setInputSource(c)
+        r = reg.align(wl.guesses[i])
+        assert bytes(r.final_transformation) == rec["final_transformation"][i].tobytes()
+        assert r.converged == rec["converged"][i] and r.iterations == rec["iterations"][i]
+        assert reg.getFitnessScore(4.0) == rec["fitness_score"][i]
+    reg.close()
+
+
+def test_prefilter_and_map_cloud_match_the_oracle():
+    from hdl_graph_slam_amd import _lib as L
+    import ctypes as C
+    tgt, src, T = synth.make_pair("VLP-16", 2)
+    reg = _engine(O.default_params(O.HGS_FAST_GICP))
+    for outlier in (L.HGS_OUTLIER_RADIUS, L.HGS_OUTLIER_STATISTICAL):
+        p = L.HgsPrefilterParams()
+        L.lib().hgs_prefilter_params_default(C.byref(p))
+        p.downsample_resolution, p.outlier_removal_method = 0.3, outlier
+        op = O.PrefilterParams()
+        for name, _ in O.PrefilterParams._fields_:
+            setattr(op, name, getattr(p, name))
+        got = reg.prefilter(tgt, p).download()
+        ref = O.prefilter(tgt, op)
+        assert len(got) == len(ref)
+        assert np.array_equal(synth.xyz_of(got), synth.xyz_of(ref))
+    kfs = [reg.upload(synth.voxel_downsample(c, 0.3)) for c in (tgt, src)]
+    poses = [np.eye(4), T]
+    got = reg.map_cloud(kfs, poses, 0.5).download()
+    ref = O.map_cloud([synth.voxel_downsample(c, 0.3) for c in (tgt, src)], poses, 0.5)
+    assert np.array_equal(np.sort(synth.xyz_of(got).view("f4,f4,f4"), axis=0), np.sort(synth.xyz_of(ref).view("f4,f4,f4"), axis=0))
+    reg.close()
+
+
+def test_edge_cases():
+    from hdl_graph_slam_amd.registration import HgsError
+    p = O.default_params(O.HGS_FAST_GICP)
+    e = _engine(p)
+    with pytest.raises(HgsError):
+        e.align(np.eye(4))
+    tgt = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [np.nan, 0, 0], [0, 0, 1], [np.inf, 1, 1]], np.float32)
+    e.setInputTarget(tgt)
+    idx, d2 = e.nn_target(np.array([[0.9, 0.1, 0.0], [0.1, 0.1, 0.8]], np.float32))
+    assert list(idx) == [1, 4]
+    e.setInputSource(np.zeros((0, 3), np.float32))
+    assert e.align(np.eye(4)).iterations >= 1
+    assert e.getFitnessScore() == np.finfo(np.float64).max
+    tgt2, src2, T = synth.make_pair("VLP-16", 1, downsample=0.4)
+    o = O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt2, src2[:7])
+    PC.check_align(e, o, T, tol_m=1e-4, tol_rad=1e-4)
+    e.close()
