@@ -812,10 +812,13 @@ void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView
 // SVD-solve(A, b) by the calling wave: the three rotations of a Jacobi round on lanes 0..2, U and V (36 doubles each) in
 // LDS.  Same arithmetic and the same pair order as solve_svd6 (hgs_math.h) => same bits; x is valid on lane 0.
 // LDS accesses of one wave are performed in program order, and the volatile qualifier keeps the compiler from caching a
-// column across rounds, so a lane reads the columns the other lanes rotated in the round before without a barrier.
+// column across rounds, so a lane reads the columns the other lanes rotated in the round before; the wave barrier between
+// rounds emits no instruction — it states the lock-step dependence (and is where the host emulation of tests/emul lets the
+// three lanes meet).
 __device__ __forceinline__ void solve_svd6_wave(const double* A, const double* b, volatile double* U, volatile double* V, double* x) {
   const int lane = (int)(threadIdx.x & 63);
   if (lane < 36) U[lane] = A[lane], V[lane] = (lane % 7 == 0) ? 1.0 : 0.0;
+  __builtin_amdgcn_wave_barrier();
   for (int sweep = 0; sweep < 60; sweep++) {
     bool rotated = false;
     for (int round = 0; round < 5; round++) {
@@ -824,6 +827,7 @@ __device__ __forceinline__ void solve_svd6_wave(const double* A, const double* b
         svd6_pair(round, lane, &p, &q);
         if (svd6_rotate<volatile double*>(U, V, p, q)) rotated = true;
       }
+      __builtin_amdgcn_wave_barrier();
     }
     if (__ballot(rotated) == 0ull) break;
   }

@@ -3,7 +3,7 @@ for the host against the SIMT emulation shim of tests/emul (GPU threads as fiber
 __ballot / __shfl_down / readlane / wave barriers, blocks one after the other, HIP runtime mapped to malloc / memcpy) and
 driven through the same C-ABI and the same Python mirror as on the GPU.  What the `-m gpu` parity tests assert on an MI355X
 is asserted here on small clouds without one: packet walks, the two-pass k-NN with its tie rule, tile reductions, the
-on-device LM state machine, the NDT voxel table and derivative pass, the batch lanes and the progress mirror of the
+on-device LM / Newton state machines including the three-lane Jacobi SVD, the batch lanes and the progress mirror of the
 host loop, prefilter and map-cloud kernels.  (Performance, and anything that depends on real concurrency, is not.)"""
 import numpy as np
 import pytest
@@ -135,7 +135,8 @@ def test_vgicp(res, search):
 
 @pytest.mark.parametrize("kind,res,search", [("hdl32", 1.0, O.HGS_DIRECT7), ("hdl32", 0.5, O.HGS_DIRECT1), ("vlp16", 1.0, O.HGS_DIRECT7), ("hdl32", 1.0, O.HGS_KDTREE)])
 def test_ndt(kind, res, search):
-    """Voxel table build (hash insertion, stable per-cell accumulation, eigen floor), derivative kernel + tile reduction."""
+    """Voxel table build (hash insertion, stable per-cell accumulation, eigen floor), derivative kernel + tile reduction, the
+    Newton loop."""
     tgt, src, T = _pair(kind)
     p = O.default_params(O.HGS_NDT_OMP)
     p.resolution, p.neighbor_search = res, search
@@ -144,13 +145,16 @@ def test_ndt(kind, res, search):
     PC.check_ndt_cells(e, o)
     PC.check_ndt_derivatives(e, o, np.array([T[0, 3], T[1, 3], T[2, 3], 0.003, -0.004, 0.02]))
     e.close()
-    # Not emulated: the Newton loop.  k_ndt_solve's three-lane Jacobi SVD (solve_svd6_wave) exchanges columns through volatile
-    # LDS between rounds WITHOUT a cross-lane operation, relying on the hardware executing the lanes of a wave in lock-step;
-    # fibers only meet in explicit wave operations, so lane 0 would run a whole sweep before lanes 1 and 2 start.  Covered on
-    # the GPU (tests/test_hip_parity.py::test_ndt_align, test_full_size.py) and, for the serial order, by tests/emul.
+    for max_it in (1, 6):      # the Newton state machine with the three-lane Jacobi SVD; fixed-length prefixes compare tightly
+        p2 = O.default_params(O.HGS_NDT_OMP)
+        p2.resolution, p2.neighbor_search, p2.max_iterations = res, search, max_it
+        e2, o2 = _engine(p2), O.OracleRegistration(p2)
+        PC.load_pair(e2, o2, tgt, src)
+        PC.check_align(e2, o2, T @ synth.pose_matrix([0.05, 0.02, 0.0], [0.0, 0.0, 0.004]), tol_m=1e-6, tol_rad=1e-6)
+        e2.close()
 
 
-@pytest.mark.parametrize("method", ["FAST_GICP", "FAST_VGICP"])
+@pytest.mark.parametrize("method", ["FAST_GICP", "NDT_OMP"])
 def test_loop_batch_equals_the_sequential_loop(method):
     """hgs_loop_match_batch on 4 lanes (run_batch / drive_lanes / the progress mirror) against one align + getFitnessScore per
     candidate, bit for bit; 7 candidates so that the lanes are uneven."""
@@ -159,6 +163,8 @@ def test_loop_batch_equals_the_sequential_loop(method):
     from hdl_graph_slam_amd.registrations import select_registration_method
     wl = workloads.make_loop_closure_set("VLP-16", 3, n_candidates=7, n_distinct=3, downsample=0.4)
     pnh = {"registration_method": method, "reg_resolution": 1.0}
+    if method == "NDT_OMP":
+        pnh["reg_maximum_iterations"] = 6      # 8 Newton iterations per candidate keep the emulated run short
     reg = select_registration_method(pnh)
     reg.setInputTarget(wl.target)
     clouds = [reg.upload(c) for c in wl.candidates]
