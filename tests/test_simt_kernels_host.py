@@ -221,3 +221,38 @@ def test_edge_cases():
     PC.load_pair(e, o, tgt2, src2[:7])
     PC.check_align(e, o, T, tol_m=1e-4, tol_rad=1e-4)
     e.close()
+
+
+@pytest.mark.parametrize("method", [0, 2])
+def test_cpp_adapter_end_to_end(simt_library, tmp_path, method):
+    """adapters/registration_hip.hpp (the pcl::Registration subclass the reference's factory would construct) driven like
+    scan_matching_odometry_nodelet.cpp:166-221 by tests/cpp/adapter_main.cpp, linked against the emulated library: the C++
+    boundary returns the bits of the Python mirror and the pose of the oracle."""
+    import os
+    import subprocess
+    from hdl_graph_slam_amd import _lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "adapter_main_simt")
+    src_cpp = os.path.join(root, "tests", "cpp", "adapter_main.cpp")
+    deps = [src_cpp, os.path.join(root, "adapters", "registration_hip.hpp"), os.path.join(root, "include", "hgs_registration.h"), simt_library]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "tests", "mock_pcl"), "-I", os.path.join(root, "include"), src_cpp, "-o", exe,
+                        "-L", os.path.dirname(simt_library), "-l:libhgs_simt.so", f"-Wl,-rpath,{os.path.dirname(simt_library)}"], check=True)
+    tgt, src, T = _pair("vlp16")
+    tgt.tofile(tmp_path / "t.bin")
+    src.tofile(tmp_path / "s.bin")
+    out = subprocess.run([exe, str(method), str(tmp_path / "t.bin"), str(tmp_path / "s.bin")], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == "converged 1"
+    Tc = np.array([float(v) for v in out[1].split()], np.float32).reshape(4, 4).T
+    p = O.default_params(method)
+    if method == O.HGS_NDT_OMP:
+        p.resolution, p.neighbor_search = 1.0, O.HGS_DIRECT7
+    e, o = _engine(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    r = e.align(np.eye(4))
+    assert np.array_equal(Tc, r.matrix())
+    assert abs(float(out[2].split()[1]) - e.getFitnessScore()) < 1e-9
+    if method == 0:
+        dt, dr = synth.pose_error(Tc.astype(np.float64), o.align(np.eye(4)).matrix())
+        assert dt < 1e-5 and dr < 1e-5
+    e.close()
