@@ -256,3 +256,41 @@ def test_cpp_adapter_end_to_end(simt_library, tmp_path, method):
         dt, dr = synth.pose_error(Tc.astype(np.float64), o.align(np.eye(4)).matrix())
         assert dt < 1e-5 and dr < 1e-5
     e.close()
+
+
+# ---- the `-m gpu` tests of the caller-level modules, run as they are against the emulated library (their inputs are small
+# enough).  Each wrapper calls the GPU test function directly; the module fixture above has redirected the loader.
+def _gpu_test(module, name):
+    import importlib
+    return getattr(importlib.import_module(module), name)
+
+
+@pytest.mark.parametrize("method", ["FAST_GICP", "NDT_OMP"])
+def test_gpu_suite_odometry_stream(method):
+    _gpu_test("test_odometry", "test_hip_stream_follows_the_oracle_stream")(method)
+
+
+def test_gpu_suite_odometry_device_downsample():
+    _gpu_test("test_odometry", "test_hip_stream_with_device_voxelgrid_downsample")()
+
+
+def test_gpu_suite_information_matrix_fitness():
+    _gpu_test("test_loop_detector", "test_information_matrix_fitness_score_on_device")()
+
+
+def test_gpu_suite_prefilter_edges_and_download():
+    _gpu_test("test_prefilter", "test_hip_prefilter_edge_cases")()
+    _gpu_test("test_prefilter", "test_cloud_download_round_trip")()
+
+
+def test_gpu_suite_map_cloud():
+    _gpu_test("test_map_cloud", "test_hip_map_cloud_matches_oracle")(0.5)
+
+
+def test_gpu_suite_keyframe_directory(tmp_path):
+    _gpu_test("test_keyframe_io", "test_loaded_keyframes_become_resident_candidates")(tmp_path)
+
+
+def test_gpu_suite_golden_vectors():
+    _gpu_test("test_golden", "test_hip_reproduces_golden")()
+    _gpu_test("test_golden", "test_hip_reproduces_golden_v2")()
