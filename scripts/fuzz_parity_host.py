@@ -3,7 +3,11 @@
 sensors, resolutions and adversarial clouds (duplicates, collinear runs, coincident planes, far outliers, tiny clouds).
 Not part of the test suite (minutes of CPU time); prints one line per case and a summary, exits non-zero on a mismatch.
 
-  python scripts/fuzz_parity_host.py [--seeds 6] [--quick]"""
+  python scripts/fuzz_parity_host.py [--seeds 6] [--quick] [--backend emul|simt]
+
+--backend emul (default): the per-item device functions run by tests/emul/emul.cpp;  --backend simt: the product kernels
+and engine themselves, compiled for the host against the SIMT emulation shim (tests/emul/simt.py) — slower, but it is the
+code that runs on the GPU (packet walks, tile reductions, state machines, hash tables) that meets the adversarial inputs."""
 import argparse
 import os
 import sys
@@ -49,13 +53,27 @@ def cases(n_seeds: int, quick: bool):
         yield f"tiny source {n}", b, a, np.eye(4)
 
 
+def make_engine(params):
+    if BACKEND == "emul":
+        return emul.EmulRegistration(params)
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    p = L.HgsParams()
+    for name, _ in L.HgsParams._fields_:
+        setattr(p, name, getattr(params, name))
+    return RegistrationHIP(p)
+
+
+BACKEND = "emul"
+
+
 def run_case(name, tgt, src, T, quick):
     rng = np.random.default_rng(abs(hash(name)) % (1 << 31))
     near = T @ synth.pose_matrix(rng.normal(0, 0.1, 3), rng.normal(0, 0.01, 3))
     done = []
     # ---- exact search + covariances + GICP
     p = O.default_params(O.HGS_FAST_GICP)
-    e, o = emul.EmulRegistration(p), O.OracleRegistration(p)
+    e, o = make_engine(p), O.OracleRegistration(p)
     PC.load_pair(e, o, tgt, src)
     q = synth.xyz_of(src)
     PC.check_nn(e, o, q[:: max(1, len(q) // 4000)])
@@ -70,7 +88,7 @@ def run_case(name, tgt, src, T, quick):
         for res, search in ((1.0, O.HGS_DIRECT1), (0.5, O.HGS_DIRECT7)) + (() if quick else ((2.0, O.HGS_DIRECT27),)):
             p = O.default_params(O.HGS_FAST_VGICP)
             p.resolution, p.neighbor_search = res, search
-            e, o = emul.EmulRegistration(p), O.OracleRegistration(p)
+            e, o = make_engine(p), O.OracleRegistration(p)
             PC.load_pair(e, o, tgt, src)
             PC.check_gicp_linearize(e, o, near)
         done.append("vgicp")
@@ -78,7 +96,7 @@ def run_case(name, tgt, src, T, quick):
     for res, search in ((1.0, O.HGS_DIRECT7), (0.5, O.HGS_DIRECT1), (2.0, O.HGS_KDTREE)):
         p = O.default_params(O.HGS_NDT_OMP)
         p.resolution, p.neighbor_search, p.max_iterations = res, search, 3
-        e, o = emul.EmulRegistration(p), O.OracleRegistration(p)
+        e, o = make_engine(p), O.OracleRegistration(p)
         PC.load_pair(e, o, tgt, src)
         if len(o.ndt_cells()[0]) == 0:
             continue
@@ -97,7 +115,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=6)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--backend", default="emul", choices=["emul", "simt"])
     args = ap.parse_args()
+    global BACKEND
+    BACKEND = args.backend
+    if BACKEND == "simt":
+        from emul import simt
+        from hdl_graph_slam_amd import _lib as L
+        L.LIB_PATH, L._lib = simt.build(), None
     failures = 0
     t0 = time.time()
     for name, tgt, src, T in cases(args.seeds, args.quick):
