@@ -1,0 +1,69 @@
+"""bench.py's output contract, checked without a GPU: the script is run as the driver runs it (`python bench.py --gpus 1
+--steps K --warmup W`, and through torch.distributed.run with two ranks) against the host emulation of the kernels
+(HGS_BENCH_EMULATED_LIB, tests/emul/simt.py) on a tiny workload.  Only the shape of the JSON line is asserted — the numbers
+of an emulated run mean nothing, and the line says so in `data`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+simt = pytest.importorskip("emul.simt", reason="needs tests/emul")
+
+REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float, "higher_is_better": bool,
+            "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
+ROOFLINE = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def _run(cmd, extra_env=None):
+    lib = simt.build()
+    if lib is None:
+        pytest.skip("clang++ not available")
+    env = dict(os.environ, HGS_BENCH_EMULATED_LIB=lib, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", **(extra_env or {}))
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def _check(rec, n_gpus, steps, warmup, candidates):
+    for key, typ in REQUIRED.items():
+        assert key in rec, key
+        assert isinstance(rec[key], typ) or (typ is float and isinstance(rec[key], int)), (key, rec[key])
+    assert rec["metric"].startswith("registrations/sec") and rec["unit"] == "registrations/sec"
+    assert rec["n_gpus"] == n_gpus and rec["steps"] == steps and rec["warmup"] == warmup
+    assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["vs_baseline"] is None
+    assert "EMULATED" in rec["data"]
+    assert "workload" in rec["config"] and rec["config"]["candidates_per_gpu"] == candidates and "model" not in rec["config"]
+    assert ROOFLINE <= set(rec["roofline"]) and rec["roofline"]["bound"] in ("hbm", "mfma") and rec["roofline"]["unit"] == "GB/s"
+    assert rec["roofline"]["peak"] == 8000.0
+    # value is whole-job throughput: registrations of all ranks over the timed steps / time
+    assert abs(rec["value"] - n_gpus * candidates * steps / (rec["ms_per_step"] * 1e-3 * steps)) <= 1e-3 * rec["value"] + 1e-3
+
+
+SMALL = ["--candidates", "2", "--distinct", "2", "--sensor", "VLP-16", "--downsample", "0.5"]     # ~3 k points per keyframe
+
+
+def test_single_rank_line():
+    rec = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", *SMALL, "--cpu-sample", "1"])
+    _check(rec, 1, 2, 1, 2)
+    cpu = rec["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "registrations/sec" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert rec["roofline"]["kernel"] in ("k_gicp_linearize", "k_knn_cov", "k_ndt_derivatives", "k_fitness", "k_gicp_error")
+
+
+def test_two_ranks_through_torch_distributed_run():
+    """The N > 1 path exactly as the driver launches it: rank/world from the environment, the records all-gathered, the time
+    max-reduced over ranks, one line from rank 0, cpu_baseline null."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    rec = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *SMALL, "--method", "NDT_OMP"])
+    _check(rec, 2, 2, 1, 2)
+    assert rec["cpu_baseline"] is None and "x2" in rec["config"]["parallelism"]
