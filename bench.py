@@ -183,7 +183,8 @@ def main():
     # records and 16-byte gathers, so treat it as an upper estimate).  null when no committed counters match.
     traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.method.lower()}.json")
-    if os.path.exists(pmc_path):
+    default_workload = args.sensor == "HDL-64E" and B == 16 and not args.downsample   # what the committed counters were collected on
+    if os.path.exists(pmc_path) and default_workload:
         with open(pmc_path) as fh:
             pmc = json.load(fh)
         for kn, cv in pmc.get("kernels", {}).items():
