@@ -294,3 +294,16 @@ def test_gpu_suite_keyframe_directory(tmp_path):
 def test_gpu_suite_golden_vectors():
     _gpu_test("test_golden", "test_hip_reproduces_golden")()
     _gpu_test("test_golden", "test_hip_reproduces_golden_v2")()
+
+
+def test_graft_entry_smoke(capsys):
+    """__graft_entry__.smoke() — what the driver runs on the GPU box before the bench — against the emulated library."""
+    import importlib
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    importlib.import_module("__graft_entry__").smoke()
+    out = capsys.readouterr().out
+    assert "smoke FAST_GICP" in out and "smoke NDT_OMP" in out
