@@ -845,7 +845,7 @@ int hgs_params_default(int32_t method, hgs_params* p) {
 int hgs_create(const hgs_params* p, hgs_handle** out) {
   if (!p || !out) return HGS_ERR_INVALID_ARGUMENT;
   *out = nullptr;
-  if (p->method < HGS_FAST_GICP || p->method > HGS_NDT_OMP || p->max_iterations < 0 || p->correspondence_randomness < 1 || !(p->resolution > 0) ||
+  if (p->method < HGS_FAST_GICP || p->method > HGS_NDT_OMP || p->max_iterations < 0 || p->correspondence_randomness < 1 || p->correspondence_randomness > 64 /* k_knn_cov's largest list */ || !(p->resolution > 0) ||
       p->regularization_method < HGS_REG_FROBENIUS || p->regularization_method > HGS_REG_NONE) {
     g_create_error = "invalid hgs_params";
     return HGS_ERR_INVALID_ARGUMENT;

@@ -70,7 +70,7 @@ typedef struct hgs_params {
   double transformation_epsilon;      /* reg_transformation_epsilon       (0.01)                           */
   double rotation_epsilon;            /* fast_gicp LsqRegistration        (2e-3), not exposed by hdl       */
   double max_correspondence_distance; /* reg_max_correspondence_distance  (2.5), FAST_GICP only            */
-  int32_t correspondence_randomness;  /* reg_correspondence_randomness    (20) = k of the covariance kNN   */
+  int32_t correspondence_randomness;  /* reg_correspondence_randomness    (20) = k of the covariance kNN, 1..64 */
   int32_t neighbor_search;            /* hgs_neighbor_search: NDT (DIRECT7), VGICP (DIRECT1)               */
   double resolution;                  /* reg_resolution                   (NDT 0.5 / VGICP 1.0)            */
   double ndt_step_size;               /* pclomp NDT step_size_            (0.1)                            */
