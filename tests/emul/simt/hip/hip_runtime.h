@@ -26,7 +26,7 @@
 #define __device__
 #define __global__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local   // one block at a time PER HOST THREAD (engines driven from several threads)
 #define __launch_bounds__(...)
 #define amdgpu_waves_per_eu(...)  // __attribute__((amdgpu_waves_per_eu(n))) -> __attribute__(())
 
@@ -48,8 +48,8 @@ struct Thread {
   Idx tid;
   int lane, wave;
 };
-extern Thread* g_cur;
-extern Idx g_block, g_block_dim, g_grid_dim;
+extern thread_local Thread* g_cur;
+extern thread_local Idx g_block, g_block_dim, g_grid_dim;
 
 // all-to-all exchange of one 64-bit value among the live lanes of the calling lane's wave; returns the mask of lanes that took
 // part, out[l] = value of lane l.  `kind` must agree among the participants (a mismatch means divergent collectives).

@@ -44,8 +44,8 @@ simt_switch:
 
 namespace simt {
 
-Thread* g_cur = nullptr;
-Idx g_block = {0, 0, 0}, g_block_dim = {1, 1, 1}, g_grid_dim = {1, 1, 1};
+thread_local Thread* g_cur = nullptr;
+thread_local Idx g_block = {0, 0, 0}, g_block_dim = {1, 1, 1}, g_grid_dim = {1, 1, 1};
 
 namespace {
 
@@ -66,13 +66,14 @@ struct Wave {
   unsigned long long mask[2];
 };
 
-std::vector<Fiber> g_fibers;       // grown on demand, stacks reused between launches
-std::vector<Wave> g_waves;
-std::vector<int> g_ready;          // FIFO of runnable fibers
-size_t g_ready_head = 0;
-int g_nthreads = 0, g_block_alive = 0, g_block_arrived = 0;
-void* g_sched_sp = nullptr;
-const std::function<void()>* g_body = nullptr;
+// one scheduler per host thread: engines are independent and may be driven from different threads
+thread_local std::vector<Fiber> g_fibers;       // grown on demand, stacks reused between launches
+thread_local std::vector<Wave> g_waves;
+thread_local std::vector<int> g_ready;          // FIFO of runnable fibers
+thread_local size_t g_ready_head = 0;
+thread_local int g_nthreads = 0, g_block_alive = 0, g_block_arrived = 0;
+thread_local void* g_sched_sp = nullptr;
+thread_local const std::function<void()>* g_body = nullptr;
 
 void make_ready(int f) {
   g_fibers[f].state = READY;

@@ -313,3 +313,13 @@ def test_graft_entry_smoke(capsys):
     importlib.import_module("__graft_entry__").smoke()
     out = capsys.readouterr().out
     assert "smoke FAST_GICP" in out and "smoke NDT_OMP" in out
+
+
+def test_gpu_suite_two_engines_from_two_host_threads(gicp_case):
+    """The odometry and the loop-closure engine of one process, driven from different threads (one emulated scheduler each)."""
+    _gpu_test("test_hip_parity", "test_two_engines_run_concurrently")(gicp_case)
+
+
+def test_gpu_suite_multi_device_matcher():
+    """MultiDeviceLoopMatcher: one engine per device, one host thread per engine, records merged on the host."""
+    _gpu_test("test_distributed", "test_multi_device_matcher_equals_single_batch")()
