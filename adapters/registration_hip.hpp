@@ -65,6 +65,8 @@ public:
   void setResolution(double r) { params_.resolution = r; recreate(); }
   void setNeighborhoodSearchMethod(int hgs_neighbor_search_value) { params_.neighbor_search = hgs_neighbor_search_value; recreate(); }
   void setRotationEpsilon(double eps) { params_.rotation_epsilon = eps; recreate(); }
+  // extension: 1 = a working More-Thuente line search in NDT (ndt_omp itself never runs its loop; 0 reproduces it)
+  void setNdtLineSearch(bool on) { params_.ndt_line_search = on ? 1 : 0; recreate(); }
   // fast_gicp::FastGICP::setRegularizationMethod (hgs_regularization value); never called by hdl_graph_slam
   void setRegularizationMethod(int hgs_regularization_value) { params_.regularization_method = hgs_regularization_value; recreate(); }
 

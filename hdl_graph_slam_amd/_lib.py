@@ -32,6 +32,7 @@ class HgsParams(C.Structure):
         ("ndt_min_points_per_voxel", C.c_int32), ("ndt_upstream_hd1_sign", C.c_int32),
         ("lm_max_iterations", C.c_int32), ("lm_init_lambda_factor", C.c_double),
         ("device_id", C.c_int32), ("regularization_method", C.c_int32),
+        ("ndt_line_search", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -524,7 +524,7 @@ NdtConsts ndt_consts(const hgs_params& p) {
   c.max_iterations = p.max_iterations;
   c.search = p.neighbor_search == HGS_DIRECT1 ? 1 : (p.neighbor_search == HGS_KDTREE ? 0 : 2);
   c.kdtree_radius2 = (float)(p.resolution * p.resolution);
-  c.pad2 = 0.f;
+  c.line_search = p.ndt_line_search ? 1 : 0;
   c.upstream_hd1_sign = p.ndt_upstream_hd1_sign;
   c.pad = std::getenv("HGS_TRACE") ? 1 : 0;  // device-side per-iteration trace (parity debugging)
   return c;
@@ -732,7 +732,8 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     NdtTargetView tv;
     tv.hash_keys = tgt->ndt_hash_keys, tv.hash_vals = tgt->ndt_hash_vals, tv.cells = tgt->ndt_cells, tv.meta = tgt->desc.meta;
     tv.hash_mask = tgt->ndt_hash_cap - 1, tv.inv_leaf = 1.0f / (float)h->prm.resolution;
-    const long max_rounds = (long)c.max_iterations + 4;
+    // one derivative pass per iteration as ndt_omp runs; up to 1 + 10 with the More-Thuente search
+    const long max_rounds = ((long)c.max_iterations + 4) * (c.line_search ? 11 : 1);
     std::vector<BatchLane> lanes;
     HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
     auto finish_lane = [&](BatchLane& L) {
@@ -839,6 +840,7 @@ int hgs_params_default(int32_t method, hgs_params* p) {
   p->lm_init_lambda_factor = 1e-9;
   p->device_id = 0;
   p->regularization_method = HGS_REG_FROBENIUS;  // fast_gicp constructor default; hdl never calls the setter
+  p->ndt_line_search = 0;                        // ndt_omp as it runs
   return HGS_OK;
 }
 

@@ -89,7 +89,7 @@ struct NdtConsts {
   int upstream_hd1_sign;
   int pad;
   float kdtree_radius2;  // KDTREE: (float)(resolution^2), the radius of VoxelGridCovariance::radiusSearch
-  float pad2;
+  int line_search;       // hgs_params.ndt_line_search
 };
 
 // Neighbourhood of a transformed point (getNeighborhoodAtPoint1 / 7, or the KDTREE search of ndt_omp: a radius search of
@@ -263,6 +263,92 @@ HGS_HD void ndt_euler_xyz_f(const float* g16_colmajor, float* out) {
 // ---- per-problem Newton state machine (computeTransformation + computeStepLengthMT without the dead MT loop) --
 enum NdtPhase { NDT_DERIV = 0, NDT_DONE = 1 };
 
+// More-Thuente line search (Sun & Yuan; the structure of pcl::NormalDistributionsTransform::computeStepLengthMT /
+// trialValueSelectionMT / updateIntervalMT), one trial per derivative pass: wants_another_trial() consumes phi and its
+// directional derivative at the trial step and, if the search goes on, leaves the next trial step in a_next.  Every trial
+// is a full derivative pass, so the accepted trial's Hessian needs no separate computeHessian.  Only used with
+// hgs_params.ndt_line_search (ndt_omp itself never enters the loop).
+struct MoreThuente {
+  double phi_0, d_phi_0, a_l, f_l, g_l, a_u, f_u, g_u, a_next;
+  int open_interval, trials;
+};
+HGS_HD void mt_start(MoreThuente& m, double phi_0, double d_phi_0) {
+  HGS_FP_STRICT
+  m.phi_0 = phi_0, m.d_phi_0 = d_phi_0;
+  m.a_l = m.a_u = 0.0, m.f_l = m.f_u = 0.0;
+  m.g_l = m.g_u = d_phi_0 - 1e-4 * d_phi_0;
+  m.open_interval = 1, m.trials = 0, m.a_next = 0.0;
+}
+HGS_HD double mt_cubic(double a_l, double f_l, double g_l, double a_t, double f_t, double g_t) {
+  HGS_FP_STRICT
+  const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+  return a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+}
+HGS_HD double mt_trial_value(const MoreThuente& m, double a_t, double f_t, double g_t) {
+  HGS_FP_STRICT
+  if (f_t > m.f_l) {  // higher value: the minimum is bracketed between a_l and a_t
+    const double a_c = mt_cubic(m.a_l, m.f_l, m.g_l, a_t, f_t, g_t);
+    const double a_q = m.a_l - 0.5 * (m.a_l - a_t) * m.g_l / (m.g_l - (m.f_l - f_t) / (m.a_l - a_t));
+    return fabs(a_c - m.a_l) < fabs(a_q - m.a_l) ? a_c : 0.5 * (a_q + a_c);
+  }
+  if (g_t * m.g_l < 0) {  // lower value, derivative of opposite sign
+    const double a_c = mt_cubic(m.a_l, m.f_l, m.g_l, a_t, f_t, g_t);
+    const double a_s = m.a_l - (m.a_l - a_t) / (m.g_l - g_t) * m.g_l;
+    return fabs(a_c - a_t) >= fabs(a_s - a_t) ? a_c : a_s;
+  }
+  if (fabs(g_t) <= fabs(m.g_l)) {  // lower value, same sign, smaller derivative
+    const double a_c = mt_cubic(m.a_l, m.f_l, m.g_l, a_t, f_t, g_t);
+    const double a_s = m.a_l - (m.a_l - a_t) / (m.g_l - g_t) * m.g_l;
+    const double a_n = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
+    const double lim = a_t + 0.66 * (m.a_u - a_t);
+    return a_t > m.a_l ? (lim < a_n ? lim : a_n) : (lim > a_n ? lim : a_n);
+  }
+  return mt_cubic(m.a_u, m.f_u, m.g_u, a_t, f_t, g_t);  // lower value, same sign, larger derivative
+}
+HGS_HD bool mt_update_interval(MoreThuente& m, double a_t, double f_t, double g_t) {
+  HGS_FP_STRICT
+  if (f_t > m.f_l) {
+    m.a_u = a_t, m.f_u = f_t, m.g_u = g_t;
+    return false;
+  }
+  if (g_t * (m.a_l - a_t) > 0) {
+    m.a_l = a_t, m.f_l = f_t, m.g_l = g_t;
+    return false;
+  }
+  if (g_t * (m.a_l - a_t) < 0) {
+    m.a_u = m.a_l, m.f_u = m.f_l, m.g_u = m.g_l;
+    m.a_l = a_t, m.f_l = f_t, m.g_l = g_t;
+    return false;
+  }
+  return true;
+}
+HGS_HD bool mt_wants_another_trial(MoreThuente& m, double a_t, double phi_t, double d_phi_t, double step_max, double step_min) {
+  HGS_FP_STRICT
+  const double mu = 1e-4, nu = 0.9;
+  const double psi_t = phi_t - m.phi_0 - mu * m.d_phi_0 * a_t, d_psi_t = d_phi_t - mu * m.d_phi_0;
+  bool interval_converged;
+  if (m.trials == 0) {
+    interval_converged = (step_max - step_min) < 0;
+  } else {  // bookkeeping of the trial just evaluated (the tail of upstream's loop body)
+    if (m.open_interval && psi_t <= 0 && d_psi_t >= 0) {
+      m.open_interval = 0;
+      m.f_l += m.phi_0 - mu * m.d_phi_0 * m.a_l, m.g_l += mu * m.d_phi_0;
+      m.f_u += m.phi_0 - mu * m.d_phi_0 * m.a_u, m.g_u += mu * m.d_phi_0;
+    }
+    interval_converged = m.open_interval ? mt_update_interval(m, a_t, psi_t, d_psi_t) : mt_update_interval(m, a_t, phi_t, d_phi_t);
+  }
+  if (interval_converged || m.trials >= 10 || (psi_t <= 0 && d_phi_t <= -nu * m.d_phi_0)) return false;
+  double a = m.open_interval ? mt_trial_value(m, a_t, psi_t, d_psi_t) : mt_trial_value(m, a_t, phi_t, d_phi_t);
+  a = step_max < a ? step_max : a;  // std::min / std::max as upstream applies them (a NaN passes through)
+  a = a < step_min ? step_min : a;
+  // (not in PCL) the clamped trial is the point just evaluated, or the interpolation broke down (a_t == a_l gives 0/0): the
+  // search cannot make progress — PCL would re-evaluate the same point until the trial limit
+  if (a == a_t || a != a) return false;
+  m.a_next = a;
+  m.trials++;
+  return true;
+}
+
 struct NdtState {
   double p[6];      // parameters the NEXT derivative pass is evaluated at
   double p_acc[6];  // upstream's `p` (accumulated; differs from the evaluation point only by rounding)
@@ -275,7 +361,8 @@ struct NdtState {
   int passes;
   int converged;
   int first;  // 1 until the initial derivative pass has been consumed
-  int pad;
+  int searching;  // ndt_line_search: the pending pass is a trial of the line search described by `mt`
+  MoreThuente mt;
 };
 
 HGS_HD void ndt_state_init(NdtState& s, const float* guess_colmajor) {
@@ -287,11 +374,13 @@ HGS_HD void ndt_state_init(NdtState& s, const float* guess_colmajor) {
   s.a_t = 0, s.score = 0;
   s.final_T = pose_from_colmajor_f(guess_colmajor);
   s.phase = NDT_DERIV;
-  s.iterations = 0, s.passes = 0, s.converged = 0, s.first = 1, s.pad = 0;
+  s.iterations = 0, s.passes = 0, s.converged = 0, s.first = 1, s.searching = 0;
+  mt_start(s.mt, 0.0, 0.0);
 }
 
 // True if the pass that has just been reduced completes the final iteration (no Newton direction is needed any more).
 HGS_HD bool ndt_pass_is_last(const NdtState& s, const NdtConsts& c) {
+  if (s.searching) return false;  // the step length is not known before the trial has been judged
   return !s.first && ((s.iterations > c.max_iterations) || (s.iterations && fabs(s.a_t) < c.trans_eps));
 }
 
@@ -304,6 +393,19 @@ HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConst
   for (int i = 0; i < 6; i++) g[i] = acc[36 + i];
   s.score = acc[42];
   s.passes++;
+  if (s.searching) {
+    // this pass evaluated the trial step s.a_t along s.dp from p_acc
+    double d_phi_t = 0;
+    for (int i = 0; i < 6; i++) d_phi_t -= g[i] * s.dp[i];
+    const double step_min = c.trans_eps / 2;
+    if (mt_wants_another_trial(s.mt, s.a_t, -s.score, d_phi_t, c.step_size, step_min)) {
+      s.a_t = s.mt.a_next;
+      for (int i = 0; i < 6; i++) s.p[i] = s.p_acc[i] + s.dp[i] * s.a_t;
+      s.phase = NDT_DERIV;
+      return;
+    }
+    s.searching = 0;
+  }
   if (!s.first) {
     // finish the iteration whose step produced this pass: p += dp * a_t ; convergence test ; iter++
     for (int i = 0; i < 6; i++) s.p_acc[i] += s.dp[i] * s.a_t;
@@ -355,6 +457,10 @@ HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConst
     }
     s.a_t = a_t;
     s.phase = NDT_DERIV;
+    if (c.line_search) {
+      mt_start(s.mt, -s.score, d_phi_0 < 0 ? d_phi_0 : -d_phi_0);  // d_phi_0 of the (possibly reversed) direction
+      s.searching = 1;
+    }
     return;
   }
 }

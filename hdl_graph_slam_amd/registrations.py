@@ -58,6 +58,9 @@ def params_from_rosparams(pnh) -> L.HgsParams:
     p.max_iterations = int(get("reg_maximum_iterations", 64))
     nn = str(get("reg_nn_search_method", "DIRECT7"))
     p.neighbor_search = {"KDTREE": L.HGS_KDTREE, "DIRECT1": L.HGS_DIRECT1}.get(nn, L.HGS_DIRECT7)      # registrations.cpp:112-118
+    # Not a rosparam of the reference: ndt_omp's More-Thuente loop never executes, which is what 0 reproduces;
+    # 1 turns on a working line search (fewer, better-behaved iterations; NOT the reference's result).
+    p.ndt_line_search = 1 if get("reg_ndt_line_search", False) in (True, 1, "1", "true", "True") else 0
     return p
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 1
+#define HGS_ABI_VERSION 2
 
 enum hgs_status {
   HGS_OK = 0,
@@ -81,6 +81,10 @@ typedef struct hgs_params {
   double lm_init_lambda_factor;       /* fast_gicp                        (1e-9)                           */
   int32_t device_id;                  /* HIP device ordinal                                                */
   int32_t regularization_method;      /* hgs_regularization               (FROBENIUS), FAST_GICP / FAST_VGICP  */
+  int32_t ndt_line_search;            /* 0: ndt_omp as it runs (its More-Thuente loop never executes: every step is the
+                                         Newton direction with length clamp(|dp|, eps/2, step_size)); 1: a working
+                                         More-Thuente search (<= 10 trials, mu 1e-4, nu 0.9) — NOT the reference's result  */
+  int32_t reserved;
 } hgs_params;
 
 typedef struct hgs_result {

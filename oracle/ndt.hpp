@@ -151,6 +151,86 @@ public:
   }
 };
 
+// More-Thuente line search state (Sun & Yuan, as in pcl::NormalDistributionsTransform::computeStepLengthMT /
+// trialValueSelectionMT / updateIntervalMT), driven one trial at a time: wants_another_trial() consumes the value and
+// directional derivative of phi at the trial step a_t and, if the search goes on, leaves the next trial step in a_next.
+struct MoreThuente {
+  double phi_0, d_phi_0, a_l, f_l, g_l, a_u, f_u, g_u, a_next;
+  bool open_interval, interval_converged;
+  int trials;
+  static constexpr double mu = 1e-4, nu = 0.9;
+  static constexpr int max_trials = 10;
+  void start(double phi0, double dphi0) {
+    phi_0 = phi0, d_phi_0 = dphi0;
+    a_l = a_u = 0;
+    f_l = f_u = 0;                          // psi(0) = 0
+    g_l = g_u = dphi0 - mu * dphi0;         // dpsi(0)
+    open_interval = true, interval_converged = false, trials = 0, a_next = 0;
+  }
+  static double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
+    if (f_t > f_l) {  // case 1
+      const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
+      const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+      const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+      return std::fabs(a_c - a_l) < std::fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+    }
+    if (g_t * g_l < 0) {  // case 2
+      const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
+      const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+      const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+      return std::fabs(a_c - a_t) >= std::fabs(a_s - a_t) ? a_c : a_s;
+    }
+    if (std::fabs(g_t) <= std::fabs(g_l)) {  // case 3
+      const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = std::sqrt(z * z - g_t * g_l);
+      const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+      const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+      const double a_n = std::fabs(a_c - a_t) < std::fabs(a_s - a_t) ? a_c : a_s;
+      return a_t > a_l ? std::min(a_t + 0.66 * (a_u - a_t), a_n) : std::max(a_t + 0.66 * (a_u - a_t), a_n);
+    }
+    const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u, w = std::sqrt(z * z - g_t * g_u);  // case 4
+    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+  }
+  bool update_interval(double a_t, double f_t, double g_t) {
+    if (f_t > f_l) {
+      a_u = a_t, f_u = f_t, g_u = g_t;
+      return false;
+    }
+    if (g_t * (a_l - a_t) > 0) {
+      a_l = a_t, f_l = f_t, g_l = g_t;
+      return false;
+    }
+    if (g_t * (a_l - a_t) < 0) {
+      a_u = a_l, f_u = f_l, g_u = g_l;
+      a_l = a_t, f_l = f_t, g_l = g_t;
+      return false;
+    }
+    return true;
+  }
+  bool wants_another_trial(double a_t, double phi_t, double d_phi_t, double step_max, double step_min) {
+    const double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t, d_psi_t = d_phi_t - mu * d_phi_0;
+    if (trials == 0) {
+      interval_converged = (step_max - step_min) < 0;
+    } else {
+      // bookkeeping of the trial just evaluated (the tail of upstream's loop body)
+      if (open_interval && psi_t <= 0 && d_psi_t >= 0) {
+        open_interval = false;
+        f_l += phi_0 - mu * d_phi_0 * a_l, g_l += mu * d_phi_0;
+        f_u += phi_0 - mu * d_phi_0 * a_u, g_u += mu * d_phi_0;
+      }
+      interval_converged = open_interval ? update_interval(a_t, psi_t, d_psi_t) : update_interval(a_t, phi_t, d_phi_t);
+    }
+    if (interval_converged || trials >= max_trials || (psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) return false;
+    a_next = open_interval ? trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t) : trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+    a_next = std::min(a_next, step_max);
+    a_next = std::max(a_next, step_min);
+    // (not in PCL) the clamped trial is the point just evaluated, or the interpolation broke down (a_t == a_l gives 0/0):
+    // the search cannot make progress — PCL would re-evaluate the same point until max_trials
+    if (a_next == a_t || a_next != a_next) return false;
+    trials++;
+    return true;
+  }
+};
+
 // Eigen's MatrixBase::eulerAngles(0,1,2) (Graphics Gems IV variant) on a float rotation, as ndt_omp uses to
 // initialise p from the guess.
 // Float transcendental = the double function rounded once (a correctly rounded float result, which is what a
@@ -391,7 +471,22 @@ public:
         double xt[6];
         for (int k = 0; k < 6; k++) xt[k] = p[k] + dp.v[k] * a_t;
         finalT = ndt_pose_from_p(xt);
+        const double phi_0 = -score;
         score = derivatives(xt, g, H);
+        if (prm.ndt_line_search) {
+          // the More-Thuente loop as PCL >= 1.9 runs it (interval_converged = (step_max - step_min) < 0); every trial is a full
+          // derivative pass, so the Hessian of the accepted trial needs no separate computeHessian
+          MoreThuente mt;
+          mt.start(phi_0, d_phi_0);
+          double phi_t = -score, d_phi_t = -dot(g, dp);
+          while (mt.wants_another_trial(a_t, phi_t, d_phi_t, step_max, step_min)) {
+            a_t = mt.a_next;
+            for (int k = 0; k < 6; k++) xt[k] = p[k] + dp.v[k] * a_t;
+            finalT = ndt_pose_from_p(xt);
+            score = derivatives(xt, g, H);
+            phi_t = -score, d_phi_t = -dot(g, dp);
+          }
+        }
       }
     step_done:
       for (int k = 0; k < 6; k++) p[k] += dp.v[k] * a_t;

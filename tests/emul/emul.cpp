@@ -311,7 +311,7 @@ static NdtConsts ndt_consts(const hgs_params& p) {
   c.step_size = p.ndt_step_size, c.trans_eps = p.transformation_epsilon, c.max_iterations = p.max_iterations;
   c.search = p.neighbor_search == HGS_DIRECT1 ? 1 : (p.neighbor_search == HGS_KDTREE ? 0 : 2);
   c.upstream_hd1_sign = p.ndt_upstream_hd1_sign, c.pad = 0;
-  c.kdtree_radius2 = (float)(p.resolution * p.resolution), c.pad2 = 0.f;
+  c.kdtree_radius2 = (float)(p.resolution * p.resolution), c.line_search = p.ndt_line_search ? 1 : 0;
   return c;
 }
 

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(L):
     lib = L.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hgs_abi_version() == 1
+    assert lib.hgs_abi_version() == 2      # 2: hgs_params grew ndt_line_search
 
 
 def test_struct_layouts_match_the_header(L):
@@ -61,6 +61,7 @@ def test_rosparam_mapping_follows_registrations_cpp(L):
     p = params_from_rosparams({"registration_method": "NDT_OMP", "reg_nn_search_method": "DIRECT1", "reg_resolution": 1.0})
     assert (p.neighbor_search, p.resolution) == (L.HGS_DIRECT1, 1.0)
     assert params_from_rosparams({"reg_nn_search_method": "KDTREE"}).neighbor_search == L.HGS_KDTREE
+    assert params_from_rosparams({}).ndt_line_search == 0 and params_from_rosparams({"reg_ndt_line_search": True}).ndt_line_search == 1
     assert params_from_rosparams({"registration_method": "FAST_GICP"}).regularization_method == L.HGS_REG_FROBENIUS
     assert params_from_rosparams({"registration_method": "FAST_VGICP", "reg_regularization_method": "plane"}).regularization_method == L.HGS_REG_PLANE
     with pytest.raises(ValueError):

@@ -136,6 +136,20 @@ def ndt_case(request):
     return e, o, tgt, src, T, kind
 
 
+@pytest.mark.parametrize("kind", ["vlp16", "hdl32"])
+def test_ndt_line_search_follows_the_oracle(kind):
+    """hgs_params.ndt_line_search = 1: the More-Thuente state (interval, trial values, stop rule) lives in the device state
+    machine, one trial per derivative pass; same iterations, same number of passes, same pose as the oracle's loop."""
+    tgt, src, T = _pair(kind)
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution, p.ndt_line_search = 1.0, 1
+    e, o = emul.EmulRegistration(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    for off in ([0.0, 0.0, 0.0, 0.0], [0.3, 0.1, 0.0, 0.02], [0.1, -0.05, 0.0, 0.01], [0.02, 0.01, 0.0, 0.002]):
+        re, ro = PC.check_align(e, o, T @ synth.pose_matrix(off[:3], [0, 0, off[3]]), tol_m=1e-6, tol_rad=1e-6)
+        assert ro.lm_tries >= ro.iterations + 1
+
+
 def test_ndt_cells(ndt_case):
     e, o, *_ = ndt_case
     PC.check_ndt_cells(e, o)

@@ -230,6 +230,21 @@ def test_ndt_align(ndt_case):
     PC.check_fitness(e, o, T.astype(np.float32))
 
 
+@pytest.mark.parametrize("kind", ["vlp16", "hdl32"])
+def test_ndt_line_search_follows_the_oracle(kind):
+    """hgs_params.ndt_line_search = 1 (a working More-Thuente search, opt-in): same iterations, derivative passes and pose as
+    the oracle's loop."""
+    tgt, src, T = _pair(kind)
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution, p.ndt_line_search = 1.0, 1
+    e, o = _hip(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    for off in ([0.0, 0.0, 0.0, 0.0], [0.3, 0.1, 0.0, 0.02], [0.1, -0.05, 0.0, 0.01], [0.02, 0.01, 0.0, 0.002]):
+        re, ro = PC.check_align(e, o, T @ synth.pose_matrix(off[:3], [0, 0, off[3]]), tol_m=1e-6, tol_rad=1e-6)
+        assert ro.lm_tries >= ro.iterations + 1
+    e.close()
+
+
 def test_edge_cases():
     p = O.default_params(O.HGS_FAST_GICP)
     e = _hip(p)

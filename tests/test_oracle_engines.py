@@ -212,3 +212,15 @@ def test_ndt_align_from_close_guess(medium_pair):
     tr = r.trace()
     assert np.all(tr[:, 7] <= 0.1 + 1e-12) and np.all(tr[:, 7] >= 0.005 - 1e-12)   # step clamp [eps/2, step_size]
     assert res.lm_tries == res.iterations + 1                                      # one derivative pass per iteration + the initial one
+
+
+def test_ndt_line_search_tames_the_clamped_newton_steps(medium_pair):
+    """Opt-in More-Thuente search (hgs_params.ndt_line_search): on a guess where ndt_omp's fixed-length steps wander for 23
+    iterations the search converges in fewer iterations and closer to the ground truth; the default stays ndt_omp's."""
+    tgt, src, T = medium_pair
+    guess = T @ synth.pose_matrix([0.3, 0.1, 0.0], [0.0, 0.0, 0.02])
+    plain, searched = _ndt(tgt, src).align(guess), _ndt(tgt, src, ndt_line_search=1).align(guess)
+    assert O.default_params(O.HGS_NDT_OMP).ndt_line_search == 0
+    assert plain.lm_tries == plain.iterations + 1                      # one derivative pass per iteration
+    assert searched.converged and searched.iterations < plain.iterations and searched.lm_tries > searched.iterations + 1
+    assert synth.pose_error(searched.matrix(), T)[0] <= synth.pose_error(plain.matrix(), T)[0] + 1e-3

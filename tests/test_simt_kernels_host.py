@@ -154,6 +154,19 @@ def test_ndt(kind, res, search):
         e2.close()
 
 
+def test_ndt_line_search():
+    """The More-Thuente switch through the real k_ndt_solve / k_ndt_derivatives and the host loop's round budget."""
+    tgt, src, T = _pair("vlp16")
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution, p.ndt_line_search = 1.0, 1
+    e, o = _engine(p), O.OracleRegistration(p)
+    PC.load_pair(e, o, tgt, src)
+    for off in ([0.3, 0.1, 0.0, 0.02], [0.02, 0.01, 0.0, 0.002]):
+        re, ro = PC.check_align(e, o, T @ synth.pose_matrix(off[:3], [0, 0, off[3]]), tol_m=1e-6, tol_rad=1e-6)
+    assert ro.lm_tries > ro.iterations + 1
+    e.close()
+
+
 @pytest.mark.parametrize("method", ["FAST_GICP", "NDT_OMP"])
 def test_loop_batch_equals_the_sequential_loop(method):
     """hgs_loop_match_batch on 4 lanes (run_batch / drive_lanes / the progress mirror) against one align + getFitnessScore per
