@@ -336,3 +336,49 @@ def test_gpu_suite_two_engines_from_two_host_threads(gicp_case):
 def test_gpu_suite_multi_device_matcher():
     """MultiDeviceLoopMatcher: one engine per device, one host thread per engine, records merged on the host."""
     _gpu_test("test_distributed", "test_multi_device_matcher_equals_single_batch")()
+
+
+@pytest.mark.parametrize("n_engines", [1, 3])
+def test_cpp_loop_matcher_end_to_end(simt_library, tmp_path, n_engines):
+    """adapters/loop_match_hip.hpp — the replacement of LoopDetector::matching's loop body, with one engine per GPU driven from
+    host threads and resident keyframes reused across detections — against the Python mirror's single batch, bit for bit."""
+    import os
+    import subprocess
+    from hdl_graph_slam_amd import workloads
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "loop_match_main_simt")
+    src_cpp = os.path.join(root, "tests", "cpp", "loop_match_main.cpp")
+    deps = [src_cpp, os.path.join(root, "adapters", "loop_match_hip.hpp"), os.path.join(root, "include", "hgs_registration.h"), simt_library]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(root, "include"), src_cpp, "-o", exe,
+                        "-L", os.path.dirname(simt_library), "-l:libhgs_simt.so", f"-Wl,-rpath,{os.path.dirname(simt_library)}"], check=True)
+    wl = workloads.make_loop_closure_set("VLP-16", 3, n_candidates=5, n_distinct=3, downsample=0.4)
+    wl.target.tofile(tmp_path / "t.bin")
+    np.stack([L_colmajor(g) for g in wl.guesses]).astype(np.float32).tofile(tmp_path / "g.bin")
+    files = []
+    for i, c in enumerate(wl.candidates):
+        c.tofile(tmp_path / f"c{i}.bin")
+        files.append(str(tmp_path / f"c{i}.bin"))
+    out = subprocess.run([exe, "0", str(n_engines), str(tmp_path / "t.bin"), str(tmp_path / "g.bin"), *files], check=True, capture_output=True,
+                         text=True).stdout.splitlines()
+    reg = select_registration_method({"registration_method": "FAST_GICP"})
+    reg.setInputTarget(wl.target)
+    clouds = [reg.upload(c) for c in wl.candidates]
+    line = 0
+    for order in (list(range(5)), [4, 3, 2, 1]):
+        rec, best = reg.loop_match_batch([clouds[c] for c in order], [wl.guesses[c] for c in order], 4.0)
+        head = out[line].split()
+        assert head[0] == "best" and int(head[1]) == best and int(head[3]) == 5      # all five keyframes stay resident
+        for k, c in enumerate(order):
+            f = out[line + 1 + k].split()
+            assert int(f[0]) == c and int(f[1]) == rec["converged"][k] and int(f[2]) == rec["iterations"][k]
+            assert float(f[3]) == rec["fitness_score"][k]
+            assert np.array_equal(np.array([float(v) for v in f[4:]], np.float32), rec["final_transformation"][k])
+        line += 1 + len(order)
+    reg.close()
+
+
+def L_colmajor(T):
+    from hdl_graph_slam_amd import _lib as L
+    return L.colmajor16(T)
