@@ -144,7 +144,9 @@ void launch_pf_compact(hipStream_t s, const float4* in, int n, const unsigned* k
 void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta);
 void launch_pf_grid(hipStream_t s, unsigned* meta, float inv_leaf);
 void launch_pf_voxel_keys(hipStream_t s, const float4* pts, const int* count, const unsigned* meta, float inv_leaf, int cap, unsigned long long* keys, unsigned* vals);
-void launch_pf_voxel_heads(hipStream_t s, const unsigned long long* keys, int cap, unsigned* head);
+void launch_pf_voxel_heads(hipStream_t s, const unsigned long long* keys, int cap, unsigned* head, unsigned long long invalid_key);
+constexpr unsigned long long kVoxelInvalidKey = 0xffffffffull;  // prefilter voxel grid: 31-bit linear indices like pcl::VoxelGrid
+constexpr unsigned long long kMapInvalidKey = ~0ull;            // map cloud: up to 2^62 lattice cells
 void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* slot,
                                int cap, float4* out, int* count_out);
 void launch_pf_radius_flags(hipStream_t s, CloudDesc d, float r2, int min_neighbors, unsigned* keep);

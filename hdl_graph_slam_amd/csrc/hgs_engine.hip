@@ -1261,7 +1261,7 @@ extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t st
       h->err = "rocprim radix_sort_pairs failed";
       return HGS_ERR_HIP;
     }
-    launch_pf_voxel_heads(h->stream, h->sort_keys[1].as<unsigned long long>(), (int)n, h->pf_keep.as<unsigned>());
+    launch_pf_voxel_heads(h->stream, h->sort_keys[1].as<unsigned long long>(), (int)n, h->pf_keep.as<unsigned>(), kVoxelInvalidKey);
     HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));
     launch_pf_voxel_centroids(h->stream, cur, h->sort_keys[1].as<unsigned long long>(), h->sort_vals[1].as<unsigned>(), h->pf_keep.as<unsigned>(),
                               h->pf_slot.as<unsigned>(), (int)n, other, d_count);
@@ -1389,32 +1389,40 @@ extern "C" int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes
       HGS_HIP(h, h->sort_keys[i].reserve(total * sizeof(uint64_t)));
       HGS_HIP(h, h->sort_vals[i].reserve(total * sizeof(uint32_t)));
     }
+    // the lattice box decides how many key bits the sort has to look at (the reference's map_cloud_resolution of 0.05 / 0.01 m
+    // over a few hundred metres is 10^10 .. 10^12 cells): one small read-back, map clouds are generated every few seconds
+    int* hs = h->h_small.as<int>();
+    HGS_HIP(h, hipMemcpyAsync(hs, d_meta, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HGS_HIP(h, hipStreamSynchronize(h->stream));
+    int key_bits = 1;
+    if (hs[0] < n) {  // some finite point exists
+      const double cells = ((double)hs[4] - hs[1] + 1.0) * ((double)hs[5] - hs[2] + 1.0) * ((double)hs[6] - hs[3] + 1.0);
+      if (!(cells < 4.6e18)) {  // 2^62
+        h->err = "map cloud: resolution too fine for the extent of the map (more than 2^62 lattice cells)";
+        return HGS_ERR_INVALID_ARGUMENT;
+      }
+      while (key_bits < 63 && (double)(1ull << key_bits) <= cells) key_bits++;  // 2^key_bits > cells: all-ones stays above every cell
+    }
     launch_map_keys(h->stream, all, n, resolution, d_meta, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
     size_t tmp_bytes = 0;
     int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
-                                    h->sort_vals[1].as<uint32_t>(), total, 0, 32, h->stream);
+                                    h->sort_vals[1].as<uint32_t>(), total, 0, key_bits, h->stream);
     if (rc == 0) {
       HGS_HIP(h, h->sort_tmp.reserve(tmp_bytes));
       rc = hgs_sort_pairs_u64_u32(h->sort_tmp.p, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
-                                  h->sort_vals[1].as<uint32_t>(), total, 0, 32, h->stream);
+                                  h->sort_vals[1].as<uint32_t>(), total, 0, key_bits, h->stream);
     }
     if (rc != 0) {
       h->err = "rocprim radix_sort_pairs failed";
       return HGS_ERR_HIP;
     }
-    launch_pf_voxel_heads(h->stream, h->sort_keys[1].as<unsigned long long>(), n, h->pf_keep.as<unsigned>());
+    launch_pf_voxel_heads(h->stream, h->sort_keys[1].as<unsigned long long>(), n, h->pf_keep.as<unsigned>(), kMapInvalidKey);
     HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), total));
     launch_map_centers(h->stream, all, h->sort_keys[1].as<unsigned long long>(), h->pf_keep.as<unsigned>(), h->pf_slot.as<unsigned>(), n, resolution, d_meta,
                        h->pf_b.as<float4>(), d_count);
     HGS_HIP(h, hipGetLastError());
-    int* hs = h->h_small.as<int>();
     HGS_HIP(h, hipMemcpyAsync(hs, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HGS_HIP(h, hipMemcpyAsync(hs + 1, d_meta + 7, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HGS_HIP(h, hipStreamSynchronize(h->stream));
-    if (hs[1]) {
-      h->err = "map cloud: resolution too fine for the extent of the map (cell index overflow)";
-      return HGS_ERR_INVALID_ARGUMENT;
-    }
     m = (size_t)std::max(0, hs[0]);
     result = h->pf_b.as<float4>();
   }

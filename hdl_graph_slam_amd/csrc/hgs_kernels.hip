@@ -1129,11 +1129,12 @@ __global__ __launch_bounds__(kBlock) void k_pf_voxel_keys(const float4* __restri
   vals[i] = (unsigned)i;
 }
 // head flags of the sorted key runs (keep) — the scan of these gives each voxel its output slot
-__global__ __launch_bounds__(kBlock) void k_pf_voxel_heads(const unsigned long long* __restrict__ keys, int cap, unsigned* __restrict__ head) {
+__global__ __launch_bounds__(kBlock) void k_pf_voxel_heads(const unsigned long long* __restrict__ keys, int cap, unsigned* __restrict__ head,
+                                                           unsigned long long invalid_key) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= cap) return;
   const unsigned long long k = keys[i];
-  head[i] = (k != 0xffffffffull && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+  head[i] = (k != invalid_key && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
 }
 // one thread per voxel: float centroid of x, y, z, intensity over the run in (stable) input order
 __global__ __launch_bounds__(kBlock) void k_pf_voxel_centroids(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
@@ -1165,8 +1166,8 @@ void launch_pf_voxel_keys(hipStream_t s, const float4* pts, const int* count, co
                           unsigned* vals) {
   if (cap > 0) hipLaunchKernelGGL(k_pf_voxel_keys, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, count, meta, inv_leaf, cap, keys, vals);
 }
-void launch_pf_voxel_heads(hipStream_t s, const unsigned long long* keys, int cap, unsigned* head) {
-  if (cap > 0) hipLaunchKernelGGL(k_pf_voxel_heads, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, keys, cap, head);
+void launch_pf_voxel_heads(hipStream_t s, const unsigned long long* keys, int cap, unsigned* head, unsigned long long invalid_key) {
+  if (cap > 0) hipLaunchKernelGGL(k_pf_voxel_heads, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, keys, cap, head, invalid_key);
 }
 void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* slot,
                                int cap, float4* out, int* count_out) {
@@ -1321,16 +1322,12 @@ __global__ __launch_bounds__(kBlock) void k_map_keys(const float4* __restrict__ 
                                                      unsigned* __restrict__ vals) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  unsigned long long key = 0xffffffffull;
-  if (meta[0] < n && !meta[7]) {
-    const long long dx = (long long)meta[4] - meta[1] + 1, dy = (long long)meta[5] - meta[2] + 1, dz = (long long)meta[6] - meta[3] + 1;
-    if (dx * dy * dz > 2147483647LL) {
-      if (i == 0) meta[7] = 1;
-    } else {
-      const float4 p = pts[i];
-      long long c[3];
-      if (finite3(p) && map_cell_of(p, pts[meta[0]], res, c)) key = (unsigned long long)((c[0] - meta[1]) + (c[1] - meta[2]) * dx + (c[2] - meta[3]) * dx * dy);
-    }
+  unsigned long long key = kMapInvalidKey;  // the host has checked that the lattice box holds fewer than 2^62 cells
+  if (meta[0] < n) {
+    const long long dx = (long long)meta[4] - meta[1] + 1, dy = (long long)meta[5] - meta[2] + 1;
+    const float4 p = pts[i];
+    long long c[3];
+    if (finite3(p) && map_cell_of(p, pts[meta[0]], res, c)) key = (unsigned long long)((c[0] - meta[1]) + (c[1] - meta[2]) * dx + (c[2] - meta[3]) * dx * dy);
   }
   keys[i] = key;
   vals[i] = (unsigned)i;

@@ -59,7 +59,7 @@ inline bool map_cloud_generate(const std::vector<std::vector<PfPoint>>& keyframe
   for (auto& c : cells)
     for (int a = 0; a < 3; a++) mn[a] = std::min(mn[a], c[a]), mx[a] = std::max(mx[a], c[a]);
   const long long dx = mx[0] - mn[0] + 1, dy = mx[1] - mn[1] + 1, dz = mx[2] - mn[2] + 1;
-  if (dx * dy * dz > 2147483647LL) return false;  // the device path uses 31-bit linear cell indices
+  if (!((double)dx * (double)dy * (double)dz < 4.6e18)) return false;  // linear cell indices must fit 62 bits
   std::vector<long long> keys;
   keys.reserve(cells.size());
   for (auto& c : cells) keys.push_back((c[0] - mn[0]) + (c[1] - mn[1]) * dx + (c[2] - mn[2]) * dx * dy);

@@ -7,12 +7,12 @@ import oracle as O
 from hdl_graph_slam_amd import synth
 
 
-def _keyframes(seed=4, n_kf=3):
+def _keyframes(seed=4, n_kf=3, spacing=2.0):
     scene = synth.make_scene(seed)
     rng = np.random.default_rng(seed)
     clouds, poses = [], []
     for k in range(n_kf):
-        pose = synth.pose_matrix([2.0 * k, 0.3 * k, 0.0], [0.0, 0.0, 0.05 * k])
+        pose = synth.pose_matrix([spacing * k, 0.3 * k, 0.0], [0.0, 0.0, 0.05 * k])
         c = synth.scan(scene, "VLP-16", pose, 300 + k)[::2]
         c["intensity"] = rng.uniform(0, 255, len(c)).astype(np.float32)
         clouds.append(c)
@@ -40,6 +40,22 @@ def _np_map(clouds, poses, res):
     return out
 
 
+LARGE = dict(n_kf=3, spacing=400.0)   # 0.8 km of trajectory at the launch files' 0.05 / 0.01 m: 10^10 .. 10^12 lattice cells
+
+
+def _scan_poses(clouds, poses, spacing):
+    """_keyframes() ray-casts at the poses; for the large map the scans are simply placed `spacing` apart."""
+    return clouds, [synth.pose_matrix([spacing * k, 0.3 * k, 0.0], [0.0, 0.0, 0.05 * k]) for k in range(len(clouds))]
+
+
+@pytest.mark.parametrize("res", [0.05, 0.01])
+def test_oracle_map_cloud_beyond_31_bit_cell_indices(res):
+    clouds, poses = _scan_poses(*_keyframes(), spacing=LARGE["spacing"])
+    got = O.map_cloud(clouds, poses, res)
+    ref = _np_map(clouds, poses, res)
+    assert len(ref) > 1000 and got.shape == ref.shape and np.array_equal(got, ref, equal_nan=True)
+
+
 @pytest.mark.parametrize("res", [0.0, 0.05, 0.5])
 def test_oracle_map_cloud_matches_numpy(res):
     clouds, poses = _keyframes()
@@ -61,4 +77,10 @@ def test_hip_map_cloud_matches_oracle(res):
     got = np.stack([m["x"], m["y"], m["z"], m["intensity"]], axis=1)
     assert got.shape == ref.shape and np.array_equal(got, ref, equal_nan=True)
     assert reg.map_cloud([], [], res).size == 0
+    if res == 0.05:   # a map whose lattice box has more cells than 31 bits index (the launch files' resolution over 0.8 km)
+        clouds, poses = _scan_poses(clouds, poses, spacing=LARGE["spacing"])
+        for fine in (0.05, 0.01):
+            m = reg.map_cloud(resident, poses, fine).download()
+            ref = O.map_cloud(clouds, poses, fine)
+            assert np.array_equal(np.stack([m["x"], m["y"], m["z"], m["intensity"]], axis=1), ref, equal_nan=True)
     reg.close()

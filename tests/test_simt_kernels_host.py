@@ -302,8 +302,9 @@ def test_gpu_suite_prefilter_edges_and_download():
     _gpu_test("test_prefilter", "test_cloud_download_round_trip")()
 
 
-def test_gpu_suite_map_cloud():
-    _gpu_test("test_map_cloud", "test_hip_map_cloud_matches_oracle")(0.5)
+@pytest.mark.parametrize("res", [0.5, 0.05])
+def test_gpu_suite_map_cloud(res):
+    _gpu_test("test_map_cloud", "test_hip_map_cloud_matches_oracle")(res)      # 0.05 includes the > 2^31-cell map
 
 
 def test_gpu_suite_keyframe_directory(tmp_path):
