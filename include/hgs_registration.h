@@ -183,7 +183,8 @@ int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_bytes);
 /* Every resident keyframe cloud transformed by its pose (float 4x4, column-major, 16 floats each) and concatenated; with
  * resolution > 0 the centres of the occupied voxels of pcl::octree::OctreePointCloud(resolution) (lattice anchored on the
  * first finite point, intensity 0) in ascending (z, y, x) cell order, else the transformed points with their intensity.
- * The map stays resident (*out); fetch it with hgs_cloud_download. */
+ * The map stays resident (*out); fetch it with hgs_cloud_download.  The bounding box of the map may hold up to 2^62
+ * lattice cells (0.01 m over kilometres); HGS_ERR_INVALID_ARGUMENT beyond that. */
 int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes, const float* poses, size_t n_keyframes, double resolution, hgs_cloud** out);
 
 /* ---- measurement ---------------------------------------------------------------------------------------- */
