@@ -75,6 +75,27 @@ thread_local int g_nthreads = 0, g_block_alive = 0, g_block_arrived = 0;
 thread_local void* g_sched_sp = nullptr;
 thread_local const std::function<void()>* g_body = nullptr;
 
+// HGS_SIMT_ORDER: 0 ascending (default), 1 reverse, 2 shuffle
+int order_mode() {
+  static const int mode = [] {
+    const char* e = getenv("HGS_SIMT_ORDER");
+    if (!e) return 0;
+    if (!strncmp(e, "reverse", 7)) return 1;
+    if (!strncmp(e, "shuffle", 7)) return 2;
+    return 0;
+  }();
+  return mode;
+}
+unsigned next_random() {
+  static thread_local unsigned long long state = [] {
+    const char* e = getenv("HGS_SIMT_ORDER");
+    const char* c = e ? strchr(e, ':') : nullptr;
+    return 0x9E3779B97F4A7C15ull ^ (c ? strtoull(c + 1, nullptr, 10) : 1ull);
+  }();
+  state ^= state << 13, state ^= state >> 7, state ^= state << 17;
+  return (unsigned)(state >> 16);
+}
+
 void make_ready(int f) {
   g_fibers[f].state = READY;
   g_ready.push_back(f);
@@ -181,9 +202,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   g_body = &body;
   g_block_dim = {block.x, block.y, block.z};
   g_grid_dim = {grid.x, grid.y, grid.z};
-  for (unsigned bz = 0; bz < grid.z; bz++)
-    for (unsigned by = 0; by < grid.y; by++)
-      for (unsigned bx = 0; bx < grid.x; bx++) {
+  const bool backwards = order_mode() != 0;   // the blocks of a grid have no order either
+  for (unsigned bzi = 0; bzi < grid.z; bzi++)
+    for (unsigned byi = 0; byi < grid.y; byi++)
+      for (unsigned bxi = 0; bxi < grid.x; bxi++) {
+        const unsigned bx = backwards ? grid.x - 1 - bxi : bxi, by = backwards ? grid.y - 1 - byi : byi, bz = backwards ? grid.z - 1 - bzi : bzi;
         g_block = {bx, by, bz};
         g_ready.clear();
         g_ready_head = 0;
@@ -199,8 +222,12 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
           f.th.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
           f.th.lane = t & 63, f.th.wave = t >> 6;
           prepare(f);
-          g_ready.push_back(t);
         }
+        // start order of the fibers: ascending, or (HGS_SIMT_ORDER=reverse | shuffle[:seed]) another one — results must not
+        // depend on which wave or lane runs first (a missing barrier or an order-dependent atomic shows up as a difference)
+        for (int t = 0; t < nthreads; t++) g_ready.push_back(order_mode() == 1 ? nthreads - 1 - t : t);
+        if (order_mode() == 2)
+          for (int t = nthreads - 1; t > 0; t--) std::swap(g_ready[(size_t)t], g_ready[(size_t)(next_random() % (unsigned)(t + 1))]);
         while (g_block_alive > 0) {
           if (g_ready_head == g_ready.size()) {
             fprintf(stderr, "simt: deadlock in block (%u,%u,%u): %d threads alive, none runnable (a barrier or wave operation inside divergent code?)\n", bx,
