@@ -300,7 +300,7 @@ struct KnnGatherLane {
   }
   // after finish(): arm another walk for the next TIES equidistant points (r2_ < 0: this lane is complete)
   __device__ __forceinline__ void rearm_ties(float r2_, int ties) {
-    min_orig = tie_orig[TIES - 1] + 1;
+    min_orig = (int)((unsigned)tie_orig[TIES - 1] + 1u);  // unsigned: a lane that is complete still holds the INT_MAX sentinel
     r2 = r2_, ties_left = ties, ties_only = true;
 #pragma unroll
     for (int t = 0; t < TIES; t++) tie_orig[t] = 0x7fffffff, tie_pos[t] = -1;
