@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct ray-cast scans behind the candidates")
     ap.add_argument("--method", default="FAST_GICP", choices=["FAST_GICP", "FAST_VGICP", "NDT_OMP"])
     ap.add_argument("--downsample", type=float, default=0.0, help="voxel size applied to every keyframe (0 = raw scans, the metric's configuration)")
+    ap.add_argument("--ndt-line-search", action="store_true", help="NDT_OMP with the opt-in More-Thuente search (NOT the reference's behaviour; "
+                    "the line then says so in config.workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=3, help="candidates registered by the CPU oracle for cpu_baseline")
     args = ap.parse_args()
@@ -88,6 +90,8 @@ def main():
     pnh = {"registration_method": args.method}
     if args.method in ("NDT_OMP", "FAST_VGICP"):
         pnh["reg_resolution"] = 1.0   # launch files use 1.0 (NDT factory default 0.5)
+    if args.ndt_line_search and args.method == "NDT_OMP":
+        pnh["reg_ndt_line_search"] = True
     B = args.candidates
     # every rank holds the query keyframe (replicated target) and its own shard of the N*B candidates
     wl = workloads.make_loop_closure_set(args.sensor, scene_seed=0, n_candidates=B, n_distinct=min(args.distinct, B), downsample=args.downsample or None)
@@ -244,12 +248,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.method == "NDT_OMP" else "f64",
             "data": "synthetic" if not emulated else "synthetic (EMULATED ON THE CPU - not a measurement)",
             "config": {"workload": f"loop-closure batch: {B} candidate keyframes/GPU x {args.sensor} (~{int(np.mean(n_pts))} pts) vs 1 query keyframe, "
-                                   f"{args.method} + getFitnessScore, cold (index + covariances rebuilt every step)",
+                                   f"{args.method}{' with the opt-in More-Thuente line search (not the reference behaviour)' if pnh.get('reg_ndt_line_search') else ''}"
+                                   f" + getFitnessScore, cold (index + covariances rebuilt every step)",
                        "candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": args.method,
                        "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU"},
             "pose_rmse_vs_ground_truth": {"translation_m": round(rmse_t, 5), "rotation_rad": round(rmse_r, 6)},
             "resident_keyframes_value": round(world * B * args.steps / dt_warm, 3) if world == 1 else None,
-            "converged": int(np.sum(rec["converged"])), "mean_iterations": float(np.mean(rec["iterations"])), "best_candidate": int(best),
+            "converged": int(np.sum(rec["converged"])), "mean_iterations": float(np.mean(rec["iterations"])),
+            "mean_linearizations": float(np.mean(rec["lm_tries"])), "best_candidate": int(best),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -2,7 +2,7 @@
 # The product kernels + engine under AddressSanitizer / UndefinedBehaviorSanitizer: the emulated library (tests/emul) is built
 # with -fsanitize=address,undefined and the emulated test module runs against it, so an out-of-bounds read of a "device"
 # buffer (silent garbage on the GPU) or a signed overflow in an index computation is reported with a stack trace.
-#   bash scripts/emulated_sanitizers.sh [pytest -k expression]
+#   bash scripts/emulated_sanitizers.sh [pytest -k expression]      (-s: a sanitizer report must not be swallowed by pytest's capture)
 set -eu
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 CXX=/opt/rocm/lib/llvm/bin/clang++
@@ -21,5 +21,5 @@ cd "$ROOT"
 LD_PRELOAD="$RT/libclang_rt.asan-x86_64.so" LD_LIBRARY_PATH="$RT" ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:verify_asan_link_order=0 \
   UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 HGS_SIMT_LIB="$OUT/libhgs_simt.so" PYTHONPATH="$ROOT/tests/emul/plugins" \
   python -m pytest tests/test_hip_parity.py tests/test_prefilter.py tests/test_map_cloud.py tests/test_odometry.py tests/test_loop_detector.py \
-    tests/test_keyframe_io.py tests/test_golden.py -m gpu -p simt_everywhere -q -x \
+    tests/test_keyframe_io.py tests/test_golden.py -m gpu -p simt_everywhere -q -x -s \
     -k "${1:-not hdl32_raw and not dense and not two_engines}"   # (modules that import torch do not load under the ASan preload)

@@ -27,9 +27,10 @@ def main():
     ap.add_argument("--scans", type=int, default=40)
     ap.add_argument("--oracle-scans", type=int, default=6)
     ap.add_argument("--downsample", type=float, default=0.0)
+    ap.add_argument("--ndt-line-search", action="store_true", help="opt-in More-Thuente search (not the reference behaviour)")
     ap.add_argument("--speed", type=float, default=8.0, help="vehicle speed [m/s] at 10 Hz sweeps (8 m/s = KITTI-like 0.8 m per sweep)")
     args = ap.parse_args()
-    pnh = {"registration_method": args.method, "reg_resolution": 1.0}
+    pnh = {"registration_method": args.method, "reg_resolution": 1.0, "reg_ndt_line_search": args.ndt_line_search}
     stream = workloads.make_odometry_stream(args.sensor, 0, args.scans, speed=args.speed, downsample=args.downsample or None)
     # keyframe rule of launch/hdl_graph_slam_kitti.launch:41-43
     kf = dict(keyframe_delta_trans=5.0, keyframe_delta_angle=2.0, keyframe_delta_time=10000.0)

@@ -64,6 +64,7 @@ def test_two_ranks_through_torch_distributed_run():
     port = s.getsockname()[1]
     s.close()
     rec = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *SMALL, "--method", "NDT_OMP"])
+                os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *SMALL, "--method", "NDT_OMP", "--ndt-line-search"])
     _check(rec, 2, 2, 1, 2)
+    assert "More-Thuente" in rec["config"]["workload"] and rec["mean_linearizations"] >= rec["mean_iterations"] + 1
     assert rec["cpu_baseline"] is None and "x2" in rec["config"]["parallelism"]
