@@ -383,3 +383,35 @@ def test_cpp_loop_matcher_end_to_end(simt_library, tmp_path, n_engines):
 def L_colmajor(T):
     from hdl_graph_slam_amd import _lib as L
     return L.colmajor16(T)
+
+
+@pytest.mark.parametrize("method", [O.HGS_FAST_GICP, O.HGS_FAST_VGICP, O.HGS_NDT_OMP])
+def test_api_call_sequences(method):
+    """Orders of calls the nodelets can produce: source before target, one resident cloud as target AND source, a new target
+    with the old source, back to a cached target, invalidation between two aligns, a batch whose candidate is the target."""
+    tgt, src, T = synth.make_pair("VLP-16", 1, downsample=0.4)
+    tgt2, src2, _ = synth.make_pair("VLP-16", 2, downsample=0.4)
+    p = O.default_params(method)
+    p.resolution = 1.0
+    e, o = _engine(p), O.OracleRegistration(p)
+    tol = dict(tol_m=1e-5, tol_rad=2e-5)
+    e.setInputSource(src), o.setInputSource(src), e.setInputTarget(tgt), o.setInputTarget(tgt)
+    PC.check_align(e, o, np.eye(4), **tol)
+    c = e.upload(tgt)
+    e.setInputTarget(c), e.setInputSource(c), o.setInputTarget(tgt), o.setInputSource(tgt)
+    PC.check_align(e, o, synth.pose_matrix([0.05, 0.02, 0], [0, 0, 0.01]), **tol)
+    PC.check_fitness(e, o, np.eye(4), max_ranges=(np.finfo(np.float64).max, 1.0))
+    e.setInputTarget(tgt2), o.setInputTarget(tgt2), e.setInputSource(src2), o.setInputSource(src2)
+    PC.check_align(e, o, np.eye(4), **tol)
+    e.setInputTarget(c), o.setInputTarget(tgt), e.setInputSource(src), o.setInputSource(src)
+    r1, _ = PC.check_align(e, o, np.eye(4), **tol)
+    r2, _ = PC.check_align(e, o, np.eye(4), **tol)
+    c.invalidate()
+    r3, _ = PC.check_align(e, o, np.eye(4), **tol)
+    assert bytes(r1.final_transformation) == bytes(r2.final_transformation) == bytes(r3.final_transformation)
+    out = e.transformed_source(r1.matrix())
+    ref = synth.xyz_of(src) @ r1.matrix()[:3, :3].T.astype(np.float32) + r1.matrix()[:3, 3].astype(np.float32)
+    assert np.abs(synth.xyz_of(out) - ref).max() < 1e-4
+    rec, best = e.loop_match_batch([c], [np.eye(4, dtype=np.float32)], 1.0)
+    assert rec["converged"][0] == 1 and rec["fitness_score"][0] < 1e-4 and best == 0
+    e.close()
