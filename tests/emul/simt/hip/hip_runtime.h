@@ -70,30 +70,30 @@ static inline T from_bits(unsigned long long b) {
   memcpy(&v, &b, sizeof(T));
   return v;
 }
-static inline unsigned long long ballot(bool p) {
+static inline unsigned long long ballot(bool p, int site = 0) {
   unsigned long long all[64];
-  const unsigned long long live = wave_exchange(1, p ? 1ull : 0ull, all);
+  const unsigned long long live = wave_exchange(1 | (site << 4), p ? 1ull : 0ull, all);
   unsigned long long m = 0;
   for (int l = 0; l < 64; l++)
     if (((live >> l) & 1ull) && all[l]) m |= 1ull << l;
   return m;
 }
 template <typename T>
-static inline T shfl_down(T v, unsigned delta) {
+static inline T shfl_down(T v, unsigned delta, int site = 0) {
   unsigned long long all[64];
-  const unsigned long long live = wave_exchange(2, to_bits(v), all);
+  const unsigned long long live = wave_exchange(2 | (site << 4), to_bits(v), all);
   const unsigned src = (unsigned)g_cur->lane + delta;
   return (src < 64u && ((live >> src) & 1ull)) ? from_bits<T>(all[src]) : v;
 }
 template <typename T>
-static inline T readlane(T v, int lane) {
+static inline T readlane(T v, int lane, int site = 0) {
   unsigned long long all[64];
-  wave_exchange(3, to_bits(v), all);
+  wave_exchange(3 | (site << 4), to_bits(v), all);
   return from_bits<T>(all[lane & 63]);
 }
-static inline void wave_barrier() {
+static inline void wave_barrier(int site = 0) {
   unsigned long long all[64];
-  wave_exchange(4, 0ull, all);
+  wave_exchange(4 | (site << 4), 0ull, all);
 }
 }  // namespace simt
 
@@ -103,11 +103,13 @@ static inline void wave_barrier() {
 #define gridDim simt::g_grid_dim
 
 #define __syncthreads() simt::block_barrier()
-#define __ballot(p) simt::ballot((p) != 0)
-#define __shfl_down(v, d, ...) simt::shfl_down((v), (unsigned)(d))
+// the source line identifies the call site: lanes of one wave that meet in the same KIND of operation at different sites (an
+// operation inside divergent code) are reported, not silently combined
+#define __ballot(p) simt::ballot((p) != 0, __LINE__)
+#define __shfl_down(v, d, ...) simt::shfl_down((v), (unsigned)(d), __LINE__)
 #define __lane_id() ((unsigned)simt::g_cur->lane)
-#define __builtin_amdgcn_readlane(v, l) simt::readlane((v), (l))
-#define __builtin_amdgcn_wave_barrier() simt::wave_barrier()
+#define __builtin_amdgcn_readlane(v, l) simt::readlane((v), (l), __LINE__)
+#define __builtin_amdgcn_wave_barrier() simt::wave_barrier(__LINE__)
 #define __builtin_amdgcn_fmed3f(a, b, c) fmaxf(fminf((a), (b)), fminf(fmaxf((a), (b)), (c)))
 #define __threadfence_system() ((void)0)
 

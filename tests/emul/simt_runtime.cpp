@@ -162,8 +162,8 @@ unsigned long long wave_exchange(int kind, unsigned long long mine, unsigned lon
   const unsigned gen = w.gen, buf = gen & 1u;
   if (w.arrived == 0) w.kind = kind;
   if (w.kind != kind) {
-    fprintf(stderr, "simt: lanes of wave %d meet in different cross-lane operations (%d vs %d): divergent control flow around a wave operation\n",
-            me.th.wave, w.kind, kind);
+    fprintf(stderr, "simt: lanes of wave %d meet in different cross-lane operations (kind %d at source line %d vs kind %d at line %d): divergent "
+            "control flow around a wave operation\n", me.th.wave, w.kind & 15, w.kind >> 4, kind & 15, kind >> 4);
     abort();
   }
   w.vals[buf][me.th.lane] = mine;
