@@ -38,9 +38,9 @@ def adversarial(seed: int, base: np.ndarray) -> np.ndarray:
     return synth.to_xyzi(out[rng.permutation(len(out))])
 
 
-def cases(n_seeds: int, quick: bool):
+def cases(n_seeds: int, quick: bool, seed_base: int = 10):
     sensors = [("VLP-16", 0.1), ("VLP-16", None), ("HDL-32E", 0.25)] + ([] if quick else [("HDL-32E", None), ("HDL-64E", 0.2)])
-    for seed in range(10, 10 + n_seeds):
+    for seed in range(seed_base, seed_base + n_seeds):
         for sensor, ds in sensors:
             tgt, src, T = synth.make_pair(sensor, seed, downsample=ds)
             yield f"{sensor} seed {seed} ds {ds}", tgt, src, T
@@ -114,6 +114,7 @@ def run_case(name, tgt, src, T, quick):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=6)
+    ap.add_argument("--seed-base", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--backend", default="emul", choices=["emul", "simt"])
     args = ap.parse_args()
@@ -125,7 +126,7 @@ def main():
         L.LIB_PATH, L._lib = simt.build(), None
     failures = 0
     t0 = time.time()
-    for name, tgt, src, T in cases(args.seeds, args.quick):
+    for name, tgt, src, T in cases(args.seeds, args.quick, args.seed_base):
         t1 = time.time()
         try:
             done = run_case(name, tgt, src, T, args.quick)
