@@ -416,3 +416,19 @@ def test_api_call_sequences(method):
     rec, best = e.loop_match_batch([c], [np.eye(4, dtype=np.float32)], 1.0)
     assert rec["converged"][0] == 1 and rec["fitness_score"][0] < 1e-4 and best == 0
     e.close()
+
+
+def test_batch_records_do_not_depend_on_the_lane_count(monkeypatch):
+    """HGS_BATCH_LANES (read in hgs_create) only changes how the problems are spread over streams."""
+    from hdl_graph_slam_amd import workloads
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    wl = workloads.make_loop_closure_set("VLP-16", 3, n_candidates=6, n_distinct=3, downsample=0.5)
+    records = []
+    for lanes in ("1", "2", "4"):
+        monkeypatch.setenv("HGS_BATCH_LANES", lanes)
+        reg = select_registration_method({"registration_method": "FAST_GICP"})
+        reg.setInputTarget(wl.target)
+        rec, best = reg.loop_match_batch([reg.upload(c) for c in wl.candidates], wl.guesses, 4.0)
+        records.append((rec.tobytes(), best))
+        reg.close()
+    assert records[0] == records[1] == records[2]
