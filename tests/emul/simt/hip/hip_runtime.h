@@ -49,6 +49,7 @@ struct Thread {
   int lane, wave;
 };
 extern thread_local Thread* g_cur;
+extern unsigned long long g_record_fetches, g_waves_launched;   // statistics (fetch_record calls of lane 0, waves started)
 extern thread_local Idx g_block, g_block_dim, g_grid_dim;
 
 // all-to-all exchange of one 64-bit value among the live lanes of the calling lane's wave; returns the mask of lanes that took

@@ -45,6 +45,7 @@ simt_switch:
 namespace simt {
 
 thread_local Thread* g_cur = nullptr;
+unsigned long long g_record_fetches = 0, g_waves_launched = 0;
 thread_local Idx g_block = {0, 0, 0}, g_block_dim = {1, 1, 1}, g_grid_dim = {1, 1, 1};
 
 namespace {
@@ -217,6 +218,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
           w.live_mask = w.alive == 64 ? ~0ull : ((1ull << w.alive) - 1);
         }
         g_block_alive = nthreads, g_block_arrived = 0;
+        g_waves_launched += (unsigned long long)nwaves;
         for (int t = 0; t < nthreads; t++) {
           Fiber& f = g_fibers[t];
           f.th.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
@@ -280,4 +282,10 @@ extern "C" int hgs_exclusive_scan_u32(void* temp, size_t* temp_bytes, const uint
     s += v;
   }
   return 0;
+}
+
+// statistics for scripts/walk_steps_emulated.py: {record fetches by lane 0 = packet-walk steps, waves launched}; reset on read
+extern "C" void simt_read_counters(unsigned long long* out2) {
+  out2[0] = simt::g_record_fetches, out2[1] = simt::g_waves_launched;
+  simt::g_record_fetches = 0, simt::g_waves_launched = 0;
 }
