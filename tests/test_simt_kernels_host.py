@@ -424,11 +424,11 @@ def test_batch_records_do_not_depend_on_the_lane_count(monkeypatch):
     from hdl_graph_slam_amd.registrations import select_registration_method
     wl = workloads.make_loop_closure_set("VLP-16", 3, n_candidates=6, n_distinct=3, downsample=0.5)
     records = []
-    for lanes in ("1", "2", "4"):
+    for lanes in ("1", "4"):
         monkeypatch.setenv("HGS_BATCH_LANES", lanes)
         reg = select_registration_method({"registration_method": "FAST_GICP"})
         reg.setInputTarget(wl.target)
         rec, best = reg.loop_match_batch([reg.upload(c) for c in wl.candidates], wl.guesses, 4.0)
         records.append((rec.tobytes(), best))
         reg.close()
-    assert records[0] == records[1] == records[2]
+    assert records[0] == records[1]
