@@ -14,6 +14,7 @@ import sys, json
 r = json.loads(sys.stdin.readline()); print(r['value'], r['ms_per_step'], r['mean_iterations'], r.get('mean_linearizations'), r['pose_rmse_vs_ground_truth'])" | tee -a gpurun_out/ndt_line_search.log
   echo "== odometry HDL-64E NDT 3 m/s $ls"; timeout 300 python scripts/odometry_stream.py --sensor HDL-64E --method NDT_OMP --scans 30 --oracle-scans 2 --speed 3 $ls 2>/dev/null | tail -1 | cut -c1-600 | tee -a gpurun_out/ndt_line_search.log
 done
+echo "== odometry HDL-64E NDT 8 m/s with the KITTI prefilter (voxel 0.25, SURVEY 8d cfg 3)"; timeout 300 python scripts/odometry_stream.py --sensor HDL-64E --method NDT_OMP --scans 30 --oracle-scans 2 --downsample 0.25 2>/dev/null | tail -1 | cut -c1-600 | tee -a gpurun_out/odometry_prefilter.log
 echo "== rocprofv3 (whole-device launches)"
 (cd /tmp && HGS_BATCH_LANES=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof_lanes1" -o bench -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_lanes1.log" 2>&1); echo "prof exit $?"
 f=$(find gpurun_out/prof_lanes1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python scripts/prof_summary.py "$f" | head -12
