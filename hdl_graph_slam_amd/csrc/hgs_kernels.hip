@@ -848,7 +848,7 @@ __global__ __launch_bounds__(kNdtSolveBlock) void k_ndt_solve(const CloudDesc* d
   reduce_tiles<kAccNdt, kNdtSolveBlock>(partials + (size_t)b * max_blocks * kAccNdt, ntiles, acc, scratch);
   if (threadIdx.x >= 64) return;
   double dp_newton[6] = {0, 0, 0, 0, 0, 0};
-  if (!ndt_pass_is_last(st, c)) {  // wave-uniform
+  if (!ndt_pass_is_last(st, c, acc)) {  // wave-uniform
     double ng[6];
     for (int i = 0; i < 6; i++) ng[i] = -acc[36 + i];
     solve_svd6_wave(acc, ng, scratch, scratch + 36, dp_newton);

@@ -378,10 +378,19 @@ HGS_HD void ndt_state_init(NdtState& s, const float* guess_colmajor) {
   mt_start(s.mt, 0.0, 0.0);
 }
 
-// True if the pass that has just been reduced completes the final iteration (no Newton direction is needed any more).
-HGS_HD bool ndt_pass_is_last(const NdtState& s, const NdtConsts& c) {
-  if (s.searching) return false;  // the step length is not known before the trial has been judged
-  return !s.first && ((s.iterations > c.max_iterations) || (s.iterations && fabs(s.a_t) < c.trans_eps));
+// True if the pass that has just been reduced needs no Newton direction: it completes the final iteration, or it is a trial of
+// the line search that will be followed by another trial (judged here on a copy of the search state, exactly as
+// ndt_after_derivatives will judge it).
+HGS_HD bool ndt_pass_is_last(const NdtState& s, const NdtConsts& c, const double* acc) {
+  HGS_FP_STRICT  // the same arithmetic as ndt_after_derivatives: both must reach the same verdict
+  double a_t = s.a_t;
+  if (s.searching) {
+    MoreThuente m = s.mt;
+    double d_phi_t = 0;
+    for (int i = 0; i < 6; i++) d_phi_t -= acc[36 + i] * s.dp[i];
+    if (mt_wants_another_trial(m, s.a_t, -acc[42], d_phi_t, c.step_size, c.trans_eps / 2)) return true;
+  }
+  return !s.first && ((s.iterations > c.max_iterations) || (s.iterations && fabs(a_t) < c.trans_eps));
 }
 
 // Consumes the reduced {H, g, score} of a derivative pass evaluated at s.p and prepares the next evaluation point.
@@ -469,7 +478,7 @@ HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConst
 HGS_HD void ndt_after_derivatives(NdtState& s, const double* acc, const NdtConsts& c) {
   double ng[6], dp[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 6; i++) ng[i] = -acc[36 + i];
-  if (!ndt_pass_is_last(s, c)) solve_svd6(acc, ng, dp);
+  if (!ndt_pass_is_last(s, c, acc)) solve_svd6(acc, ng, dp);
   ndt_after_derivatives(s, acc, c, dp);
 }
 
