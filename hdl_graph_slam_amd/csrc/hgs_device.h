@@ -53,8 +53,18 @@ struct NdtTargetView {
   const int* hash_vals;
   const NdtCellRec* cells;
   const CloudMeta* meta;
+  const int2* hash_kv;  // NDT only: (key, cell index) per slot — the derivative kernel's one-load probe
   int hash_mask;
   float inv_leaf;
+};
+
+// Integer totals of one NDT derivative pass of one problem (hgs_ndt.h "exact accumulation"), in HBM: the blocks of
+// k_ndt_pass add into it with 64-bit atomics, the block that finishes last reads and clears it.
+struct NdtAccum {
+  unsigned long long w[kAccNdt][2][2];  // [accumulator][chunk][0: low 32 bits of the block sums | 1: their high parts]
+  unsigned ticket;                      // blocks of the current pass that have added their share
+  unsigned overflow;                    // a per-point term left the fixed range (or was NaN): the pass yields NaN
+  double out[kAccNdt];                  // hgs_debug_ndt_derivatives: the totals as doubles
 };
 
 struct DevResult {
@@ -108,10 +118,11 @@ void launch_ndt_cell_keys(hipStream_t s, CloudDesc desc, float inv_leaf, unsigne
 void launch_ndt_build_cells(hipStream_t s, CloudDesc desc, const unsigned long long* sorted_keys, const unsigned* sorted_vals, int min_points,
                             int* hash_keys, int* hash_vals, int hash_mask, NdtCellRec* cells);
 void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog);
-void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles, NdtConsts c,
-                            double* partials, int max_blocks, int B);
-void launch_ndt_solve(hipStream_t s, const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c, const double* partials, int max_blocks,
-                      int B, Progress prog);
+void launch_ndt_pack_hash(hipStream_t s, const int* keys, const int* vals, int2* kv, int cap);
+// one Newton iteration of B problems in one launch (derivatives + exact integer reduction + solve by the last block);
+// sorted: read the sources in Hilbert order (they have a search index); debug: only leave the totals in accum[].out
+void launch_ndt_pass(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c, NdtAccum* accum, int max_blocks,
+                     int B, int sorted, int debug, Progress prog);
 void launch_ndt_results(hipStream_t s, const CloudDesc* descs, const NdtState* states, DevResult* out, int B);
 
 void launch_vgicp_grid_params(hipStream_t s, CloudDesc desc, double resolution);

@@ -103,6 +103,7 @@ struct hgs_cloud {
   int* ndt_hash_keys = nullptr;
   int* ndt_hash_vals = nullptr;
   NdtCellRec* ndt_cells = nullptr;
+  int2* ndt_hash_kv = nullptr;
   int ndt_hash_cap = 0;
   // VGICP Gaussian voxel map (target role)
   bool has_vg = false;
@@ -139,6 +140,8 @@ struct hgs_handle {
 
   DeviceBuffer staging, sort_keys[2], sort_vals[2], sort_tmp, descs, states, angles, partials, partials_err, results, guesses, done, misc;
   DeviceBuffer lane_partials[3], lane_partials_err[3];
+  DeviceBuffer ndt_accum;  // NdtAccum per problem of the running NDT batch
+  int ndt_sort = -1;       // NDT source order: -1 Hilbert order if the source has an index, 1 build the index first, 0 input order (HGS_NDT_SORT, A/B runs)
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_descs, h_results, h_small, h_flags;  // h_flags: host-mapped progress mirror (Progress)
 
@@ -383,11 +386,13 @@ int ensure_ndt_target(hgs_handle* h, hgs_cloud* c) {
   if (!c->ndt_block || c->ndt_hash_cap != cap) {
     if (c->ndt_block) (void)hipFree(c->ndt_block);
     c->ndt_block = nullptr;
-    const size_t o_keys = 0, o_vals = align_up((size_t)cap * 4, 256), o_cells = o_vals + align_up((size_t)cap * 4, 256);
+    const size_t o_keys = 0, o_vals = align_up((size_t)cap * 4, 256), o_kv = o_vals + align_up((size_t)cap * 4, 256);
+    const size_t o_cells = o_kv + align_up((size_t)cap * 8, 256);
     const size_t bytes = o_cells + (size_t)max_cells * sizeof(NdtCellRec);
     HGS_HIP(h, hipMalloc(&c->ndt_block, bytes));
     c->ndt_hash_keys = (int*)((char*)c->ndt_block + o_keys);
     c->ndt_hash_vals = (int*)((char*)c->ndt_block + o_vals);
+    c->ndt_hash_kv = (int2*)((char*)c->ndt_block + o_kv);
     c->ndt_cells = (NdtCellRec*)((char*)c->ndt_block + o_cells);
     c->ndt_hash_cap = cap;
   }
@@ -417,6 +422,7 @@ int ensure_ndt_target(hgs_handle* h, hgs_cloud* c) {
     launch_ndt_build_cells(h->stream, c->desc, h->sort_keys[1].as<unsigned long long>(), h->sort_vals[1].as<unsigned>(), min_pts, c->ndt_hash_keys,
                            c->ndt_hash_vals, cap - 1, c->ndt_cells);
   }
+  launch_ndt_pack_hash(h->stream, c->ndt_hash_keys, c->ndt_hash_vals, c->ndt_hash_kv, cap);
   HGS_HIP(h, hipGetLastError());
   c->has_ndt = true;
   c->ndt_resolution = res;
@@ -477,9 +483,16 @@ int ensure_vgicp_target(hgs_handle* h, hgs_cloud* c) {
   return HGS_OK;
 }
 
+NdtTargetView ndt_target_view(const hgs_handle* h, const hgs_cloud* t) {
+  NdtTargetView tv;
+  tv.hash_keys = t->ndt_hash_keys, tv.hash_vals = t->ndt_hash_vals, tv.cells = t->ndt_cells, tv.meta = t->desc.meta, tv.hash_kv = t->ndt_hash_kv;
+  tv.hash_mask = t->ndt_hash_cap - 1, tv.inv_leaf = 1.0f / (float)h->prm.resolution;
+  return tv;
+}
+
 NdtTargetView vgicp_target_view(const hgs_cloud* t) {
   NdtTargetView tv;
-  tv.hash_keys = t->vg_hash_keys, tv.hash_vals = t->vg_hash_vals, tv.cells = t->vg_cells, tv.meta = t->desc.meta;
+  tv.hash_keys = t->vg_hash_keys, tv.hash_vals = t->vg_hash_vals, tv.cells = t->vg_cells, tv.meta = t->desc.meta, tv.hash_kv = nullptr;
   tv.hash_mask = t->vg_hash_cap - 1, tv.inv_leaf = 0.f;
   return tv;
 }
@@ -729,27 +742,28 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     HGS_HIP(h, h->angles.reserve((size_t)B * sizeof(NdtAngles)));
     NdtState* st = h->states.as<NdtState>();
     NdtAngles* ang = h->angles.as<NdtAngles>();
-    NdtTargetView tv;
-    tv.hash_keys = tgt->ndt_hash_keys, tv.hash_vals = tgt->ndt_hash_vals, tv.cells = tgt->ndt_cells, tv.meta = tgt->desc.meta;
-    tv.hash_mask = tgt->ndt_hash_cap - 1, tv.inv_leaf = 1.0f / (float)h->prm.resolution;
+    const NdtTargetView tv = ndt_target_view(h, tgt);
+    // the sums are order-independent (hgs_ndt.h): read the sources in Hilbert order whenever they have a search index
+    // (neighbouring lanes then share cells), in input order otherwise
+    if (h->ndt_sort == 1) HGS_TRY(ensure_index(h, sources));
+    bool sorted = h->ndt_sort != 0;
+    for (hgs_cloud* sc : sources) sorted = sorted && sc->has_index;
+    HGS_HIP(h, h->ndt_accum.reserve((size_t)B * sizeof(NdtAccum)));
+    HGS_HIP(h, hipMemsetAsync(h->ndt_accum.p, 0, (size_t)B * sizeof(NdtAccum), h->stream));
+    NdtAccum* accum = h->ndt_accum.as<NdtAccum>();
+    const int pass_blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
     // one derivative pass per iteration as ndt_omp runs; up to 1 + 10 with the More-Thuente search
     const long max_rounds = ((long)c.max_iterations + 4) * (c.line_search ? 11 : 1);
     std::vector<BatchLane> lanes;
-    HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
+    HGS_TRY(open_lanes(h, B, (size_t)max_blocks * 2 * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
     auto finish_lane = [&](BatchLane& L) {
       launch_ndt_results(L.stream, d_descs + L.b0, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
       if (fit_max_range) lane_fitness(h, L, d_descs, *fit_max_range, max_blocks, qpw, nn_tile);
     };
     for (BatchLane& L : lanes) launch_ndt_init(L.stream, st + L.b0, ang + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, c, L.B, L.prog);
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
-      {
-        StageTimer tm(h, HGS_STAGE_LINEARIZE);
-        launch_ndt_derivatives(L.stream, d_descs + L.b0, tv, st + L.b0, ang + L.b0, c, L.partials, max_blocks, L.B);
-      }
-      {
-        StageTimer tm(h, HGS_STAGE_SOLVE);
-        launch_ndt_solve(L.stream, d_descs + L.b0, st + L.b0, ang + L.b0, c, L.partials, max_blocks, L.B, L.prog);
-      }
+      StageTimer tm(h, HGS_STAGE_LINEARIZE);
+      launch_ndt_pass(L.stream, d_descs + L.b0, tv, st + L.b0, ang + L.b0, c, accum + L.b0, pass_blocks, L.B, sorted ? 1 : 0, 0, L.prog);
     }, finish_lane);
     HGS_TRY(close_lanes(h, lanes));
   }
@@ -864,6 +878,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) {
   for (int i = 0; i < 16; i++) h->final_T[i] = (i % 5 == 0) ? 1.f : 0.f;
   for (int i = 0; i < HGS_STAGE_COUNT; i++) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
   if (const char* e = std::getenv("HGS_BATCH_LANES")) h->batch_lanes = std::max(1, std::min(kMaxLanes, std::atoi(e)));  // A/B measurements
+  if (const char* e = std::getenv("HGS_NDT_SORT")) h->ndt_sort = std::max(-1, std::min(1, std::atoi(e)));
   if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     g_create_error = "hipSetDevice / hipStreamCreate failed";
     delete h;
@@ -883,7 +898,7 @@ int hgs_destroy(hgs_handle* h) {
   if (h->own_source) cloud_free(h->source);
   DeviceBuffer* bufs[] = {&h->staging, &h->sort_keys[0], &h->sort_keys[1], &h->sort_vals[0], &h->sort_vals[1], &h->sort_tmp, &h->descs, &h->states,
                           &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc,
-                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist};
+                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum};
   for (DeviceBuffer* b : bufs) b->release();
   for (int i = 0; i < 3; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
   for (hipEvent_t ev : h->lane_event)
@@ -1598,19 +1613,16 @@ int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, 
   const NdtConsts c = ndt_consts(h->prm);
   HGS_HIP(h, h->states.reserve(sizeof(NdtState)));
   HGS_HIP(h, h->angles.reserve(sizeof(NdtAngles)));
-  HGS_HIP(h, h->partials.reserve((size_t)max_blocks * kAccNdt * sizeof(double)));
+  HGS_HIP(h, h->ndt_accum.reserve(sizeof(NdtAccum)));
   HGS_HIP(h, h->misc.reserve(128 * sizeof(double)));
-  HGS_HIP(h, hipMemsetAsync(h->partials.p, 0, (size_t)max_blocks * kAccNdt * sizeof(double), h->stream));
+  HGS_HIP(h, hipMemsetAsync(h->ndt_accum.p, 0, sizeof(NdtAccum), h->stream));
   HGS_HIP(h, hipMemcpyAsync(h->misc.p, p6, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   launch_ndt_debug_state(h->stream, h->states.as<NdtState>(), h->angles.as<NdtAngles>(), h->misc.as<double>(), c);
-  NdtTargetView tv;
-  tv.hash_keys = t->ndt_hash_keys, tv.hash_vals = t->ndt_hash_vals, tv.cells = t->ndt_cells, tv.meta = t->desc.meta;
-  tv.hash_mask = t->ndt_hash_cap - 1, tv.inv_leaf = 1.0f / (float)h->prm.resolution;
-  launch_ndt_derivatives(h->stream, d_descs, tv, h->states.as<NdtState>(), h->angles.as<NdtAngles>(), c, h->partials.as<double>(), max_blocks, 1);
-  double* d_out = h->misc.as<double>() + 16;
-  launch_reduce_partials(h->stream, h->partials.as<double>(), max_blocks, kAccNdt, d_out);
+  Progress none{};
+  launch_ndt_pass(h->stream, d_descs, ndt_target_view(h, t), h->states.as<NdtState>(), h->angles.as<NdtAngles>(), c, h->ndt_accum.as<NdtAccum>(), max_blocks, 1,
+                  (h->ndt_sort != 0 && s->has_index) ? 1 : 0, 1, none);
   double acc[kAccNdt];
-  HGS_HIP(h, hipMemcpyAsync(acc, d_out, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipMemcpyAsync(acc, h->ndt_accum.as<NdtAccum>()->out, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < 36; i++) H36[i] = acc[i];
   for (int i = 0; i < 6; i++) g6[i] = acc[36 + i];

@@ -760,53 +760,15 @@ void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const f
   hipLaunchKernelGGL(k_ndt_init, dim3((B + 63) / 64), dim3(64), 0, s, states, angles, guesses, c, B, prog);
 }
 
-// computeDerivatives: per source point, transform, visit the DIRECT1/DIRECT7 cells, accumulate score / gradient /
-// Hessian.  Algorithmic bytes per source point: 16 + 7*40 = 296 (DIRECT7), 56 (DIRECT1).
-__global__ __launch_bounds__(kBlock, 2) void k_ndt_derivatives(const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles,
-                                                            NdtConsts c, double* __restrict__ partials, int max_blocks) {
-  const int b = blockIdx.y;
-  if (states[b].phase != NDT_DERIV) return;
-  const CloudDesc d = descs[b];
-  const int n = d.n_input;
-  const int ntiles = (n + kBlock - 1) / kBlock;
-  if ((int)blockIdx.x >= ntiles) return;
-  const int tile = blockIdx.x;
-  const int i = tile * kBlock + threadIdx.x;
-  __shared__ double lds[4 * kAccNdt];
-  __shared__ NdtAngles ang;
-  for (int k = threadIdx.x; k < (int)(sizeof(NdtAngles) / 4); k += kBlock) reinterpret_cast<float*>(&ang)[k] = reinterpret_cast<const float*>(&angles[b])[k];
-  __syncthreads();
-  double acc[kAccNdt];
-#pragma unroll
-  for (int k = 0; k < kAccNdt; k++) acc[k] = 0.0;
-  if (i < n) {
-    const float4 x = d.raw[i];
-    if (finite3(x)) {
-      NdtGrid g;
-      g.hash_keys = tgt.hash_keys, g.hash_vals = tgt.hash_vals, g.cells = tgt.cells, g.hash_mask = tgt.hash_mask, g.inv_leaf = tgt.inv_leaf;
-      for (int k = 0; k < 3; k++) g.min_b[k] = tgt.meta->ndt_min_b[k], g.max_b[k] = tgt.meta->ndt_max_b[k], g.div_mul[k] = tgt.meta->ndt_div_mul[k];
-      const F3 xt = transform_point_f(ang.T, x.x, x.y, x.z);
-      const int cx = (int)floorf(xt.x * g.inv_leaf), cy = (int)floorf(xt.y * g.inv_leaf), cz = (int)floorf(xt.z * g.inv_leaf);
-      NdtPointDeriv pd;
-      ndt_point_derivatives(ang, x.x, x.y, x.z, pd);
-      const int nn = ndt_num_offsets(c.search);
-      for (int o = 0; o < nn; o++) {
-        int ox, oy, oz;
-        ndt_offset(c.search, o, &ox, &oy, &oz);
-        const int ci = ndt_lookup(g, cx + ox, cy + oy, cz + oz);
-        if (ci < 0) continue;
-        const NdtCellRec rec = g.cells[ci];
-        if (!ndt_cell_in_reach(c, xt, rec.mean)) continue;
-        const float icov[6] = {rec.v0.x, rec.v0.y, rec.v0.z, rec.v0.w, rec.v1.x, rec.v1.y};
-        ndt_cell_terms(c, pd, (float)((double)xt.x - rec.mean[0]), (float)((double)xt.y - rec.mean[1]), (float)((double)xt.z - rec.mean[2]), icov, acc);
-      }
-    }
-  }
-  block_reduce_store<kAccNdt>(acc, partials + ((size_t)b * max_blocks + tile) * kAccNdt, lds);
+// hash_kv[slot] = (key, cell index): one 8-byte load per probe in the derivative kernel
+__global__ __launch_bounds__(kBlock) void k_ndt_pack_hash(const int* __restrict__ keys, const int* __restrict__ vals, int2* __restrict__ kv, int cap) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= cap) return;
+  const int k = keys[i];
+  kv[i] = make_int2(k, k == -1 ? -1 : vals[i]);
 }
-void launch_ndt_derivatives(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, const NdtState* states, const NdtAngles* angles, NdtConsts c,
-                            double* partials, int max_blocks, int B) {
-  hipLaunchKernelGGL(k_ndt_derivatives, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, angles, c, partials, max_blocks);
+void launch_ndt_pack_hash(hipStream_t s, const int* keys, const int* vals, int2* kv, int cap) {
+  hipLaunchKernelGGL(k_ndt_pack_hash, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, keys, vals, kv, cap);
 }
 
 // SVD-solve(A, b) by the calling wave: the three rotations of a Jacobi round on lanes 0..2, U and V (36 doubles each) in
@@ -834,37 +796,205 @@ __device__ __forceinline__ void solve_svd6_wave(const double* A, const double* b
   if (lane == 0) svd6_backsolve<volatile double*>(U, V, b, x);
 }
 
-__global__ __launch_bounds__(kNdtSolveBlock) void k_ndt_solve(const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c,
-                                                     const double* __restrict__ partials, int max_blocks, Progress prog) {
-  const int b = blockIdx.x;
-  NdtState& st = states[b];
-  if (st.phase != NDT_DERIV) {  // wave-uniform: finished in an earlier round
-    if (threadIdx.x == 0) progress_tick(prog, false);
+// The 64 lanes' values of four registers summed (mod 2^32) into the last lane of each 16-lane row of the result: row 0 <- a,
+// row 1 <- c, row 2 <- b, row 3 <- d.  Two transposing steps (v_permlane32_swap / v_permlane16_swap: swap halves of two
+// registers, add — one add reduces two values) and four DPP row shifts: 10 instructions for four wave reductions.
+__device__ __forceinline__ unsigned wave_sum4_u32(unsigned a, unsigned b, unsigned c, unsigned d) {
+  const auto ab = __builtin_amdgcn_permlane32_swap(a, b, false, false);  // {a.lo | b.lo}, {a.hi | b.hi}
+  const unsigned x = ab[0] + ab[1];                                      // lanes 0..31: a, lanes 32..63: b
+  const auto cd = __builtin_amdgcn_permlane32_swap(c, d, false, false);
+  const unsigned y = cd[0] + cd[1];
+  const auto xy = __builtin_amdgcn_permlane16_swap(x, y, false, false);  // rows {x0, y0, x2, y2}, {x1, y1, x3, y3}
+  unsigned z = xy[0] + xy[1];                                            // rows: a, c, b, d
+  z += __builtin_amdgcn_update_dpp(0u, z, 0x111, 0xf, 0xf, true);        // row_shr:1
+  z += __builtin_amdgcn_update_dpp(0u, z, 0x112, 0xf, 0xf, true);        // row_shr:2
+  z += __builtin_amdgcn_update_dpp(0u, z, 0x114, 0xf, 0xf, true);        // row_shr:4
+  z += __builtin_amdgcn_update_dpp(0u, z, 0x118, 0xf, 0xf, true);        // row_shr:8  -> lane 15 of each row holds the row's sum
+  return z;
+}
+
+// One NDT iteration in ONE launch (computeDerivatives + the Newton step of computeTransformation / computeStepLengthMT):
+//   1. per source point: transform, look up the DIRECT1 / DIRECT7 / KDTREE cells (all hash probes of a point are issued
+//      together, the cell records are fetched one visit ahead of the arithmetic), accumulate the point's score /
+//      gradient / Hessian over its cells in neighbourhood order (double, like ndt_omp's per-point sums);
+//   2. the per-point doubles are split into fixed-grid integer chunks (hgs_ndt.h "exact accumulation") and summed as
+//      integers: wave (wave_sum4_u32 on 25-bit digits: the sum of 64 digits fits 32 bits) -> block (LDS) -> problem
+//      (64-bit atomics in HBM).  Integer addition is associative: the totals do not depend on tiling, launch order or on
+//      the order the points are stored in, so the points are read in whatever order is resident (Hilbert order when the
+//      cloud has a search index — neighbouring lanes then share cells —, input order otherwise);
+//   3. the block that finishes last (ticket counter) turns the totals into doubles, runs the Newton step (Jacobi-SVD
+//      solve on three lanes, step clamp, convergence test, next angle tables) and ticks the batch progress.
+// Algorithmic bytes per source point: 16 + 7*40 = 296 (DIRECT7), 56 (DIRECT1); bound by VALU issue (~300 packed / fp64
+// instructions per visited cell), the cell table of a LiDAR scan is L2-resident.
+template <int NOFF>
+__device__ __forceinline__ int ndt_pop_cell(unsigned& mask, const int (&ci)[NOFF]) {
+  if (!mask) return -1;
+  const int o = __builtin_ctz(mask);
+  mask &= mask - 1u;
+  int c = ci[0];
+#pragma unroll
+  for (int k = 1; k < NOFF; k++) c = o == k ? ci[k] : c;
+  return c;
+}
+
+template <int NOFF>
+__global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restrict__ descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c,
+                                                      NdtAccum* accum, int sorted, int debug, Progress prog) {
+  const int b = blockIdx.y;
+  if (states[b].phase != NDT_DERIV) {  // finished in an earlier round
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !debug) progress_tick(prog, false);
     return;
   }
-  __shared__ double acc[kAccNdt];
-  __shared__ double scratch[kNdtSolveBlock];
-  const int ntiles = (descs[b].n_input + kBlock - 1) / kBlock;
-  reduce_tiles<kAccNdt, kNdtSolveBlock>(partials + (size_t)b * max_blocks * kAccNdt, ntiles, acc, scratch);
+  const CloudDesc d = descs[b];
+  const int n = sorted ? d.meta->nvalid : d.n_input;
+  const int ntiles = n > 0 ? (n + kBlock - 1) / kBlock : 1;  // an empty source still completes its pass (all sums zero)
+  if ((int)blockIdx.x >= ntiles) return;
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  __shared__ NdtAngles ang;
+  __shared__ unsigned s_dig[kBlock / 64][kAccNdt * 4];
+  __shared__ double s_acc[kAccNdt];
+  __shared__ double s_svd[72];
+  __shared__ int s_last;
+  for (int k = threadIdx.x; k < (int)(sizeof(NdtAngles) / 4); k += kBlock) reinterpret_cast<float*>(&ang)[k] = reinterpret_cast<const float*>(&angles[b])[k];
+  __syncthreads();
+
+  double acc[kAccNdt];
+#pragma unroll
+  for (int k = 0; k < kAccNdt; k++) acc[k] = 0.0;
+  {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    bool have = i < n;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have) x = sorted ? d.pts[i] : d.raw[i];
+    if (!sorted && !finite3(x)) have = false;
+    const F3 xt = transform_point_f(ang.T, x.x, x.y, x.z);
+    int ci[NOFF];
+    unsigned vmask = 0;
+    {
+      const CloudMeta* m = tgt.meta;
+      const int mnx = m->ndt_min_b[0], mny = m->ndt_min_b[1], mnz = m->ndt_min_b[2];
+      const int mxx = m->ndt_max_b[0], mxy = m->ndt_max_b[1], mxz = m->ndt_max_b[2];
+      const int mul1 = m->ndt_div_mul[1], mul2 = m->ndt_div_mul[2];
+      const int cx = (int)floorf(xt.x * tgt.inv_leaf), cy = (int)floorf(xt.y * tgt.inv_leaf), cz = (int)floorf(xt.z * tgt.inv_leaf);
+      int key[NOFF];
+      unsigned slot[NOFF];
+      int2 kv[NOFF];
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) {
+        int ox, oy, oz;
+        ndt_offset(c.search, o, &ox, &oy, &oz);
+        const int px = cx + ox, py = cy + oy, pz = cz + oz;
+        const bool in = have && px >= mnx && px <= mxx && py >= mny && py <= mxy && pz >= mnz && pz <= mxz;
+        key[o] = in ? (px - mnx) + (py - mny) * mul1 + (pz - mnz) * mul2 : -1;
+        slot[o] = (ndt_hash(key[o]) >> 7) & (unsigned)tgt.hash_mask;
+        kv[o] = in ? tgt.hash_kv[slot[o]] : make_int2(-1, -1);
+      }
+#pragma unroll
+      for (int o = 0; o < NOFF; o++) {
+        while (kv[o].x != key[o] && kv[o].x != -1) {  // linear probing (load factor <= 1/4: almost never taken)
+          slot[o] = (slot[o] + 1u) & (unsigned)tgt.hash_mask;
+          kv[o] = tgt.hash_kv[slot[o]];
+        }
+        ci[o] = (key[o] >= 0 && kv[o].x == key[o]) ? kv[o].y : -1;
+        if (ci[o] >= 0) vmask |= 1u << o;
+      }
+    }
+    NdtPointDeriv pd;
+    ndt_point_derivatives(ang, x.x, x.y, x.z, pd);
+    const float d1 = (float)c.gauss_d1, d2 = (float)c.gauss_d2;
+    // Visit the point's valid cells in neighbourhood order, the record of visit k+1 in flight during the arithmetic of
+    // visit k.  A counted loop with a wave-uniform early exit: the `while (any lane has a cell)` form of the same loop
+    // made the register allocator keep two copies of the 43 double sums (368 VGPRs instead of 216).
+    int cur = ndt_pop_cell<NOFF>(vmask, ci);
+    NdtCellRec rc = tgt.cells[cur >= 0 ? cur : 0];
+#pragma unroll 1
+    for (int it = 0; it < NOFF; it++) {
+      if (__ballot(cur >= 0) == 0ull) break;
+      const int nxt = ndt_pop_cell<NOFF>(vmask, ci);
+      NdtCellRec rn = rc;
+      if (nxt >= 0) rn = tgt.cells[nxt];
+      if (cur >= 0 && ndt_cell_in_reach(c, xt, rc.mean)) {
+        const float icov[6] = {rc.v0.x, rc.v0.y, rc.v0.z, rc.v0.w, rc.v1.x, rc.v1.y};
+        ndt_cell_terms_pk(d1, d2, pd, (float)((double)xt.x - rc.mean[0]), (float)((double)xt.y - rc.mean[1]), (float)((double)xt.z - rc.mean[2]), icov, acc);
+      }
+      cur = nxt;
+      rc = rn;
+    }
+  }
+
+  // ---- exact accumulation: per-point doubles -> 25-bit digits -> wave -> block -> problem --------------------------------
+  bool out_of_range = false;
+#pragma unroll
+  for (int k = 0; k < kAccNdt; k++) {
+    double m0, m1;
+    if (!ndt_exact_split(acc[k], ndt_sum_exponent(k), &m0, &m1)) out_of_range = true, m0 = m1 = kNdtMagic;
+    const unsigned long long b0 = (unsigned long long)__double_as_longlong(m0), b1 = (unsigned long long)__double_as_longlong(m1);
+    // digit = chunk mod 2^25 (low) and floor(chunk / 2^25) + constant (high): the constants of 64 lanes add up to 0 mod 2^32
+    const unsigned z = wave_sum4_u32((unsigned)b0 & 0x1ffffffu, (unsigned)(b0 >> 25), (unsigned)b1 & 0x1ffffffu, (unsigned)(b1 >> 25));
+    if ((lane & 15) == 15) s_dig[wave][k * 4 + (lane >> 4)] = z;  // rows: q0 low, q1 low, q0 high, q1 high
+  }
+  NdtAccum& A = accum[b];
+  if (__ballot(out_of_range) != 0ull && lane == 0) atomicOr(&A.overflow, 1u);
+  __syncthreads();
+  if (threadIdx.x < 2 * kAccNdt) {
+    const int k = threadIdx.x >> 1, ch = threadIdx.x & 1;
+    long long lo = 0, hi = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) lo += (long long)s_dig[w][k * 4 + ch], hi += (long long)(int)s_dig[w][k * 4 + 2 + ch];
+    const long long q = hi * (1ll << 25) + lo;  // this block's sum of chunk `ch` of accumulator k (|q| < 2^58)
+    if (q != 0) {
+      atomicAdd(&A.w[k][ch][0], (unsigned long long)q & 0xffffffffull);
+      atomicAdd(&A.w[k][ch][1], (unsigned long long)(q >> 32));
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&A.ticket, 1u) + 1u == (unsigned)ntiles) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+
+  // ---- last block of this problem: totals -> doubles, Newton step -----------------------------------------------------
+  __threadfence();
+  if (threadIdx.x < kAccNdt) {
+    const int k = threadIdx.x;
+    // read-and-clear (the next pass starts from zero): exchanges execute where the additions did
+    const unsigned long long w00 = atomicExch(&A.w[k][0][0], 0ull), w01 = atomicExch(&A.w[k][0][1], 0ull);
+    const unsigned long long w10 = atomicExch(&A.w[k][1][0], 0ull), w11 = atomicExch(&A.w[k][1][1], 0ull);
+    const __int128 s0 = (__int128)(long long)w01 * ((__int128)1 << 32) + (__int128)w00;
+    const __int128 s1 = (__int128)(long long)w11 * ((__int128)1 << 32) + (__int128)w10;
+    s_acc[k] = ndt_i128_to_double(s0 * ((__int128)1 << kNdtChunkBits) + s1, ndt_sum_exponent(k));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicExch(&A.ticket, 0u);
+    if (atomicExch(&A.overflow, 0u))
+      for (int k = 0; k < kAccNdt; k++) s_acc[k] = __longlong_as_double(0x7ff8000000000000ll);
+  }
+  __syncthreads();
+  if (debug) {
+    if (threadIdx.x < kAccNdt) A.out[threadIdx.x] = s_acc[threadIdx.x];
+    return;
+  }
   if (threadIdx.x >= 64) return;
+  NdtState& st = states[b];
   double dp_newton[6] = {0, 0, 0, 0, 0, 0};
-  if (!ndt_pass_is_last(st, c, acc)) {  // wave-uniform
+  if (!ndt_pass_is_last(st, c, s_acc)) {  // wave-uniform
     double ng[6];
-    for (int i = 0; i < 6; i++) ng[i] = -acc[36 + i];
-    solve_svd6_wave(acc, ng, scratch, scratch + 36, dp_newton);
+    for (int i = 0; i < 6; i++) ng[i] = -s_acc[36 + i];
+    solve_svd6_wave(s_acc, ng, s_svd, s_svd + 36, dp_newton);
   }
   if (threadIdx.x == 0) {
-    ndt_after_derivatives(st, acc, c, dp_newton);
-    if (c.pad)  // HGS_TRACE=1: per-iteration trace for parity debugging
-      printf("hgs ndt b=%d it=%d passes=%d p=%.9f %.9f %.9f %.9f %.9f %.9f score=%.9f a_t=%.9f phase=%d\n", b, st.iterations, st.passes, st.p[0], st.p[1],
-             st.p[2], st.p[3], st.p[4], st.p[5], st.score, st.a_t, st.phase);
+    ndt_after_derivatives(st, s_acc, c, dp_newton);
     if (st.phase != NDT_DONE) ndt_angle_tables(st.p, c.upstream_hd1_sign, angles[b]);
     progress_tick(prog, st.phase == NDT_DONE);
   }
 }
-void launch_ndt_solve(hipStream_t s, const CloudDesc* descs, NdtState* states, NdtAngles* angles, NdtConsts c, const double* partials, int max_blocks,
-                      int B, Progress prog) {
-  hipLaunchKernelGGL(k_ndt_solve, dim3(B), dim3(kNdtSolveBlock), 0, s, descs, states, angles, c, partials, max_blocks, prog);
+void launch_ndt_pass(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c, NdtAccum* accum, int max_blocks,
+                     int B, int sorted, int debug, Progress prog) {
+  const dim3 grid(max_blocks < 1 ? 1 : max_blocks, B), block(kBlock);
+  if (c.search == 1) hipLaunchKernelGGL(k_ndt_pass<1>, grid, block, 0, s, descs, tgt, states, angles, c, accum, sorted, debug, prog);
+  else if (c.search == 2) hipLaunchKernelGGL(k_ndt_pass<7>, grid, block, 0, s, descs, tgt, states, angles, c, accum, sorted, debug, prog);
+  else hipLaunchKernelGGL(k_ndt_pass<27>, grid, block, 0, s, descs, tgt, states, angles, c, accum, sorted, debug, prog);
 }
 
 __global__ void k_ndt_results(const CloudDesc* descs, const NdtState* states, DevResult* out, int B) {

@@ -2,6 +2,7 @@
 // (pclomp::NormalDistributionsTransform + VoxelGridCovariance; reference call site
 // src/hdl_graph_slam/registrations.cpp:101-120).  HGS_HD like hgs_gicp.h.
 #pragma once
+#include <string.h>
 #include "hgs_bvh.h"
 
 namespace hgs {
@@ -91,6 +92,87 @@ struct NdtConsts {
   float kdtree_radius2;  // KDTREE: (float)(resolution^2), the radius of VoxelGridCovariance::radiusSearch
   int line_search;       // hgs_params.ndt_line_search
 };
+
+// exp() of the Gaussian term as a fixed sequence of IEEE operations (round-to-even multiply, fma, rint, ldexp), so that
+// every implementation — this header on gfx950, the CPU oracle — returns the same bits; libm exp() differs between
+// the device library and glibc in the last place of a few results, and ndt_omp's iteration amplifies exactly that.
+// ndt_omp evaluates exp in float; here: Cody-Waite reduction + degree-13 Taylor polynomial in double (error < 1 ulp of the
+// double result), rounded once to float by the caller.  Only the range the float result can represent is resolved.
+HGS_HD double ndt_exp(double x) {
+  HGS_FP_STRICT
+  if (x != x) return x;
+  if (x < -110.0) return 0.0;        // below the smallest float subnormal
+  if (x > 90.0) return INFINITY;     // above FLT_MAX
+  const double kd = rint(x * 0x1.71547652b82fep+0);
+  const double r = fma(-kd, 0x1.a39ef35793c76p-33, fma(-kd, 0x1.62e42fee00000p-1, x));
+  double p = 0x1.6124613a86d09p-33;
+  p = fma(p, r, 0x1.1eed8eff8d898p-29);
+  p = fma(p, r, 0x1.ae64567f544e4p-26);
+  p = fma(p, r, 0x1.27e4fb7789f5cp-22);
+  p = fma(p, r, 0x1.71de3a556c734p-19);
+  p = fma(p, r, 0x1.a01a01a01a01ap-16);
+  p = fma(p, r, 0x1.a01a01a01a01ap-13);
+  p = fma(p, r, 0x1.6c16c16c16c17p-10);
+  p = fma(p, r, 0x1.1111111111111p-7);
+  p = fma(p, r, 0x1.5555555555555p-5);
+  p = fma(p, r, 0x1.5555555555555p-3);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kd);
+}
+
+// ---- order-independent ("exact") accumulation of the per-point score / gradient / Hessian contributions ------------
+// ndt_omp sums the N per-point doubles serially; a parallel sum re-associates them, and the Newton iteration of a weakly
+// constrained scan amplifies that last-bit difference until two implementations part.  Here every per-point double t is
+// split on a FIXED binary grid into two 50-bit integer chunks
+//     q0 = RN(t / 2^(E+50)),   q1 = RN((t - q0 2^(E+50)) / 2^E)           (what lies below 2^E is rounded away)
+// which are summed as integers — associative, so any tiling / atomics / thread order gives the same total — and the total
+// V = (sum q0) 2^50 + (sum q1) is rounded ONCE to double: result = RN(V) 2^E.  E depends only on which accumulator it is:
+// Hessian -47 (range |t| < 2^52, resolution 7e-15), gradient -51 (2^48, 4e-16), score -59 (2^40, 2e-18): finer than the
+// rounding error of the serial double sum it replaces.  A term outside its range (or NaN) poisons the pass: all sums NaN,
+// which ends the registration unconverged like a NaN Newton step does upstream.  The oracle implements the same definition
+// (oracle/ndt.hpp, sum mode "exact") independently.
+constexpr int kNdtChunkBits = 50;
+constexpr double kNdtMagic = 6755399441055744.0;  // 1.5 * 2^52: adding it leaves RN(x) in the low mantissa bits
+HGS_HD int ndt_sum_exponent(int k /* accumulator 0..42 */) { return k < 36 ? -47 : (k < 42 ? -51 : -59); }
+
+// m0 / m1 = kNdtMagic + q0 / q1 (as doubles: mantissa field = 2^51 + q); false if t is out of range or NaN.
+HGS_HD bool ndt_exact_split(double t, int E, double* m0, double* m1) {
+  HGS_FP_STRICT
+  const double s0 = ldexp(1.0, -(E + kNdtChunkBits)), S0 = ldexp(1.0, E + kNdtChunkBits), s1 = ldexp(1.0, -E);
+  const double a = fma(t, s0, kNdtMagic);
+  const double q0 = a - kNdtMagic;
+  const double r = fma(-q0, S0, t);
+  *m0 = a;
+  *m1 = fma(r, s1, kNdtMagic);
+  return fabs(t) < ldexp(1.0, E + 2 * kNdtChunkBits - 1);
+}
+HGS_HD long long ndt_chunk_of(double m) {  // the signed integer a magic-added double carries
+  unsigned long long b;
+  memcpy(&b, &m, 8);
+  return (long long)(b & 0xfffffffffffffull) - (1ll << 51);
+}
+// RN-even of the 128-bit integer V (two's complement in hi:lo), times 2^E.
+HGS_HD double ndt_i128_to_double(__int128 v, int E) {
+  if (v == 0) return 0.0;
+  const bool neg = v < 0;
+  unsigned __int128 u = neg ? (unsigned __int128)0 - (unsigned __int128)v : (unsigned __int128)v;
+  const unsigned long long hi = (unsigned long long)(u >> 64), lo = (unsigned long long)u;
+  const int hb = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);
+  double d;
+  if (hb <= 52) {
+    d = (double)lo;
+  } else {
+    const int sh = hb - 52;
+    unsigned long long m = (unsigned long long)(u >> sh);
+    const unsigned __int128 rem = u & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+    if (rem > half || (rem == half && (m & 1ull))) m++;
+    d = ldexp((double)m, sh);
+  }
+  d = ldexp(d, E);
+  return neg ? -d : d;
+}
 
 // Neighbourhood of a transformed point (getNeighborhoodAtPoint1 / 7, or the KDTREE search of ndt_omp: a radius search of
 // `resolution` around the point on the kd-tree of the valid cells' centroids).  A centroid lies inside its own cell, so
@@ -187,7 +269,7 @@ HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx
 #pragma unroll
   for (int s = 0; s < 3; s++) qC[s] = qx * C[0][s] + qy * C[1][s] + qz * C[2][s];
   const float qCq = qC[0] * qx + qC[1] * qy + qC[2] * qz;
-  float e = (float)exp((double)(-d2 * qCq * 0.5f));  // double exp rounded once: identical on CPU and GPU libm
+  float e = (float)ndt_exp((double)(-d2 * qCq * 0.5f));  // fixed-sequence double exp rounded once: same bits everywhere
   const float score_inc = -d1 * e;
   e = d2 * e;
   if (e > 1.f || e < 0.f || e != e) return;
@@ -237,6 +319,78 @@ HGS_HD void ndt_cell_terms(const NdtConsts& c, const NdtPointDeriv& pd, float qx
       acc[i * 6 + j] += (double)(e * (-d2 * qCpg[i] * qCpg[j] + qCh + pgCpg));
     }
 }
+
+#if defined(__HIPCC__)
+// updateDerivatives for one (point, cell) as the derivative kernel runs it: the SAME float operations in the SAME order as
+// ndt_cell_terms above (so the same bits), written on pairs of entries so that gfx950 issues v_pk_mul_f32 / v_pk_add_f32 —
+// two entries per VALU slot; the reference arithmetic is unfused (separate multiply and add), which is exactly what the
+// packed instructions provide.  acc[kAccNdt] are the calling point's double sums over its cells (visited in
+// neighbourhood order, like ndt_omp's per-point accumulation).
+typedef float ndt_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ndt_f2 ndt_s2(float a) { return ndt_f2{a, a}; }
+
+__device__ __forceinline__ void ndt_cell_terms_pk(float d1, float d2, const NdtPointDeriv& pd, float qx, float qy, float qz, const float* ci, double* acc) {
+#pragma clang fp contract(off)
+  const float c00 = ci[0], c01 = ci[1], c02 = ci[2], c11 = ci[3], c12 = ci[4], c22 = ci[5];
+  const ndt_f2 QX = ndt_s2(qx), QY = ndt_s2(qy), QZ = ndt_s2(qz);
+  // qC = q^T C^-1 ; entries 0,1 as a pair.  (Cpg[r][k] = C[r][k] for k < 3, so qCpg[0..2] are these same numbers.)
+  const ndt_f2 qC01 = QX * ndt_f2{c00, c01} + QY * ndt_f2{c01, c11} + QZ * ndt_f2{c02, c12};
+  const float qC2 = qx * c02 + qy * c12 + qz * c22;
+  const float qCq = qC01.x * qx + qC01.y * qy + qC2 * qz;
+  float e = (float)ndt_exp((double)(-d2 * qCq * 0.5f));
+  const float score_inc = -d1 * e;
+  e = d2 * e;
+  if (e > 1.f || e < 0.f || e != e) return;
+  e *= d1;
+  acc[42] += (double)score_inc;
+  const float pg13 = pd.xj[0], pg23 = pd.xj[1];
+  const ndt_f2 pg0_45 = {pd.xj[2], pd.xj[5]}, pg1_45 = {pd.xj[3], pd.xj[6]}, pg2_45 = {pd.xj[4], pd.xj[7]};
+  // Cpg = C^-1 * point_gradient, columns 3 | (4,5); rows 0..2
+  const ndt_f2 Cpg01_3 = ndt_f2{c01, c11} * ndt_s2(pg13) + ndt_f2{c02, c12} * ndt_s2(pg23);  // (Cpg[0][3], Cpg[1][3])
+  const float Cpg2_3 = c12 * pg13 + c22 * pg23;
+  const ndt_f2 Cpg0_45 = ndt_s2(c00) * pg0_45 + ndt_s2(c01) * pg1_45 + ndt_s2(c02) * pg2_45;
+  const ndt_f2 Cpg1_45 = ndt_s2(c01) * pg0_45 + ndt_s2(c11) * pg1_45 + ndt_s2(c12) * pg2_45;
+  const ndt_f2 Cpg2_45 = ndt_s2(c02) * pg0_45 + ndt_s2(c12) * pg1_45 + ndt_s2(c22) * pg2_45;
+  // qCpg[k] = q . Cpg[.][k]
+  const float qCpg3 = qx * Cpg01_3.x + qy * Cpg01_3.y + qz * Cpg2_3;
+  const ndt_f2 qCpg45 = QX * Cpg0_45 + QY * Cpg1_45 + QZ * Cpg2_45;
+  const ndt_f2 qCpg01 = qC01, qCpg23 = {qC2, qCpg3};
+  const ndt_f2 E2 = ndt_s2(e);
+  {
+    const ndt_f2 g01 = E2 * qCpg01, g23 = E2 * qCpg23, g45 = E2 * qCpg45;
+    acc[36] += (double)g01.x, acc[37] += (double)g01.y, acc[38] += (double)g23.x, acc[39] += (double)g23.y, acc[40] += (double)g45.x, acc[41] += (double)g45.y;
+  }
+  // q^T C^-1 (second derivatives): a, b, c have a zero first component
+  const float qC0 = qC01.x, qC1 = qC01.y;
+  const float hA = qC1 * pd.xh[0] + qC2 * pd.xh[1], hB = qC1 * pd.xh[2] + qC2 * pd.xh[3], hC = qC1 * pd.xh[4] + qC2 * pd.xh[5];
+  const float hD = qC0 * pd.xh[6] + qC1 * pd.xh[7] + qC2 * pd.xh[8], hE = qC0 * pd.xh[9] + qC1 * pd.xh[10] + qC2 * pd.xh[11],
+              hF = qC0 * pd.xh[12] + qC1 * pd.xh[13] + qC2 * pd.xh[14];
+  // Cpg by column i (rows 0..2): column i < 3 is C's, 3..5 from above
+  const float cg0[6] = {c00, c01, c02, Cpg01_3.x, Cpg0_45.x, Cpg0_45.y};
+  const float cg1[6] = {c01, c11, c12, Cpg01_3.y, Cpg1_45.x, Cpg1_45.y};
+  const float cg2[6] = {c02, c12, c22, Cpg2_3, Cpg2_45.x, Cpg2_45.y};
+  const ndt_f2 ND2 = ndt_s2(-d2);
+  const ndt_f2 u01 = ND2 * qCpg01, u23 = ND2 * qCpg23, u45 = ND2 * qCpg45;   // (-d2 * qCpg[i])
+  const float u[6] = {u01.x, u01.y, u23.x, u23.y, u45.x, u45.y};
+  const float h23[6] = {0.f, 0.f, 0.f, hA, hB, hC};                      // qCh(i, 3)
+  const ndt_f2 h45[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {hB, hC}, {hD, hE}, {hE, hF}};  // qCh(i, 4), qCh(i, 5)
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    // pg[.][j]^T Cpg[.][i] for j = 3 and (4,5)
+    const float P3 = pg13 * cg1[i] + pg23 * cg2[i];
+    const ndt_f2 P45 = pg0_45 * ndt_s2(cg0[i]) + pg1_45 * ndt_s2(cg1[i]) + pg2_45 * ndt_s2(cg2[i]);
+    const ndt_f2 U = ndt_s2(u[i]);
+    ndt_f2 t01 = U * qCpg01, t23 = U * qCpg23, t45 = U * qCpg45;
+    if (i >= 3) t23 = t23 + ndt_f2{0.f, h23[i]}, t45 = t45 + h45[i];
+    t01 = t01 + ndt_f2{cg0[i], cg1[i]};
+    t23 = t23 + ndt_f2{cg2[i], P3};
+    t45 = t45 + P45;
+    t01 = E2 * t01, t23 = E2 * t23, t45 = E2 * t45;
+    acc[i * 6 + 0] += (double)t01.x, acc[i * 6 + 1] += (double)t01.y, acc[i * 6 + 2] += (double)t23.x;
+    acc[i * 6 + 3] += (double)t23.y, acc[i * 6 + 4] += (double)t45.x, acc[i * 6 + 5] += (double)t45.y;
+  }
+}
+#endif  // __HIPCC__
 
 // Eigen's eulerAngles(0,1,2) on the float rotation of the guess (ndt_omp's initial p)
 HGS_HD void ndt_euler_xyz_f(const float* g16_colmajor, float* out) {

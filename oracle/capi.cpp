@@ -196,6 +196,13 @@ int hgso_gicp_error(hgso_handle* h, const double* T12, double* err) {
 
 // NDT: voxel table export. Returns number of valid cells; fills up to cap cells:
 // cell_ijk[3*i], mean[3*i], icov6[6*i] (xx,xy,xz,yy,yz,zz), npts[i]; sorted by linear key
+// NDT: how the per-point contributions of a derivative pass are added up: 0 = serially in double (ndt_omp, the default),
+// 1 = order-independent exact accumulation (ndt.hpp ExactSum; what a parallel backend can reproduce bit for bit)
+int hgso_ndt_set_sum_mode(hgso_handle* h, int mode) {
+  if (!h->ndt || mode < 0 || mode > 1) return 1;
+  h->ndt->sum_mode = mode;
+  return 0;
+}
 int hgso_ndt_cells(hgso_handle* h, int cap, int32_t* ijk, double* mean, double* icov6, int32_t* npts) {
   if (!h->ndt) return -1;
   const NdtVoxelGrid& g = h->ndt->grid;

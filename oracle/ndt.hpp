@@ -12,6 +12,8 @@
 //     PCL-1.8-derived code never runs: `interval_converged = (step_max - step_min) > 0`),
 //   * convergence: iter > max_iterations || (iter > 0 && step < transformation_epsilon).
 #pragma once
+#include <cstring>
+#include <limits>
 #include <unordered_map>
 #include <vector>
 #include <memory>
@@ -267,6 +269,74 @@ inline Iso ndt_pose_from_p(const double p[6]) {
   return T;
 }
 
+// exp() as a FIXED sequence of IEEE-754 operations (nothing the math library is free to round differently): Cody-Waite
+// range reduction by ln 2 (split hi/lo), degree-13 Taylor polynomial by Horner with fma, exact scaling by 2^k.  ndt_omp
+// calls float exp(); the restatement evaluates this double sequence and rounds once to float — correctly rounded except for
+// ~1e-8 of the arguments, and the same bits on every machine, which libm's exp is not.
+inline double exp_fixed(double x) {
+  if (x != x) return x;
+  if (x < -110.0) return 0.0;                                       // float result: below the smallest subnormal
+  if (x > 90.0) return std::numeric_limits<double>::infinity();     // float result: above FLT_MAX
+  const double k = std::nearbyint(x * 0x1.71547652b82fep+0);        // round half to even (default rounding mode)
+  const double r = std::fma(-k, 0x1.a39ef35793c76p-33, std::fma(-k, 0x1.62e42fee00000p-1, x));
+  static const double inv_fact[14] = {1.0, 1.0, 0.5, 0x1.5555555555555p-3, 0x1.5555555555555p-5, 0x1.1111111111111p-7, 0x1.6c16c16c16c17p-10,
+                                      0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-16, 0x1.71de3a556c734p-19, 0x1.27e4fb7789f5cp-22, 0x1.ae64567f544e4p-26,
+                                      0x1.1eed8eff8d898p-29, 0x1.6124613a86d09p-33};
+  double p = inv_fact[13];
+  for (int n = 12; n >= 0; n--) p = std::fma(p, r, inv_fact[n]);
+  return std::ldexp(p, (int)k);
+}
+
+// Order-independent total of the per-point score / gradient / Hessian contributions ("exact" sum mode).  ndt_omp adds the N
+// per-point doubles serially (sum mode 0 below restates that); any parallel implementation re-associates the sum, and the
+// iteration amplifies the resulting last-bit differences on weakly constrained scans.  Definition used by sum mode 1 — and by
+// the device backend under test, which has no other mode: every per-point double t is cut on a fixed binary grid into
+//   q0 = RN(t / 2^(E+50))  and  q1 = RN((t - q0 2^(E+50)) / 2^E)            (two 50-bit integers; bits below 2^E rounded off)
+// the q's are added as integers and V = (sum q0) 2^50 + (sum q1) is rounded to double once: total = RN(V) 2^E.
+// E = -47 for Hessian entries (|t| < 2^52), -51 for the gradient (|t| < 2^48), -59 for the score (|t| < 2^40); a term outside
+// its range, or NaN, makes every total of the pass NaN.
+struct ExactSum {
+  __int128 q0 = 0, q1 = 0;
+  int E = 0;
+  bool bad = false;
+  static constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+  static long long chunk(double magic_added) {
+    unsigned long long b;
+    std::memcpy(&b, &magic_added, 8);
+    return (long long)(b & 0xfffffffffffffull) - (1ll << 51);
+  }
+  void add(double t) {
+    if (!(std::fabs(t) < std::ldexp(1.0, E + 99))) {
+      bad = true;
+      return;
+    }
+    const double a = std::fma(t, std::ldexp(1.0, -(E + 50)), kMagic);
+    const double r = std::fma(-(a - kMagic), std::ldexp(1.0, E + 50), t);
+    const double b = std::fma(r, std::ldexp(1.0, -E), kMagic);
+    q0 += chunk(a), q1 += chunk(b);
+  }
+  double total() const {
+    const __int128 v = q0 * ((__int128)1 << 50) + q1;
+    if (v == 0) return 0.0;
+    const bool neg = v < 0;
+    unsigned __int128 u = neg ? (unsigned __int128)0 - (unsigned __int128)v : (unsigned __int128)v;
+    int hb = 127;
+    while (!((u >> hb) & 1)) hb--;
+    double d;
+    if (hb <= 52) {
+      d = (double)(unsigned long long)u;
+    } else {
+      const int sh = hb - 52;
+      unsigned long long m = (unsigned long long)(u >> sh);
+      const unsigned __int128 rem = u & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+      if (rem > half || (rem == half && (m & 1ull))) m++;  // round half to even
+      d = std::ldexp((double)m, sh);
+    }
+    d = std::ldexp(d, E);
+    return neg ? -d : d;
+  }
+};
+
 struct NdtTraceEntry {
   double p[6];
   double score;
@@ -283,6 +353,7 @@ public:
   std::vector<NdtTraceEntry> trace;
   double gauss_d1 = 0, gauss_d2 = 0;
   int derivative_passes = 0;
+  int sum_mode = 0;  // 0: serial double sum over the points (ndt_omp); 1: ExactSum (order-independent; what the device computes)
 
   void set_target(std::shared_ptr<OCloud> t) {
     target = t;
@@ -386,8 +457,8 @@ public:
         float qC[3];  // q^T C^-1 (row)
         for (int s = 0; s < 3; s++) qC[s] = q[0] * ci3[0][s] + q[1] * ci3[1][s] + q[2] * ci3[2][s];
         const float qCq = qC[0] * q[0] + qC[1] * q[1] + qC[2] * q[2];
-        // upstream: float exp(); evaluated in double and rounded once so that CPU and GPU libm agree bit-for-bit
-        float e_x_cov_x = (float)std::exp((double)(-d2 * qCq * 0.5f));
+        // upstream: float exp(); evaluated as exp_fixed in double and rounded once (same bits on every machine)
+        float e_x_cov_x = (float)exp_fixed((double)(-d2 * qCq * 0.5f));
         const float score_inc = -d1 * e_x_cov_x;
         e_x_cov_x = d2 * e_x_cov_x;
         if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
@@ -415,6 +486,33 @@ public:
     double score = 0;
     g = V6::zero();
     H = M6::zero();
+    if (sum_mode == 1) {
+      ExactSum es, eg[6], eH[6][6];
+      es.E = -59;
+      for (int r = 0; r < 6; r++) {
+        eg[r].E = -51;
+        for (int c = 0; c < 6; c++) eH[r][c].E = -47;
+      }
+      for (int i = 0; i < n; i++) {
+        es.add(scores[i]);
+        for (int r = 0; r < 6; r++) {
+          eg[r].add(gs[i].v[r]);
+          for (int c = 0; c < 6; c++) eH[r][c].add(Hs[i].m[r][c]);
+        }
+      }
+      bool bad = es.bad;
+      for (int r = 0; r < 6; r++) {
+        bad = bad || eg[r].bad;
+        for (int c = 0; c < 6; c++) bad = bad || eH[r][c].bad;
+      }
+      const double nan = std::numeric_limits<double>::quiet_NaN();
+      score = bad ? nan : es.total();
+      for (int r = 0; r < 6; r++) {
+        g.v[r] = bad ? nan : eg[r].total();
+        for (int c = 0; c < 6; c++) H.m[r][c] = bad ? nan : eH[r][c].total();
+      }
+      return score;
+    }
     for (int i = 0; i < n; i++) {  // serial, order-invariant sum like upstream
       score += scores[i];
       for (int r = 0; r < 6; r++) {

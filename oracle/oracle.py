@@ -106,6 +106,7 @@ def lib():
         L.hgso_map_cloud.restype = C.c_long
         L.hgso_ndt_cells.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hgso_ndt_set_sum_mode.argtypes = [C.c_void_p, C.c_int]
         L.hgso_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
         L.hgso_solve6.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.hgso_eig_sym3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -223,6 +224,13 @@ class OracleRegistration:
         n = lib().hgso_ndt_cells(self._h, cap, _ptr(ijk), _ptr(mean), _ptr(icov), _ptr(npts))
         n = min(n, cap)
         return ijk[:n].copy(), mean[:n].copy(), icov[:n].copy(), npts[:n].copy()
+
+    def set_ndt_sum_mode(self, mode: int):
+        """NDT: 0 = add the per-point contributions serially in double (ndt_omp; the default), 1 = order-independent exact
+        accumulation (oracle/ndt.hpp ExactSum) — the definition the device backend implements, so a whole Newton run can be
+        compared bit for bit."""
+        assert lib().hgso_ndt_set_sum_mode(self._h, int(mode)) == 0
+        return self
 
     def ndt_derivatives(self, p6):
         p = np.ascontiguousarray(p6, dtype=np.float64)

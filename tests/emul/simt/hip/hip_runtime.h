@@ -35,6 +35,11 @@ struct alignas(16) float4 {
 };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
+struct int2 {
+  int x, y;
+};
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+
 struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
@@ -92,6 +97,36 @@ static inline T readlane(T v, int lane, int site = 0) {
   wave_exchange(3 | (site << 4), to_bits(v), all);
   return from_bits<T>(all[lane & 63]);
 }
+// v_permlane32_swap / v_permlane16_swap (gfx950): {new first operand, new second operand}
+struct Pair32 {
+  unsigned v[2];
+  unsigned operator[](int i) const { return v[i]; }
+};
+static inline Pair32 permlane_swap(unsigned a, unsigned b, int width, int site = 0) {
+  unsigned long long all[64];
+  wave_exchange(5 | (site << 4), ((unsigned long long)b << 32) | a, all);
+  const int l = g_cur->lane;
+  auto A = [&](int i) { return (unsigned)all[i & 63]; };
+  auto B = [&](int i) { return (unsigned)(all[i & 63] >> 32); };
+  Pair32 r;
+  if (width == 32) {  // upper 32 lanes of the first <-> lower 32 lanes of the second
+    r.v[0] = l < 32 ? A(l) : B(l - 32);
+    r.v[1] = l < 32 ? A(l + 32) : B(l);
+  } else {            // odd 16-lane rows of the first <-> even rows of the second
+    const bool odd = (l >> 4) & 1;
+    r.v[0] = odd ? B(l - 16) : A(l);
+    r.v[1] = odd ? B(l) : A(l + 16);
+  }
+  return r;
+}
+// DPP row_shr:n with bound_ctrl (a lane whose source lies outside its 16-lane row reads 0) — the only control used
+static inline unsigned update_dpp_row_shr(unsigned src, int ctrl, int site = 0) {
+  unsigned long long all[64];
+  wave_exchange(6 | (site << 4), src, all);
+  const int l = g_cur->lane, n = ctrl & 15;
+  if (ctrl < 0x111 || ctrl > 0x11f) abort();
+  return (l & 15) >= n ? (unsigned)all[l - n] : 0u;
+}
 static inline void wave_barrier(int site = 0) {
   unsigned long long all[64];
   wave_exchange(4 | (site << 4), 0ull, all);
@@ -111,8 +146,12 @@ static inline void wave_barrier(int site = 0) {
 #define __lane_id() ((unsigned)simt::g_cur->lane)
 #define __builtin_amdgcn_readlane(v, l) simt::readlane((v), (l), __LINE__)
 #define __builtin_amdgcn_wave_barrier() simt::wave_barrier(__LINE__)
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) simt::permlane_swap((a), (b), 32, __LINE__)
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) simt::permlane_swap((a), (b), 16, __LINE__)
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt::update_dpp_row_shr((src), (ctrl), __LINE__)
 #define __builtin_amdgcn_fmed3f(a, b, c) fmaxf(fminf((a), (b)), fminf(fmaxf((a), (b)), (c)))
 #define __threadfence_system() ((void)0)
+#define __threadfence() ((void)0)
 
 template <typename T>
 static inline T min(T a, T b) {
@@ -150,6 +189,20 @@ static inline T atomicMax(T* p, T v) {
   *p = v > o ? v : o;
   return o;
 }
+template <typename T>
+static inline T atomicOr(T* p, T v) {
+  const T o = *p;
+  *p = o | v;
+  return o;
+}
+template <typename T>
+static inline T atomicExch(T* p, T v) {
+  const T o = *p;
+  *p = v;
+  return o;
+}
+static inline long long __double_as_longlong(double d) { return simt::from_bits<long long>(simt::to_bits(d)); }
+static inline double __longlong_as_double(long long i) { return simt::from_bits<double>(simt::to_bits(i)); }
 template <typename T>
 static inline T atomicCAS(T* p, T expected, T desired) {
   const T o = *p;
