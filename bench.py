@@ -171,7 +171,7 @@ def main():
         "fitness": prof_steps * sum(n_pts),
     }
     if args.method == "NDT_OMP":
-        ALG_BYTES["linearize"] = ("k_ndt_derivatives", 296.0)
+        ALG_BYTES["linearize"] = ("k_ndt_pass", 296.0)
         units["linearize"] = prof_steps * float(np.sum(rec_p["lm_tries"].astype(np.float64) * np.array(n_pts)))
         units["covariance"] = units["error"] = 0.0
     if args.method == "FAST_VGICP":
@@ -199,7 +199,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5), "traffic": None if traffic is None else round(traffic, 1), "traffic_source": traffic_src,
                 "limiter": {"FAST_GICP": "instruction issue (VALU+SALU) of the exact tree search, not HBM: see DESIGN.md section 4",
                             "FAST_VGICP": "VALU + dependent L2 round trips of the voxel hash probes, not HBM: see DESIGN.md section 4",
-                            "NDT_OMP": "VALU of the per-cell float derivative terms at 2 waves/SIMD (256 VGPRs), not HBM: see DESIGN.md section 4"}[args.method],
+                            "NDT_OMP": "VALU issue of the per-cell derivative terms (packed fp32 + fp64 accumulation, ~300 instructions per visited cell), not HBM: see DESIGN.md section 4"}[args.method],
                 "launch_config": "whole-device launches (all candidates of the rank in one launch, HIP events on the engine's stream); the timed region "
                                  "runs the same kernels split over 4 concurrent lanes, whose launches overlap each other",
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches": launches,

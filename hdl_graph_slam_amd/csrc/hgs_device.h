@@ -59,12 +59,13 @@ struct NdtTargetView {
 };
 
 // Integer totals of one NDT derivative pass of one problem (hgs_ndt.h "exact accumulation"), in HBM: the blocks of
-// k_ndt_pass add into it with 64-bit atomics, the block that finishes last reads and clears it.
+// k_ndt_pass add into it with 64-bit atomics, the block whose contribution completes the problem's tile count reads and clears it.
 struct NdtAccum {
-  unsigned long long w[kAccNdt][2][2];  // [accumulator][chunk][0: low 32 bits of the block sums | 1: their high parts]
-  unsigned ticket;                      // blocks of the current pass that have added their share
-  unsigned overflow;                    // a per-point term left the fixed range (or was NaN): the pass yields NaN
-  double out[kAccNdt];                  // hgs_debug_ndt_derivatives: the totals as doubles
+  unsigned long long w[kAccNdt * 4];  // [accumulator * 4 + {chunk0 low digits, chunk1 low, chunk0 high, chunk1 high}]
+  unsigned long long contrib;         // lanes that went through the digit code (each added 2^26 to every high-digit total)
+  unsigned tiles_done;                // tiles of the current pass accounted for
+  unsigned overflow;                  // a per-point term left the fixed range (or was NaN): the pass yields NaN
+  double out[kAccNdt];                // hgs_debug_ndt_derivatives: the totals as doubles
 };
 
 struct DevResult {
@@ -119,10 +120,12 @@ void launch_ndt_build_cells(hipStream_t s, CloudDesc desc, const unsigned long l
                             int* hash_keys, int* hash_vals, int hash_mask, NdtCellRec* cells);
 void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog);
 void launch_ndt_pack_hash(hipStream_t s, const int* keys, const int* vals, int2* kv, int cap);
-// one Newton iteration of B problems in one launch (derivatives + exact integer reduction + solve by the last block);
-// sorted: read the sources in Hilbert order (they have a search index); debug: only leave the totals in accum[].out
-void launch_ndt_pass(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c, NdtAccum* accum, int max_blocks,
-                     int B, int sorted, int debug, Progress prog);
+// one Newton iteration of B problems in one launch: `blocks` resident blocks pull chunks of `chunk` consecutive (problem, tile)
+// items — numbered by tile_base[B + 1], the prefix sums of the problems' tile counts — from *queue, whose values
+// [base, base + tile_base[B]) belong to this pass; sorted: read the sources in Hilbert order (they have a search index);
+// debug: only leave the totals in accum[].out
+void launch_ndt_pass(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c, NdtAccum* accum, const int* tile_base,
+                     unsigned long long* queue, int B, unsigned long long base, int blocks, int chunk, int sorted, int debug, Progress prog);
 void launch_ndt_results(hipStream_t s, const CloudDesc* descs, const NdtState* states, DevResult* out, int B);
 
 void launch_vgicp_grid_params(hipStream_t s, CloudDesc desc, double resolution);

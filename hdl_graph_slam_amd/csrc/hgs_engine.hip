@@ -13,7 +13,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <limits>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -141,6 +143,9 @@ struct hgs_handle {
   DeviceBuffer staging, sort_keys[2], sort_vals[2], sort_tmp, descs, states, angles, partials, partials_err, results, guesses, done, misc;
   DeviceBuffer lane_partials[3], lane_partials_err[3];
   DeviceBuffer ndt_accum;  // NdtAccum per problem of the running NDT batch
+  DeviceBuffer ndt_plan;         // per lane: work queue head + tile prefix sums of the running NDT batch
+  int ndt_resident_blocks = 512; // blocks per k_ndt_pass launch (2 per CU); HGS_NDT_RESIDENT (A/B runs)
+  int ndt_chunk = 0;             // items per queue grab (0: total / (4 * blocks), clamped to 1..8); HGS_NDT_CHUNK
   int ndt_sort = -1;       // NDT source order: -1 Hilbert order if the source has an index, 1 build the index first, 0 input order (HGS_NDT_SORT, A/B runs)
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_descs, h_results, h_small, h_flags;  // h_flags: host-mapped progress mirror (Progress)
@@ -148,6 +153,9 @@ struct hgs_handle {
   // freed cloud blocks kept for reuse: the odometry path creates and destroys one cloud per sweep, and hipMalloc /
   // hipFree (which synchronises the device) cost more than the upload itself
   std::vector<std::pair<void*, size_t>> block_pool;
+  // every cloud this engine has created and not yet destroyed: hgs_destroy orphans them (frees their device memory, clears
+  // `owner`) so that a later hgs_cloud_destroy / hgs_cloud_download on a cached pointer is safe instead of a use-after-free
+  std::vector<hgs_cloud*> live_clouds;
 
   bool profiling = false;
   std::vector<ProfEvent> prof_events;
@@ -257,20 +265,32 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   c->desc.sort_off = 0;
   c->desc.pad = 0;
   (void)hipMemsetAsync(c->desc.corr, 0xff, slots * sizeof(int), h->stream);  // no correspondences yet (-1)
+  h->live_clouds.push_back(c);
   *out = c;
   return HGS_OK;
 }
 
-void cloud_free(hgs_cloud* c) {
-  if (!c) return;
+// Releases the device memory of a cloud (the struct itself stays): what hgs_destroy does to clouds that outlive their engine.
+void cloud_release_device(hgs_cloud* c, bool pool) {
   if (c->block) {
     // stream order makes reuse safe: every kernel that touches the block was enqueued on the owner's stream
     hgs_handle* h = c->owner;
-    if (h && h->block_pool.size() < 6) h->block_pool.emplace_back(c->block, c->block_bytes);
+    if (pool && h && h->block_pool.size() < 6) h->block_pool.emplace_back(c->block, c->block_bytes);
     else (void)hipFree(c->block);
   }
   if (c->ndt_block) (void)hipFree(c->ndt_block);
   if (c->vg_block) (void)hipFree(c->vg_block);
+  c->block = nullptr, c->ndt_block = nullptr, c->vg_block = nullptr;
+  c->has_index = c->has_cov = c->has_ndt = c->has_vg = false;
+}
+
+void cloud_free(hgs_cloud* c) {
+  if (!c) return;
+  cloud_release_device(c, true);
+  if (hgs_handle* h = c->owner) {
+    auto it = std::find(h->live_clouds.begin(), h->live_clouds.end(), c);
+    if (it != h->live_clouds.end()) h->live_clouds.erase(it);
+  }
   delete c;
 }
 
@@ -751,7 +771,9 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     HGS_HIP(h, h->ndt_accum.reserve((size_t)B * sizeof(NdtAccum)));
     HGS_HIP(h, hipMemsetAsync(h->ndt_accum.p, 0, (size_t)B * sizeof(NdtAccum), h->stream));
     NdtAccum* accum = h->ndt_accum.as<NdtAccum>();
-    const int pass_blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
+    // work plan of every lane: the (problem, tile) items of a pass are numbered by the prefix sums of the problems' tile counts
+    // (from n_input: an upper bound of the finite points), and pulled from a queue in HBM whose values advance by `stride`
+    // per pass (k_ndt_pass)
     // one derivative pass per iteration as ndt_omp runs; up to 1 + 10 with the More-Thuente search
     const long max_rounds = ((long)c.max_iterations + 4) * (c.line_search ? 11 : 1);
     std::vector<BatchLane> lanes;
@@ -760,10 +782,38 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       launch_ndt_results(L.stream, d_descs + L.b0, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
       if (fit_max_range) lane_fitness(h, L, d_descs, *fit_max_range, max_blocks, qpw, nn_tile);
     };
+    struct LanePlan {
+      int* tile_base;
+      unsigned long long* queue;
+      unsigned long long stride;
+      int blocks, chunk;
+    };
+    std::vector<LanePlan> plans(lanes.size());
+    {
+      const size_t per_lane = align_up(16 + ((size_t)B + 1) * sizeof(int), 256);
+      HGS_HIP(h, h->ndt_plan.reserve(per_lane * lanes.size()));
+      std::vector<char> host(per_lane * lanes.size(), 0);
+      for (size_t li = 0; li < lanes.size(); li++) {
+        const BatchLane& L = lanes[li];
+        int* tb = reinterpret_cast<int*>(host.data() + li * per_lane + 16);
+        tb[0] = 0;
+        for (int k = 0; k < L.B; k++) tb[k + 1] = tb[k] + std::max(1, ((int)sources[L.b0 + k]->n_input + kBlock - 1) / kBlock);
+        LanePlan& P = plans[li];
+        const int total = tb[L.B];
+        P.blocks = std::max(1, std::min(total, h->ndt_resident_blocks));
+        P.chunk = h->ndt_chunk > 0 ? h->ndt_chunk : std::max(1, std::min(8, total / (P.blocks * 4)));
+        P.stride = (unsigned long long)total + (unsigned long long)(P.blocks + 1) * P.chunk;
+        P.queue = reinterpret_cast<unsigned long long*>((char*)h->ndt_plan.p + li * per_lane);
+        P.tile_base = reinterpret_cast<int*>((char*)h->ndt_plan.p + li * per_lane + 16);
+      }
+      HGS_HIP(h, hipMemcpy(h->ndt_plan.p, host.data(), host.size(), hipMemcpyHostToDevice));  // synchronous: `host` is pageable and dies here
+    }
     for (BatchLane& L : lanes) launch_ndt_init(L.stream, st + L.b0, ang + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, c, L.B, L.prog);
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       StageTimer tm(h, HGS_STAGE_LINEARIZE);
-      launch_ndt_pass(L.stream, d_descs + L.b0, tv, st + L.b0, ang + L.b0, c, accum + L.b0, pass_blocks, L.B, sorted ? 1 : 0, 0, L.prog);
+      const LanePlan& P = plans[&L - lanes.data()];
+      launch_ndt_pass(L.stream, d_descs + L.b0, tv, st + L.b0, ang + L.b0, c, accum + L.b0, P.tile_base, P.queue, L.B, (unsigned long long)L.round * P.stride, P.blocks,
+                      P.chunk, sorted ? 1 : 0, 0, L.prog);
     }, finish_lane);
     HGS_TRY(close_lanes(h, lanes));
   }
@@ -828,6 +878,28 @@ int upload_pose_as_result(hgs_handle* h, const float T[16]) {
   return HGS_OK;
 }
 
+// The C-ABI never lets a C++ exception escape into PCL / ROS frames (include/hgs_registration.h): every entry point is a
+// function-try-block whose handler ends here.  Called from inside a catch (...) handler.
+int status_of_current_exception(hgs_handle* h) noexcept {
+  int rc = HGS_ERR_INTERNAL;
+  char what[256] = "unknown C++ exception inside the backend";
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    rc = HGS_ERR_OUT_OF_MEMORY;
+    snprintf(what, sizeof(what), "out of host memory");
+  } catch (const std::exception& e) {
+    snprintf(what, sizeof(what), "C++ exception inside the backend: %s", e.what());
+  } catch (...) {
+  }
+  try {
+    if (h) h->err = what;
+    else g_create_error = what;
+  } catch (...) {
+  }
+  return rc;
+}
+
 }  // namespace
 
 // =================================================================================================== C ABI
@@ -835,7 +907,7 @@ extern "C" {
 
 int hgs_abi_version(void) { return HGS_ABI_VERSION; }
 
-int hgs_params_default(int32_t method, hgs_params* p) {
+int hgs_params_default(int32_t method, hgs_params* p) try {
   if (!p || method < HGS_FAST_GICP || method > HGS_NDT_OMP) return HGS_ERR_INVALID_ARGUMENT;
   std::memset(p, 0, sizeof(*p));
   p->method = method;
@@ -856,9 +928,11 @@ int hgs_params_default(int32_t method, hgs_params* p) {
   p->regularization_method = HGS_REG_FROBENIUS;  // fast_gicp constructor default; hdl never calls the setter
   p->ndt_line_search = 0;                        // ndt_omp as it runs
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(nullptr);
 }
 
-int hgs_create(const hgs_params* p, hgs_handle** out) {
+int hgs_create(const hgs_params* p, hgs_handle** out) try {
   if (!p || !out) return HGS_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   if (p->method < HGS_FAST_GICP || p->method > HGS_NDT_OMP || p->max_iterations < 0 || p->correspondence_randomness < 1 || p->correspondence_randomness > 64 /* k_knn_cov's largest list */ || !(p->resolution > 0) ||
@@ -879,6 +953,8 @@ int hgs_create(const hgs_params* p, hgs_handle** out) {
   for (int i = 0; i < HGS_STAGE_COUNT; i++) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
   if (const char* e = std::getenv("HGS_BATCH_LANES")) h->batch_lanes = std::max(1, std::min(kMaxLanes, std::atoi(e)));  // A/B measurements
   if (const char* e = std::getenv("HGS_NDT_SORT")) h->ndt_sort = std::max(-1, std::min(1, std::atoi(e)));
+  if (const char* e = std::getenv("HGS_NDT_RESIDENT")) h->ndt_resident_blocks = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("HGS_NDT_CHUNK")) h->ndt_chunk = std::max(0, std::atoi(e));
   if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     g_create_error = "hipSetDevice / hipStreamCreate failed";
     delete h;
@@ -886,9 +962,11 @@ int hgs_create(const hgs_params* p, hgs_handle** out) {
   }
   *out = h;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(nullptr);
 }
 
-int hgs_destroy(hgs_handle* h) {
+int hgs_destroy(hgs_handle* h) try {
   if (!h) return HGS_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -896,9 +974,17 @@ int hgs_destroy(hgs_handle* h) {
     if (ls) (void)hipStreamSynchronize(ls);
   if (h->own_target) cloud_free(h->target);
   if (h->own_source) cloud_free(h->source);
+  // clouds the caller still holds (hgs_cloud_create / hgs_prefilter results, cached keyframes): their device memory goes with
+  // the engine, the structs stay valid as orphans — hgs_cloud_destroy frees them, every other call rejects them
+  for (hgs_cloud* c : h->live_clouds) {
+    cloud_release_device(c, false);
+    c->owner = nullptr;
+    c->n_input = 0;
+  }
+  h->live_clouds.clear();
   DeviceBuffer* bufs[] = {&h->staging, &h->sort_keys[0], &h->sort_keys[1], &h->sort_vals[0], &h->sort_vals[1], &h->sort_tmp, &h->descs, &h->states,
                           &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc,
-                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum};
+                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum,    &h->ndt_plan};
   for (DeviceBuffer* b : bufs) b->release();
   for (int i = 0; i < 3; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
   for (hipEvent_t ev : h->lane_event)
@@ -916,11 +1002,13 @@ int hgs_destroy(hgs_handle* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(nullptr);
 }
 
 const char* hgs_last_error(const hgs_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, hgs_cloud** out) {
+int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, hgs_cloud** out) try {
   if (!h || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   hgs_cloud* c = nullptr;
@@ -958,9 +1046,11 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
   }
   *out = c;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_cloud_destroy(hgs_cloud* c) {
+int hgs_cloud_destroy(hgs_cloud* c) try {
   if (!c) return HGS_OK;
   hgs_handle* h = c->owner;
   if (h) {
@@ -971,11 +1061,13 @@ int hgs_cloud_destroy(hgs_cloud* c) {
   }
   cloud_free(c);
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception((c ? c->owner : nullptr));
 }
 
 size_t hgs_cloud_size(const hgs_cloud* c) { return c ? c->n_input : 0; }
 
-int hgs_cloud_invalidate(hgs_cloud* c) {
+int hgs_cloud_invalidate(hgs_cloud* c) try {
   if (!c) return HGS_ERR_INVALID_ARGUMENT;
   c->has_index = false, c->has_cov = false, c->has_ndt = false, c->has_vg = false;
   // also forget the correspondences of earlier registrations (they seed the next search): a truly cold cloud
@@ -984,23 +1076,29 @@ int hgs_cloud_invalidate(hgs_cloud* c) {
     (void)hipMemsetAsync(c->desc.corr, 0xff, (size_t)c->P * kLeaf * sizeof(int), c->owner->stream);
   }
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception((c ? c->owner : nullptr));
 }
 
-int hgs_set_target_cloud(hgs_handle* h, hgs_cloud* c) {
+int hgs_set_target_cloud(hgs_handle* h, hgs_cloud* c) try {
   if (!h || !c || c->owner != h) return HGS_ERR_INVALID_ARGUMENT;  // clouds belong to the engine (stream) that created them
   if (h->own_target && h->target != c) cloud_free(h->target);
   h->target = c;
   h->own_target = false;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
-int hgs_set_source_cloud(hgs_handle* h, hgs_cloud* c) {
+int hgs_set_source_cloud(hgs_handle* h, hgs_cloud* c) try {
   if (!h || !c || c->owner != h) return HGS_ERR_INVALID_ARGUMENT;
   if (h->own_source && h->source != c) cloud_free(h->source);
   h->source = c;
   h->own_source = false;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
-int hgs_set_target(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes) {
+int hgs_set_target(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes) try {
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   hgs_cloud* c = nullptr;
   HGS_TRY(hgs_cloud_create(h, pts, n, stride_bytes, &c));
@@ -1011,8 +1109,10 @@ int hgs_set_target(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes
   h->target = c;
   h->own_target = true;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
-int hgs_set_source(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes) {
+int hgs_set_source(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes) try {
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   hgs_cloud* c = nullptr;
   HGS_TRY(hgs_cloud_create(h, pts, n, stride_bytes, &c));
@@ -1023,9 +1123,11 @@ int hgs_set_source(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes
   h->source = c;
   h->own_source = true;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_align(hgs_handle* h, const float guess[16], hgs_result* out) {
+int hgs_align(hgs_handle* h, const float guess[16], hgs_result* out) try {
   if (!h || !guess || !out) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   if (!h->source) return HGS_ERR_NO_SOURCE;
@@ -1037,9 +1139,11 @@ int hgs_align(hgs_handle* h, const float guess[16], hgs_result* out) {
   to_public(r[0], 0, false, out);
   std::memcpy(h->final_T, out->final_transformation, sizeof(h->final_T));
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t stride_bytes) {
+int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t stride_bytes) try {
   if (!h || !T || !out_pts || stride_bytes < 12) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->source) return HGS_ERR_NO_SOURCE;
   HGS_TRY(set_device(h));
@@ -1061,9 +1165,11 @@ int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t
     if (stride_bytes >= 16) f[3] = 1.0f;
   }
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_fitness(hgs_handle* h, const float T[16], double max_range, double* score, uint32_t* num_inliers) {
+int hgs_fitness(hgs_handle* h, const float T[16], double max_range, double* score, uint32_t* num_inliers) try {
   if (!h || !T || !score) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   if (!h->source) return HGS_ERR_NO_SOURCE;
@@ -1076,9 +1182,11 @@ int hgs_fitness(hgs_handle* h, const float T[16], double max_range, double* scor
   *score = r[0].fit_count > 0 ? r[0].fit_sum / (double)r[0].fit_count : std::numeric_limits<double>::max();
   if (num_inliers) *num_inliers = r[0].fit_count;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, const float relpose[16], double max_range, double* score) {
+int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, const float relpose[16], double max_range, double* score) try {
   if (!h || !cloud1 || !cloud2 || cloud1->owner != h || cloud2->owner != h || !relpose || !score) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   hgs_cloud* saved_t = h->target;
@@ -1092,9 +1200,11 @@ int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, 
   if (rc != HGS_OK) return rc;
   *score = r[0].fit_count > 0 ? r[0].fit_sum / (double)r[0].fit_count : std::numeric_limits<double>::max();
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_bytes, int32_t* idx, float* d2) {
+int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_bytes, int32_t* idx, float* d2) try {
   if (!h || (nq > 0 && (!q_xyz || !idx || !d2)) || stride_bytes < 12) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   if (nq == 0) return HGS_OK;
@@ -1113,9 +1223,11 @@ int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_by
   HGS_HIP(h, hipMemcpyAsync(d2, dd2, nq * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_select_best(const hgs_result* records, size_t n, int32_t* best) {
+int hgs_select_best(const hgs_result* records, size_t n, int32_t* best) try {
   if (!best || (n > 0 && !records)) return HGS_ERR_INVALID_ARGUMENT;
   // loop_detector.hpp:124,146-153: best_score starts at DBL_MAX; skip if !converged || score > best_score; else replace
   double best_score = std::numeric_limits<double>::max();
@@ -1128,10 +1240,12 @@ int hgs_select_best(const hgs_result* records, size_t n, int32_t* best) {
   }
   *best = b;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(nullptr);
 }
 
 int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_candidates, const float* guesses, double max_range, hgs_result* out,
-                         int32_t* best) {
+                         int32_t* best) try {
   if (!h || (n_candidates > 0 && (!candidates || !guesses || !out))) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   if (best) *best = -1;
@@ -1155,6 +1269,8 @@ int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_c
   for (size_t i = 0; i < n_candidates; i++) to_public(r[i], (int)i, true, &out[i]);
   if (best) HGS_TRY(hgs_select_best(out, n_candidates, best));
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
 // ---- prefilter (apps/prefiltering_nodelet.cpp:131-182) -------------------------------------------------------
@@ -1202,7 +1318,7 @@ int cloud_from_device(hgs_handle* h, const float4* src, size_t m, hgs_cloud** ou
 
 }  // namespace
 
-extern "C" int hgs_prefilter_params_default(hgs_prefilter_params* p) {
+extern "C" int hgs_prefilter_params_default(hgs_prefilter_params* p) try {
   if (!p) return HGS_ERR_INVALID_ARGUMENT;
   std::memset(p, 0, sizeof(*p));
   p->use_distance_filter = 1;          // prefiltering_nodelet.cpp:94
@@ -1216,9 +1332,11 @@ extern "C" int hgs_prefilter_params_default(hgs_prefilter_params* p) {
   p->radius_radius = 0.8;              // :85
   p->radius_min_neighbors = 2;         // :86
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(nullptr);
 }
 
-extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, hgs_cloud** out) {
+extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, hgs_cloud** out) try {
   if (!h || !p || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
   if (p->downsample_method < HGS_DOWNSAMPLE_NONE || p->downsample_method > HGS_DOWNSAMPLE_VOXELGRID || p->outlier_removal_method < HGS_OUTLIER_NONE ||
       p->outlier_removal_method > HGS_OUTLIER_RADIUS || (p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID && !(p->downsample_resolution > 0)) ||
@@ -1331,9 +1449,11 @@ extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t st
   }
   *out = c;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-extern "C" int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_bytes) {
+extern "C" int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_bytes) try {
   if (!c || !c->owner || stride_bytes < 12 || (stride_bytes % 4) != 0 || (c->n_input > 0 && !out_pts)) return HGS_ERR_INVALID_ARGUMENT;
   hgs_handle* h = c->owner;
   HGS_TRY(set_device(h));
@@ -1351,11 +1471,13 @@ extern "C" int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_byt
     if (stride_bytes >= 20) f[4] = inten[i];
   }
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception((c ? c->owner : nullptr));
 }
 
 // ---- map cloud (src/hdl_graph_slam/map_cloud_generator.cpp:13-51) --------------------------------------------
 extern "C" int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes, const float* poses /* 16 * n, column-major */, size_t n_keyframes,
-                                      double resolution, hgs_cloud** out) {
+                                      double resolution, hgs_cloud** out) try {
   if (!h || !out || (n_keyframes > 0 && (!keyframes || !poses))) return HGS_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   size_t total = 0;
@@ -1443,15 +1565,19 @@ extern "C" int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes
   }
   HGS_HIP(h, hipGetLastError());
   return cloud_from_device(h, result, m, out);
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_profile_enable(hgs_handle* h, int enabled) {
+int hgs_profile_enable(hgs_handle* h, int enabled) try {
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   h->profiling = enabled != 0;
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_profile_read(hgs_handle* h, double* ms, uint64_t* launches, int reset) {
+int hgs_profile_read(hgs_handle* h, double* ms, uint64_t* launches, int reset) try {
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
@@ -1470,17 +1596,21 @@ int hgs_profile_read(hgs_handle* h, double* ms, uint64_t* launches, int reset) {
     if (reset) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
   }
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_synchronize(hgs_handle* h) {
+int hgs_synchronize(hgs_handle* h) try {
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
 // ---- stage-level hooks for the parity tests ---------------------------------------------------------------
-int hgs_debug_target_covariances(hgs_handle* h, float* out6) {
+int hgs_debug_target_covariances(hgs_handle* h, float* out6) try {
   if (!h || !out6) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   HGS_TRY(set_device(h));
@@ -1503,9 +1633,11 @@ int hgs_debug_target_covariances(hgs_handle* h, float* out6) {
     p[0] = cov[2 * i].x, p[1] = cov[2 * i].y, p[2] = cov[2 * i].z, p[3] = cov[2 * i].w, p[4] = cov[2 * i + 1].x, p[5] = cov[2 * i + 1].y;
   }
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, double* b6, double* err, int32_t* corr) {
+int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, double* b6, double* err, int32_t* corr) try {
   if (!h || !T12 || !H36 || !b6 || !err) return HGS_ERR_INVALID_ARGUMENT;
   if (h->prm.method != HGS_FAST_GICP && h->prm.method != HGS_FAST_VGICP) return HGS_ERR_UNSUPPORTED;
   if (!h->target) return HGS_ERR_NO_TARGET;
@@ -1561,9 +1693,11 @@ int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, d
     }
   }
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_debug_ndt_cells(hgs_handle* h, int32_t cap, int32_t* ijk3, double* mean3, float* icov6, int32_t* npts, int32_t* n_cells) {
+int hgs_debug_ndt_cells(hgs_handle* h, int32_t cap, int32_t* ijk3, double* mean3, float* icov6, int32_t* npts, int32_t* n_cells) try {
   if (!h || !n_cells) return HGS_ERR_INVALID_ARGUMENT;
   if (h->prm.method != HGS_NDT_OMP) return HGS_ERR_UNSUPPORTED;
   if (!h->target) return HGS_ERR_NO_TARGET;
@@ -1596,9 +1730,11 @@ int hgs_debug_ndt_cells(hgs_handle* h, int32_t cap, int32_t* ijk3, double* mean3
     if (npts) npts[i] = (int)cells[i].v1.z;
   }
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
-int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, double* g6, double* H36) {
+int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, double* g6, double* H36) try {
   if (!h || !p6 || !score || !g6 || !H36) return HGS_ERR_INVALID_ARGUMENT;
   if (h->prm.method != HGS_NDT_OMP) return HGS_ERR_UNSUPPORTED;
   if (!h->target) return HGS_ERR_NO_TARGET;
@@ -1619,8 +1755,15 @@ int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, 
   HGS_HIP(h, hipMemcpyAsync(h->misc.p, p6, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   launch_ndt_debug_state(h->stream, h->states.as<NdtState>(), h->angles.as<NdtAngles>(), h->misc.as<double>(), c);
   Progress none{};
-  launch_ndt_pass(h->stream, d_descs, ndt_target_view(h, t), h->states.as<NdtState>(), h->angles.as<NdtAngles>(), c, h->ndt_accum.as<NdtAccum>(), max_blocks, 1,
-                  (h->ndt_sort != 0 && s->has_index) ? 1 : 0, 1, none);
+  HGS_HIP(h, h->ndt_plan.reserve(256));
+  struct {
+    unsigned long long queue, pad;
+    int tile_base[2];
+  } plan{0, 0, {0, max_blocks}};
+  HGS_HIP(h, hipMemcpy(h->ndt_plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice));
+  launch_ndt_pass(h->stream, d_descs, ndt_target_view(h, t), h->states.as<NdtState>(), h->angles.as<NdtAngles>(), c, h->ndt_accum.as<NdtAccum>(),
+                  reinterpret_cast<const int*>((char*)h->ndt_plan.p + 16), reinterpret_cast<unsigned long long*>(h->ndt_plan.p), 1, 0ull, std::min(max_blocks, 96),
+                  2 /* several tiles per block, several grabs per block */, (h->ndt_sort != 0 && s->has_index) ? 1 : 0, 1, none);
   double acc[kAccNdt];
   HGS_HIP(h, hipMemcpyAsync(acc, h->ndt_accum.as<NdtAccum>()->out, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
@@ -1628,6 +1771,8 @@ int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, 
   for (int i = 0; i < 6; i++) g6[i] = acc[36 + i];
   *score = acc[42];
   return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
 }
 
 }  // extern "C"

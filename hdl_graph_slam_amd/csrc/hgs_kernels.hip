@@ -21,6 +21,9 @@
 namespace hgs {
 
 // ------------------------------------------------------------------------------------------------ helpers
+#ifndef HGS_OPAQUE_POINTER  // (the host emulation of tests/emul supplies its own spelling of the register constraint)
+#define HGS_OPAQUE_POINTER(p) asm volatile("" : "+v"(p))
+#endif
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -796,36 +799,34 @@ __device__ __forceinline__ void solve_svd6_wave(const double* A, const double* b
   if (lane == 0) svd6_backsolve<volatile double*>(U, V, b, x);
 }
 
-// The 64 lanes' values of four registers summed (mod 2^32) into the last lane of each 16-lane row of the result: row 0 <- a,
-// row 1 <- c, row 2 <- b, row 3 <- d.  Two transposing steps (v_permlane32_swap / v_permlane16_swap: swap halves of two
-// registers, add — one add reduces two values) and four DPP row shifts: 10 instructions for four wave reductions.
-__device__ __forceinline__ unsigned wave_sum4_u32(unsigned a, unsigned b, unsigned c, unsigned d) {
+// Four registers' values partially summed across the wave by two transposing steps (v_permlane32_swap / v_permlane16_swap:
+// swap halves of two registers, add — one add reduces two values): afterwards every lane of 16-lane row 0 / 1 / 2 / 3 holds
+// the sum of four lanes' values of a / c / b / d, and the 16 lanes of a row together cover all 64 lanes.  Inputs < 2^27.
+__device__ __forceinline__ unsigned wave_rows4_u32(unsigned a, unsigned b, unsigned c, unsigned d) {
   const auto ab = __builtin_amdgcn_permlane32_swap(a, b, false, false);  // {a.lo | b.lo}, {a.hi | b.hi}
   const unsigned x = ab[0] + ab[1];                                      // lanes 0..31: a, lanes 32..63: b
   const auto cd = __builtin_amdgcn_permlane32_swap(c, d, false, false);
   const unsigned y = cd[0] + cd[1];
   const auto xy = __builtin_amdgcn_permlane16_swap(x, y, false, false);  // rows {x0, y0, x2, y2}, {x1, y1, x3, y3}
-  unsigned z = xy[0] + xy[1];                                            // rows: a, c, b, d
-  z += __builtin_amdgcn_update_dpp(0u, z, 0x111, 0xf, 0xf, true);        // row_shr:1
-  z += __builtin_amdgcn_update_dpp(0u, z, 0x112, 0xf, 0xf, true);        // row_shr:2
-  z += __builtin_amdgcn_update_dpp(0u, z, 0x114, 0xf, 0xf, true);        // row_shr:4
-  z += __builtin_amdgcn_update_dpp(0u, z, 0x118, 0xf, 0xf, true);        // row_shr:8  -> lane 15 of each row holds the row's sum
-  return z;
+  return xy[0] + xy[1];                                                  // rows: a, c, b, d
 }
 
-// One NDT iteration in ONE launch (computeDerivatives + the Newton step of computeTransformation / computeStepLengthMT):
+// One NDT iteration of a batch in ONE launch (computeDerivatives + the Newton step of computeTransformation /
+// computeStepLengthMT).  Work items are (problem, tile of 256 points); the resident blocks pull chunks of consecutive items
+// from a queue in HBM, so the load balances itself whatever the sizes of the clouds and however many problems of the batch
+// are still iterating (a finished problem's items cost one phase read each).
 //   1. per source point: transform, look up the DIRECT1 / DIRECT7 / KDTREE cells (all hash probes of a point are issued
 //      together, the cell records are fetched one visit ahead of the arithmetic), accumulate the point's score /
 //      gradient / Hessian over its cells in neighbourhood order (double, like ndt_omp's per-point sums);
 //   2. the per-point doubles are split into fixed-grid integer chunks (hgs_ndt.h "exact accumulation") and summed as
-//      integers: wave (wave_sum4_u32 on 25-bit digits: the sum of 64 digits fits 32 bits) -> block (LDS) -> problem
-//      (64-bit atomics in HBM).  Integer addition is associative: the totals do not depend on tiling, launch order or on
-//      the order the points are stored in, so the points are read in whatever order is resident (Hilbert order when the
-//      cloud has a search index — neighbouring lanes then share cells —, input order otherwise);
-//   3. the block that finishes last (ticket counter) turns the totals into doubles, runs the Newton step (Jacobi-SVD
-//      solve on three lanes, step clamp, convergence test, next angle tables) and ticks the batch progress.
-// Algorithmic bytes per source point: 16 + 7*40 = 296 (DIRECT7), 56 (DIRECT1); bound by VALU issue (~300 packed / fp64
-// instructions per visited cell), the cell table of a LiDAR scan is L2-resident.
+//      integers: wave (wave_rows4_u32 on 25/27-bit digits + LDS atomics) -> block (LDS, over all the tiles of one problem the
+//      block works on in a row) -> problem (64-bit atomics in HBM, one per digit total and flush).  Integer addition is
+//      associative: the totals do not depend on tiling, on which block took which tile or on the order the points are
+//      stored in, so the points are read in whatever order is resident (Hilbert order when the cloud has a search index —
+//      neighbouring lanes then share cells —, input order otherwise);
+//   3. the block whose flush completes a problem's tile count turns the totals into doubles, runs the Newton step
+//      (Jacobi-SVD solve on three lanes, step clamp, convergence test, next angle tables) and ticks the batch progress.
+// Algorithmic bytes per source point: 16 + 7*40 = 296 (DIRECT7), 56 (DIRECT1); the cell table of a LiDAR scan is L2-resident.
 template <int NOFF>
 __device__ __forceinline__ int ndt_pop_cell(unsigned& mask, const int (&ci)[NOFF]) {
   if (!mask) return -1;
@@ -837,164 +838,231 @@ __device__ __forceinline__ int ndt_pop_cell(unsigned& mask, const int (&ci)[NOFF
   return c;
 }
 
-template <int NOFF>
-__global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restrict__ descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c,
-                                                      NdtAccum* accum, int sorted, int debug, Progress prog) {
-  const int b = blockIdx.y;
-  if (states[b].phase != NDT_DERIV) {  // finished in an earlier round
-    if (blockIdx.x == 0 && threadIdx.x == 0 && !debug) progress_tick(prog, false);
-    return;
-  }
-  const CloudDesc d = descs[b];
-  const int n = sorted ? d.meta->nvalid : d.n_input;
-  const int ntiles = n > 0 ? (n + kBlock - 1) / kBlock : 1;  // an empty source still completes its pass (all sums zero)
-  if ((int)blockIdx.x >= ntiles) return;
-  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-  __shared__ NdtAngles ang;
-  __shared__ unsigned s_dig[kBlock / 64][kAccNdt * 4];
-  __shared__ double s_acc[kAccNdt];
-  __shared__ double s_svd[72];
-  __shared__ int s_last;
-  for (int k = threadIdx.x; k < (int)(sizeof(NdtAngles) / 4); k += kBlock) reinterpret_cast<float*>(&ang)[k] = reinterpret_cast<const float*>(&angles[b])[k];
-  __syncthreads();
-
+struct NdtPassShared {
+  NdtAngles ang;
+  unsigned long long tot[kBlock / 64][kAccNdt * 4];  // per wave: digit sums of the tiles since the last flush
+  unsigned long long w[kAccNdt * 4 + 4];             // finish: the problem's totals (+ contributions, ticket, overflow)
+  unsigned contrib[kBlock / 64];                     // per wave: lanes that went through the digit code since the last flush
   double acc[kAccNdt];
-#pragma unroll
-  for (int k = 0; k < kAccNdt; k++) acc[k] = 0.0;
-  {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    bool have = i < n;
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (have) x = sorted ? d.pts[i] : d.raw[i];
-    if (!sorted && !finite3(x)) have = false;
-    const F3 xt = transform_point_f(ang.T, x.x, x.y, x.z);
-    int ci[NOFF];
-    unsigned vmask = 0;
-    {
-      const CloudMeta* m = tgt.meta;
-      const int mnx = m->ndt_min_b[0], mny = m->ndt_min_b[1], mnz = m->ndt_min_b[2];
-      const int mxx = m->ndt_max_b[0], mxy = m->ndt_max_b[1], mxz = m->ndt_max_b[2];
-      const int mul1 = m->ndt_div_mul[1], mul2 = m->ndt_div_mul[2];
-      const int cx = (int)floorf(xt.x * tgt.inv_leaf), cy = (int)floorf(xt.y * tgt.inv_leaf), cz = (int)floorf(xt.z * tgt.inv_leaf);
-      int key[NOFF];
-      unsigned slot[NOFF];
-      int2 kv[NOFF];
-#pragma unroll
-      for (int o = 0; o < NOFF; o++) {
-        int ox, oy, oz;
-        ndt_offset(c.search, o, &ox, &oy, &oz);
-        const int px = cx + ox, py = cy + oy, pz = cz + oz;
-        const bool in = have && px >= mnx && px <= mxx && py >= mny && py <= mxy && pz >= mnz && pz <= mxz;
-        key[o] = in ? (px - mnx) + (py - mny) * mul1 + (pz - mnz) * mul2 : -1;
-        slot[o] = (ndt_hash(key[o]) >> 7) & (unsigned)tgt.hash_mask;
-        kv[o] = in ? tgt.hash_kv[slot[o]] : make_int2(-1, -1);
-      }
-#pragma unroll
-      for (int o = 0; o < NOFF; o++) {
-        while (kv[o].x != key[o] && kv[o].x != -1) {  // linear probing (load factor <= 1/4: almost never taken)
-          slot[o] = (slot[o] + 1u) & (unsigned)tgt.hash_mask;
-          kv[o] = tgt.hash_kv[slot[o]];
-        }
-        ci[o] = (key[o] >= 0 && kv[o].x == key[o]) ? kv[o].y : -1;
-        if (ci[o] >= 0) vmask |= 1u << o;
-      }
-    }
-    NdtPointDeriv pd;
-    ndt_point_derivatives(ang, x.x, x.y, x.z, pd);
-    const float d1 = (float)c.gauss_d1, d2 = (float)c.gauss_d2;
-    // Visit the point's valid cells in neighbourhood order, the record of visit k+1 in flight during the arithmetic of
-    // visit k.  A counted loop with a wave-uniform early exit: the `while (any lane has a cell)` form of the same loop
-    // made the register allocator keep two copies of the 43 double sums (368 VGPRs instead of 216).
-    int cur = ndt_pop_cell<NOFF>(vmask, ci);
-    NdtCellRec rc = tgt.cells[cur >= 0 ? cur : 0];
-#pragma unroll 1
-    for (int it = 0; it < NOFF; it++) {
-      if (__ballot(cur >= 0) == 0ull) break;
-      const int nxt = ndt_pop_cell<NOFF>(vmask, ci);
-      NdtCellRec rn = rc;
-      if (nxt >= 0) rn = tgt.cells[nxt];
-      if (cur >= 0 && ndt_cell_in_reach(c, xt, rc.mean)) {
-        const float icov[6] = {rc.v0.x, rc.v0.y, rc.v0.z, rc.v0.w, rc.v1.x, rc.v1.y};
-        ndt_cell_terms_pk(d1, d2, pd, (float)((double)xt.x - rc.mean[0]), (float)((double)xt.y - rc.mean[1]), (float)((double)xt.z - rc.mean[2]), icov, acc);
-      }
-      cur = nxt;
-      rc = rn;
-    }
-  }
+  double svd[72];
+  unsigned long long next;
+  int last, out_of_range;
+};
 
-  // ---- exact accumulation: per-point doubles -> 25-bit digits -> wave -> block -> problem --------------------------------
-  bool out_of_range = false;
-#pragma unroll
-  for (int k = 0; k < kAccNdt; k++) {
-    double m0, m1;
-    if (!ndt_exact_split(acc[k], ndt_sum_exponent(k), &m0, &m1)) out_of_range = true, m0 = m1 = kNdtMagic;
-    const unsigned long long b0 = (unsigned long long)__double_as_longlong(m0), b1 = (unsigned long long)__double_as_longlong(m1);
-    // digit = chunk mod 2^25 (low) and floor(chunk / 2^25) + constant (high): the constants of 64 lanes add up to 0 mod 2^32
-    const unsigned z = wave_sum4_u32((unsigned)b0 & 0x1ffffffu, (unsigned)(b0 >> 25), (unsigned)b1 & 0x1ffffffu, (unsigned)(b1 >> 25));
-    if ((lane & 15) == 15) s_dig[wave][k * 4 + (lane >> 4)] = z;  // rows: q0 low, q1 low, q0 high, q1 high
-  }
-  NdtAccum& A = accum[b];
-  if (__ballot(out_of_range) != 0ull && lane == 0) atomicOr(&A.overflow, 1u);
-  __syncthreads();
-  if (threadIdx.x < 2 * kAccNdt) {
-    const int k = threadIdx.x >> 1, ch = threadIdx.x & 1;
-    long long lo = 0, hi = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; w++) lo += (long long)s_dig[w][k * 4 + ch], hi += (long long)(int)s_dig[w][k * 4 + 2 + ch];
-    const long long q = hi * (1ll << 25) + lo;  // this block's sum of chunk `ch` of accumulator k (|q| < 2^58)
-    if (q != 0) {
-      atomicAdd(&A.w[k][ch][0], (unsigned long long)q & 0xffffffffull);
-      atomicAdd(&A.w[k][ch][1], (unsigned long long)(q >> 32));
-    }
-  }
+// The block that completed problem b's tile count: totals -> doubles, Newton step.  All threads of the block call it.
+__device__ __noinline__ void ndt_finish_problem(NdtPassShared& S, NdtAccum& A, NdtState& st, NdtAngles& angles_b, const NdtConsts& c, int debug, Progress prog) {
   __threadfence();
+  const int t = (int)threadIdx.x;
+  // read-and-clear (the next pass starts from zero), one exchange per thread so that they are all in flight together
+  if (t < kAccNdt * 4) S.w[t] = atomicExch(&A.w[t], 0ull);
+  else if (t == kAccNdt * 4) S.w[t] = atomicExch(&A.contrib, 0ull);
+  else if (t == kAccNdt * 4 + 1) S.w[t] = atomicExch(&A.tiles_done, 0u);
+  else if (t == kAccNdt * 4 + 2) S.w[t] = atomicExch(&A.overflow, 0u);
   __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(&A.ticket, 1u) + 1u == (unsigned)ntiles) ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-
-  // ---- last block of this problem: totals -> doubles, Newton step -----------------------------------------------------
-  __threadfence();
-  if (threadIdx.x < kAccNdt) {
-    const int k = threadIdx.x;
-    // read-and-clear (the next pass starts from zero): exchanges execute where the additions did
-    const unsigned long long w00 = atomicExch(&A.w[k][0][0], 0ull), w01 = atomicExch(&A.w[k][0][1], 0ull);
-    const unsigned long long w10 = atomicExch(&A.w[k][1][0], 0ull), w11 = atomicExch(&A.w[k][1][1], 0ull);
-    const __int128 s0 = (__int128)(long long)w01 * ((__int128)1 << 32) + (__int128)w00;
-    const __int128 s1 = (__int128)(long long)w11 * ((__int128)1 << 32) + (__int128)w10;
-    s_acc[k] = ndt_i128_to_double(s0 * ((__int128)1 << kNdtChunkBits) + s1, ndt_sum_exponent(k));
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicExch(&A.ticket, 0u);
-    if (atomicExch(&A.overflow, 0u))
-      for (int k = 0; k < kAccNdt; k++) s_acc[k] = __longlong_as_double(0x7ff8000000000000ll);
+  if (t < kAccNdt) {
+    // every lane that went through the digit code added 2^26 to each high-digit total; chunk = high * 2^25 + low ; V = chunk0 * 2^50 + chunk1
+    const __int128 off = (__int128)S.w[kAccNdt * 4] * ((__int128)1 << 26);
+    const __int128 q0 = ((__int128)S.w[t * 4 + 2] - off) * ((__int128)1 << 25) + (__int128)S.w[t * 4];
+    const __int128 q1 = ((__int128)S.w[t * 4 + 3] - off) * ((__int128)1 << 25) + (__int128)S.w[t * 4 + 1];
+    S.acc[t] = S.w[kAccNdt * 4 + 2] ? __longlong_as_double(0x7ff8000000000000ll) : ndt_i128_to_double(q0 * ((__int128)1 << kNdtChunkBits) + q1, ndt_sum_exponent(t));
   }
   __syncthreads();
   if (debug) {
-    if (threadIdx.x < kAccNdt) A.out[threadIdx.x] = s_acc[threadIdx.x];
-    return;
+    if (t < kAccNdt) A.out[t] = S.acc[t];
+  } else if (t < 64) {
+    double dp_newton[6] = {0, 0, 0, 0, 0, 0};
+    const bool no_direction_needed = ndt_pass_is_last(st, c, S.acc);  // wave-uniform
+    __builtin_amdgcn_wave_barrier();  // every lane has judged the state before lane 0 rewrites it below
+    if (!no_direction_needed) {
+      double ng[6];
+      for (int i = 0; i < 6; i++) ng[i] = -S.acc[36 + i];
+      solve_svd6_wave(S.acc, ng, S.svd, S.svd + 36, dp_newton);
+    }
+    if (t == 0) {
+      ndt_after_derivatives(st, S.acc, c, dp_newton);
+      if (st.phase != NDT_DONE) ndt_angle_tables(st.p, c.upstream_hd1_sign, angles_b);
+      progress_tick(prog, st.phase == NDT_DONE);
+    }
   }
-  if (threadIdx.x >= 64) return;
-  NdtState& st = states[b];
-  double dp_newton[6] = {0, 0, 0, 0, 0, 0};
-  if (!ndt_pass_is_last(st, c, s_acc)) {  // wave-uniform
-    double ng[6];
-    for (int i = 0; i < 6; i++) ng[i] = -s_acc[36 + i];
-    solve_svd6_wave(s_acc, ng, s_svd, s_svd + 36, dp_newton);
-  }
-  if (threadIdx.x == 0) {
-    ndt_after_derivatives(st, s_acc, c, dp_newton);
-    if (st.phase != NDT_DONE) ndt_angle_tables(st.p, c.upstream_hd1_sign, angles[b]);
-    progress_tick(prog, st.phase == NDT_DONE);
-  }
+  __syncthreads();
 }
-void launch_ndt_pass(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c, NdtAccum* accum, int max_blocks,
-                     int B, int sorted, int debug, Progress prog) {
-  const dim3 grid(max_blocks < 1 ? 1 : max_blocks, B), block(kBlock);
-  if (c.search == 1) hipLaunchKernelGGL(k_ndt_pass<1>, grid, block, 0, s, descs, tgt, states, angles, c, accum, sorted, debug, prog);
-  else if (c.search == 2) hipLaunchKernelGGL(k_ndt_pass<7>, grid, block, 0, s, descs, tgt, states, angles, c, accum, sorted, debug, prog);
-  else hipLaunchKernelGGL(k_ndt_pass<27>, grid, block, 0, s, descs, tgt, states, angles, c, accum, sorted, debug, prog);
+
+// Adds the block's digit totals of problem b to HBM and accounts for `tiles` tiles of it; true (block-uniform) if that
+// completed the problem's pass.
+__device__ __noinline__ bool ndt_flush(NdtPassShared& S, NdtAccum& A, int tiles, int tiles_total) {
+  const int t = (int)threadIdx.x;
+  __syncthreads();
+  if (t < kAccNdt * 4) {
+    unsigned long long v = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) v += S.tot[w][t], S.tot[w][t] = 0;
+    if (v) atomicAdd(&A.w[t], v);
+  } else if (t == kAccNdt * 4) {
+    unsigned v = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) v += S.contrib[w], S.contrib[w] = 0;
+    if (v) atomicAdd(&A.contrib, (unsigned long long)v);
+  } else if (t == kAccNdt * 4 + 1) {
+    if (S.out_of_range) atomicOr(&A.overflow, 1u), S.out_of_range = 0;
+  }
+  __threadfence();
+  __syncthreads();
+  if (t == 0) S.last = atomicAdd(&A.tiles_done, (unsigned)tiles) + (unsigned)tiles == (unsigned)tiles_total ? 1 : 0;
+  __syncthreads();
+  return S.last != 0;
+}
+
+template <int NOFF>
+__global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restrict__ descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c,
+                                                         NdtAccum* accum, const int* __restrict__ tile_base /* [B + 1] */, unsigned long long* queue, int B,
+                                                         unsigned long long base, int chunk, int sorted, int debug, Progress prog) {
+  __shared__ NdtPassShared S;
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  for (int k = threadIdx.x; k < (kBlock / 64) * kAccNdt * 4; k += kBlock) (&S.tot[0][0])[k] = 0;
+  if (threadIdx.x < kBlock / 64) S.contrib[threadIdx.x] = 0;
+  if (threadIdx.x == 0) S.out_of_range = 0, S.next = atomicAdd(queue, (unsigned long long)chunk);
+  __syncthreads();
+  const unsigned long long end = base + (unsigned long long)tile_base[B];
+  const CloudMeta* m = tgt.meta;
+  const int mnx = m->ndt_min_b[0], mny = m->ndt_min_b[1], mnz = m->ndt_min_b[2];
+  const int mxx = m->ndt_max_b[0], mxy = m->ndt_max_b[1], mxz = m->ndt_max_b[2];
+  const int mul1 = m->ndt_div_mul[1], mul2 = m->ndt_div_mul[2];
+  const float d1 = (float)c.gauss_d1, d2 = (float)c.gauss_d2;
+  int cur_b = -1, cur_active = 0, cur_tiles = 0, cur_n = 0, cur_first = 0, cur_end = 0;  // block-uniform: the problem being worked on
+  CloudDesc d{};
+  unsigned long long w = S.next;
+  while (w < end) {
+    __syncthreads();  // everybody has read S.next
+    unsigned long long nxt = 0;
+    if (threadIdx.x == 0) nxt = atomicAdd(queue, (unsigned long long)chunk);  // the next chunk's grab is in flight during this chunk
+    const unsigned long long lo = w < base ? base : w, hi = w + (unsigned long long)chunk < end ? w + (unsigned long long)chunk : end;
+    for (unsigned long long it = lo; it < hi; it++) {
+      const int item = (int)(it - base);
+      if (item < cur_first || item >= cur_end) {
+        // another problem: hand in what was gathered for the previous one, then look the new one up
+        if (cur_b >= 0 && cur_active && ndt_flush(S, accum[cur_b], cur_tiles, tile_base[cur_b + 1] - tile_base[cur_b]))
+          ndt_finish_problem(S, accum[cur_b], states[cur_b], angles[cur_b], c, debug, prog);
+        int b0 = 0, b1 = B;  // tile_base[b0] <= item < tile_base[b1]
+        while (b1 - b0 > 1) {
+          const int mid = (b0 + b1) >> 1;
+          if (tile_base[mid] <= item) b0 = mid;
+          else b1 = mid;
+        }
+        cur_b = b0, cur_first = tile_base[b0], cur_end = tile_base[b0 + 1], cur_tiles = 0;
+        cur_active = states[cur_b].phase == NDT_DERIV ? 1 : 0;
+        if (cur_active) {
+          d = descs[cur_b];
+          cur_n = sorted ? d.meta->nvalid : d.n_input;
+          __syncthreads();
+          for (int k = threadIdx.x; k < (int)(sizeof(NdtAngles) / 4); k += kBlock) reinterpret_cast<float*>(&S.ang)[k] = reinterpret_cast<const float*>(&angles[cur_b])[k];
+          __syncthreads();
+        }
+      }
+      if (!cur_active) {  // finished in an earlier round: its first item carries the round's progress tick
+        if (item == cur_first && threadIdx.x == 0 && !debug) progress_tick(prog, false);
+        continue;
+      }
+      cur_tiles++;
+      const int tile = item - cur_first;
+      if (tile * kBlock >= cur_n && !(tile == 0)) continue;  // the host's tile count is an upper bound (non-finite points); tile 0 always runs
+      const NdtAngles* ap = &S.ang;
+      HGS_OPAQUE_POINTER(ap);  // re-read the tables from LDS every tile: hoisted out of the loop they would pin 81 VGPRs
+      double acc[kAccNdt];
+#pragma unroll
+      for (int k = 0; k < kAccNdt; k++) acc[k] = 0.0;
+      bool any_cell;
+      {
+        const int i = tile * kBlock + threadIdx.x;
+        bool have = i < cur_n;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) x = sorted ? d.pts[i] : d.raw[i];
+        if (!sorted && !finite3(x)) have = false;
+        const F3 xt = transform_point_f(ap->T, x.x, x.y, x.z);
+        int ci[NOFF];
+        unsigned vmask = 0;
+        {
+          const int cx = (int)floorf(xt.x * tgt.inv_leaf), cy = (int)floorf(xt.y * tgt.inv_leaf), cz = (int)floorf(xt.z * tgt.inv_leaf);
+          int key[NOFF];
+          unsigned slot[NOFF];
+          int2 kv[NOFF];
+#pragma unroll
+          for (int o = 0; o < NOFF; o++) {
+            int ox, oy, oz;
+            ndt_offset(c.search, o, &ox, &oy, &oz);
+            const int px = cx + ox, py = cy + oy, pz = cz + oz;
+            const bool in = have && px >= mnx && px <= mxx && py >= mny && py <= mxy && pz >= mnz && pz <= mxz;
+            key[o] = in ? (px - mnx) + (py - mny) * mul1 + (pz - mnz) * mul2 : -1;
+            slot[o] = (ndt_hash(key[o]) >> 7) & (unsigned)tgt.hash_mask;
+            kv[o] = in ? tgt.hash_kv[slot[o]] : make_int2(-1, -1);
+          }
+#pragma unroll
+          for (int o = 0; o < NOFF; o++) {
+            while (kv[o].x != key[o] && kv[o].x != -1) {  // linear probing (load factor <= 1/4: almost never taken)
+              slot[o] = (slot[o] + 1u) & (unsigned)tgt.hash_mask;
+              kv[o] = tgt.hash_kv[slot[o]];
+            }
+            ci[o] = (key[o] >= 0 && kv[o].x == key[o]) ? kv[o].y : -1;
+            if (ci[o] >= 0) vmask |= 1u << o;
+          }
+        }
+        any_cell = __ballot(vmask != 0u) != 0ull;
+        if (any_cell) {
+          NdtPointDeriv pd;
+          ndt_point_derivatives(*ap, x.x, x.y, x.z, pd);
+          // Visit the point's valid cells in neighbourhood order, the record of visit k+1 in flight during the arithmetic of
+          // visit k.  A counted loop with a wave-uniform early exit: the `while (any lane has a cell)` form of the same loop
+          // made the register allocator keep two copies of the 43 double sums (368 VGPRs instead of 216).
+          int cur = ndt_pop_cell<NOFF>(vmask, ci);
+          NdtCellRec rc = tgt.cells[cur >= 0 ? cur : 0];
+#pragma unroll 1
+          for (int v = 0; v < NOFF; v++) {
+            if (__ballot(cur >= 0) == 0ull) break;
+            const int nx = ndt_pop_cell<NOFF>(vmask, ci);
+            NdtCellRec rn = rc;
+            if (nx >= 0) rn = tgt.cells[nx];
+            if (cur >= 0 && ndt_cell_in_reach(c, xt, rc.mean)) {
+              const float icov[6] = {rc.v0.x, rc.v0.y, rc.v0.z, rc.v0.w, rc.v1.x, rc.v1.y};
+              ndt_cell_terms_pk(d1, d2, pd, (float)((double)xt.x - rc.mean[0]), (float)((double)xt.y - rc.mean[1]), (float)((double)xt.z - rc.mean[2]), icov, acc);
+            }
+            cur = nx;
+            rc = rn;
+          }
+        }
+      }
+      // ---- exact accumulation: per-point doubles -> four unsigned digits -> rows of the wave -> this wave's totals in LDS ----
+      // digits of a chunk q (|q| < 2^49, carried as the mantissa field 2^51 + q): q mod 2^25 and 2^26 + floor(q / 2^25), both
+      // non-negative; the 2^26 of every lane that goes through here is counted (S.contrib) and taken off once at the end.
+      // The last 16 -> 1 step of the wave sum is the LDS atomic itself (ds_add_u64, 16 lanes per address): it runs on the LDS
+      // pipe next to the VALU work of the other waves instead of four dependent DPP adds.  A wave none of whose points met a
+      // cell has nothing but zeros to add and skips all of it.
+      if (any_cell) {
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < kAccNdt; k++) {
+          double m0, m1;
+          if (!ndt_exact_split(acc[k], ndt_sum_exponent(k), &m0, &m1)) bad = true;
+          const unsigned long long b0 = (unsigned long long)__double_as_longlong(m0), b1 = (unsigned long long)__double_as_longlong(m1);
+          const unsigned z = wave_rows4_u32((unsigned)b0 & 0x1ffffffu, (unsigned)(b0 >> 25) & 0x7ffffffu, (unsigned)b1 & 0x1ffffffu, (unsigned)(b1 >> 25) & 0x7ffffffu);
+          atomicAdd(&S.tot[wave][k * 4 + (lane >> 4)], (unsigned long long)z);  // rows: chunk0 low, chunk1 low, chunk0 high, chunk1 high
+        }
+        if (lane == 0) S.contrib[wave] += 64u;
+        if (__ballot(bad) != 0ull && lane == 0) S.out_of_range = 1;
+      }
+    }
+    if (threadIdx.x == 0) S.next = nxt;
+    __syncthreads();
+    w = S.next;
+  }
+  if (cur_b >= 0 && cur_active && ndt_flush(S, accum[cur_b], cur_tiles, tile_base[cur_b + 1] - tile_base[cur_b]))
+    ndt_finish_problem(S, accum[cur_b], states[cur_b], angles[cur_b], c, debug, prog);
+}
+void launch_ndt_pass(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c, NdtAccum* accum, const int* tile_base,
+                     unsigned long long* queue, int B, unsigned long long base, int blocks, int chunk, int sorted, int debug, Progress prog) {
+  const dim3 grid(blocks < 1 ? 1 : blocks), block(kBlock);
+  if (chunk < 1) chunk = 1;
+  if (c.search == 1) hipLaunchKernelGGL(k_ndt_pass<1>, grid, block, 0, s, descs, tgt, states, angles, c, accum, tile_base, queue, B, base, chunk, sorted, debug, prog);
+  else if (c.search == 2) hipLaunchKernelGGL(k_ndt_pass<7>, grid, block, 0, s, descs, tgt, states, angles, c, accum, tile_base, queue, B, base, chunk, sorted, debug, prog);
+  else hipLaunchKernelGGL(k_ndt_pass<27>, grid, block, 0, s, descs, tgt, states, angles, c, accum, tile_base, queue, B, base, chunk, sorted, debug, prog);
 }
 
 __global__ void k_ndt_results(const CloudDesc* descs, const NdtState* states, DevResult* out, int B) {

@@ -35,7 +35,9 @@ enum hgs_status {
   HGS_ERR_NO_SOURCE = 3,
   HGS_ERR_HIP = 4,      /* a HIP runtime call failed; hgs_last_error() has the text */
   HGS_ERR_NO_DEVICE = 5,
-  HGS_ERR_UNSUPPORTED = 6
+  HGS_ERR_UNSUPPORTED = 6,
+  HGS_ERR_OUT_OF_MEMORY = 7, /* host allocation failed inside the backend (std::bad_alloc caught at the boundary) */
+  HGS_ERR_INTERNAL = 8       /* any other C++ exception caught at the boundary; hgs_last_error() has the text */
 };
 
 /* registration_method strings of registrations.cpp:26-121 that this backend implements. */

@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def oracle_thread_count():
+    """The oracle's OpenMP loops default to every hardware thread; on the GPU box (2 x 128 threads) that is ~40x SLOWER than 32
+    threads for these per-point loops (measured, bench.py), and the NDT parity tests run hundreds of oracle passes."""
+    try:
+        import oracle as O
+        O.set_num_threads(min(32, os.cpu_count() or 1))
+    except Exception:  # noqa: BLE001  (oracle not built yet: the tests that need it will say so)
+        pass
+
+
 @pytest.fixture(scope="session")
 def small_pair():
     """~4k-point VLP-16 pair (voxel 0.4 m) that the oracle aligns in milliseconds."""

@@ -12,6 +12,7 @@
 #define __HIPCC__ 1
 #endif
 #define HGS_SIMT_EMULATION 1
+#define HGS_OPAQUE_POINTER(p) asm volatile("" : "+r"(p))
 
 #include <math.h>
 #include <stdint.h>
@@ -26,6 +27,7 @@
 #define __device__
 #define __global__
 #define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
 #define __shared__ static thread_local   // one block at a time PER HOST THREAD (engines driven from several threads)
 #define __launch_bounds__(...)
 #define amdgpu_waves_per_eu(...)  // __attribute__((amdgpu_waves_per_eu(n))) -> __attribute__(())

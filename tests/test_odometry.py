@@ -111,3 +111,39 @@ def test_hip_stream_with_device_voxelgrid_downsample():
         Ta, Tb = a.matching(t, c), b.matching(t, c)
         assert np.array_equal(Ta, Tb)
     reg.close(), reg2.close()
+
+
+@pytest.mark.gpu
+def test_hdl64_ndt_stream_with_the_kitti_keyframe_rule():
+    """Config 3: a 50-sweep HDL-64E stream (KITTI prefilter: 0.25 m voxel grid, hdl_graph_slam_kitti.launch:27-28) through the
+    odometry caller with the reference's NDT and the keyframe rule of hdl_graph_slam_kitti.launch:41-43 (5 m / 2 rad /
+    10000 s), every align to convergence.  The HIP stream equals the stream on the oracle's exact-sum mode bit for bit —
+    poses, keyframe switches — and stays within 1e-3 m / 1e-3 rad of the stream on the oracle's serial (ndt_omp) sum."""
+    import parity_checks as PC
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    stream = workloads.make_odometry_stream("HDL-64E", scene_seed=2, n_scans=50, speed=4.0, downsample=0.25)
+    reg = select_registration_method({"registration_method": "NDT_OMP", "reg_resolution": 1.0}, device_id=0)
+    p = O.HgsParams()
+    for name, _ in O.HgsParams._fields_:
+        setattr(p, name, getattr(reg.params, name))
+    kf = dict(keyframe_delta_trans=5.0, keyframe_delta_angle=2.0, keyframe_delta_time=10000.0)
+    hip = ScanMatchingOdometry(reg, **kf)
+    exact = ScanMatchingOdometry(O.OracleRegistration(p).set_ndt_sum_mode(1), **kf)
+    serial = ScanMatchingOdometry(O.OracleRegistration(p), **kf)
+    worst, iters = (0.0, 0.0), []
+    for t, c in zip(stream.stamps, stream.scans):
+        Ta, Tb, Tc = hip.matching(t, c), exact.matching(t, c), serial.matching(t, c)
+        assert np.array_equal(Ta, Tb), (t, synth.pose_error(Ta, Tb))
+        dt, dr = synth.pose_error(Ta, Tc)
+        worst = (max(worst[0], dt), max(worst[1], dr))
+        if hip.last_result is not None:
+            iters.append(int(hip.last_result.iterations))
+    assert worst[0] <= 1e-3 and worst[1] <= 1e-3, worst
+    assert hip.num_keyframes == exact.num_keyframes == serial.num_keyframes and hip.num_keyframes >= 2
+    gt = np.linalg.inv(stream.poses[0]) @ stream.poses[-1]
+    dt, dr = synth.pose_error(hip.keyframe_pose @ hip.prev_trans, gt)
+    PC.write_report("ndt_stream_hdl64_kitti.json", {"sweeps": len(stream.scans), "points_per_sweep": int(np.mean([len(c) for c in stream.scans])),
+                                                     "keyframes": hip.num_keyframes, "iterations_mean": float(np.mean(iters)), "iterations_max": int(max(iters)),
+                                                     "max_diff_vs_serial_m": worst[0], "max_diff_vs_serial_rad": worst[1],
+                                                     "drift_vs_ground_truth_m": float(dt), "drift_vs_ground_truth_rad": float(dr)})
+    reg.close()

@@ -135,27 +135,34 @@ def test_vgicp(res, search):
 
 @pytest.mark.parametrize("kind,res,search", [("hdl32", 1.0, O.HGS_DIRECT7), ("hdl32", 0.5, O.HGS_DIRECT1), ("vlp16", 1.0, O.HGS_DIRECT7), ("hdl32", 1.0, O.HGS_KDTREE)])
 def test_ndt(kind, res, search):
-    """Voxel table build (hash insertion, stable per-cell accumulation, eigen floor), derivative kernel + tile reduction, the
-    Newton loop."""
+    """Voxel table build (hash insertion, stable per-cell accumulation, eigen floor), the one-launch iteration (packed cell
+    terms, exact integer reduction through wave / block / atomics, Newton step by the last block): the derivative sums equal
+    the oracle's exact-sum mode bit for bit, and so do whole runs to convergence."""
     tgt, src, T = _pair(kind)
     p = O.default_params(O.HGS_NDT_OMP)
     p.resolution, p.neighbor_search = res, search
     e, o = _engine(p), O.OracleRegistration(p)
     PC.load_pair(e, o, tgt, src)
     PC.check_ndt_cells(e, o)
-    PC.check_ndt_derivatives(e, o, np.array([T[0, 3], T[1, 3], T[2, 3], 0.003, -0.004, 0.02]))
+    p6 = np.array([T[0, 3], T[1, 3], T[2, 3], 0.003, -0.004, 0.02])
+    PC.check_ndt_derivatives(e, o, p6)
+    if search != O.HGS_KDTREE:
+        se, ge, He = e.ndt_derivatives(p6)
+        sx, gx, Hx = _exact_derivatives(p, tgt, src, p6)
+        assert se == sx and np.array_equal(ge, gx) and np.array_equal(He, Hx)
+    PC.check_ndt_to_convergence(e, p, tgt, src, PC.ndt_guesses(T, 4, seed=1), bitwise=search != O.HGS_KDTREE, label=f"emulated {kind}")
     e.close()
-    for max_it in (1, 6):      # the Newton state machine with the three-lane Jacobi SVD; fixed-length prefixes compare tightly
-        p2 = O.default_params(O.HGS_NDT_OMP)
-        p2.resolution, p2.neighbor_search, p2.max_iterations = res, search, max_it
-        e2, o2 = _engine(p2), O.OracleRegistration(p2)
-        PC.load_pair(e2, o2, tgt, src)
-        PC.check_align(e2, o2, T @ synth.pose_matrix([0.05, 0.02, 0.0], [0.0, 0.0, 0.004]), tol_m=1e-6, tol_rad=1e-6)
-        e2.close()
+
+
+def _exact_derivatives(p, tgt, src, p6):
+    o = O.OracleRegistration(p).set_ndt_sum_mode(1)
+    o.setInputTarget(tgt)
+    o.setInputSource(src)
+    return o.ndt_derivatives(p6)
 
 
 def test_ndt_line_search():
-    """The More-Thuente switch through the real k_ndt_solve / k_ndt_derivatives and the host loop's round budget."""
+    """The More-Thuente switch through the real k_ndt_pass and the host loop's round budget."""
     tgt, src, T = _pair("vlp16")
     p = O.default_params(O.HGS_NDT_OMP)
     p.resolution, p.ndt_line_search = 1.0, 1
