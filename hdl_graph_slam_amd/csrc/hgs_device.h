@@ -61,8 +61,7 @@ struct NdtTargetView {
 // Integer totals of one NDT derivative pass of one problem (hgs_ndt.h "exact accumulation"), in HBM: the blocks of
 // k_ndt_pass add into it with 64-bit atomics, the block whose contribution completes the problem's tile count reads and clears it.
 struct NdtAccum {
-  unsigned long long w[kAccNdt * 4];  // [accumulator * 4 + {chunk0 low digits, chunk1 low, chunk0 high, chunk1 high}]
-  unsigned long long contrib;         // lanes that went through the digit code (each added 2^26 to every high-digit total)
+  unsigned long long w[kAccNdt * 4];  // [accumulator * 4 + {chunk0 low digits, chunk1 low, chunk0 high (signed), chunk1 high (signed)}]
   unsigned tiles_done;                // tiles of the current pass accounted for
   unsigned overflow;                  // a per-point term left the fixed range (or was NaN): the pass yields NaN
   double out[kAccNdt];                // hgs_debug_ndt_derivatives: the totals as doubles

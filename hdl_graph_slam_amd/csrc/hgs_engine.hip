@@ -145,7 +145,7 @@ struct hgs_handle {
   DeviceBuffer ndt_accum;  // NdtAccum per problem of the running NDT batch
   DeviceBuffer ndt_plan;         // per lane: work queue head + tile prefix sums of the running NDT batch
   int ndt_resident_blocks = 512; // blocks per k_ndt_pass launch (2 per CU); HGS_NDT_RESIDENT (A/B runs)
-  int ndt_chunk = 0;             // items per queue grab (0: total / (4 * blocks), clamped to 1..8); HGS_NDT_CHUNK
+  int ndt_chunk = 0;             // items per queue grab (0: the default, 2); HGS_NDT_CHUNK (A/B runs)
   int ndt_sort = -1;       // NDT source order: -1 Hilbert order if the source has an index, 1 build the index first, 0 input order (HGS_NDT_SORT, A/B runs)
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_descs, h_results, h_small, h_flags;  // h_flags: host-mapped progress mirror (Progress)
@@ -801,8 +801,11 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
         LanePlan& P = plans[li];
         const int total = tb[L.B];
         P.blocks = std::max(1, std::min(total, h->ndt_resident_blocks));
-        P.chunk = h->ndt_chunk > 0 ? h->ndt_chunk : std::max(1, std::min(8, total / (P.blocks * 4)));
-        P.stride = (unsigned long long)total + (unsigned long long)(P.blocks + 1) * P.chunk;
+        // items per queue grab: 2 (measured on the 16 x 119 k batch, 4 lanes: 1 -> 904, 2 -> 1062, 3 -> 980, 4 -> 936, 8 -> 845
+        // registrations/s: small grabs balance the tail of a pass, every change of problem costs a flush of ~170 atomics; a
+        // chunk sized by the kernel itself from the problems still iterating was slower than any fixed one)
+        P.chunk = h->ndt_chunk > 0 ? h->ndt_chunk : 2;
+        P.stride = (unsigned long long)total + (unsigned long long)(P.blocks + 1) * (unsigned long long)P.chunk;  // room for every block's last, failing grab
         P.queue = reinterpret_cast<unsigned long long*>((char*)h->ndt_plan.p + li * per_lane);
         P.tile_base = reinterpret_cast<int*>((char*)h->ndt_plan.p + li * per_lane + 16);
       }

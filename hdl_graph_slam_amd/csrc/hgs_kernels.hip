@@ -21,8 +21,9 @@
 namespace hgs {
 
 // ------------------------------------------------------------------------------------------------ helpers
-#ifndef HGS_OPAQUE_POINTER  // (the host emulation of tests/emul supplies its own spelling of the register constraint)
+#ifndef HGS_OPAQUE_POINTER  // (the host emulation of tests/emul supplies its own spelling of these two)
 #define HGS_OPAQUE_POINTER(p) asm volatile("" : "+v"(p))
+#define HGS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
@@ -52,15 +53,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 // counts finished problems and completed rounds in HBM and mirrors both into host-mapped pinned memory, so that the
 // host can keep the queue filled and stop enqueueing rounds without ever synchronising the stream.
 __device__ __forceinline__ void progress_tick(Progress p, bool finished_now) {
-  if (finished_now && atomicAdd(&p.dev[0], 1) + 1 == p.B) {
-    *p.host_done = 1;
-    __threadfence_system();
-  }
+  // the mirror lives in host-mapped memory: system-scope atomic stores reach it without a __threadfence_system(), whose cache
+  // write-back + invalidate would hit every block of a kernel that is still computing (k_ndt_pass ticks from inside)
+  if (finished_now && atomicAdd(&p.dev[0], 1) + 1 == p.B) __hip_atomic_store(const_cast<int*>(p.host_done), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int t = atomicAdd(&p.dev[1], 1) + 1;
-  if (t % p.B == 0) {
-    *p.host_rounds = t / p.B;
-    __threadfence_system();
-  }
+  if (t % p.B == 0) __hip_atomic_store(const_cast<int*>(p.host_rounds), t / p.B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Sum N per-thread doubles over a 256-thread block in a fixed order; thread k < N stores result k.
@@ -841,8 +838,7 @@ __device__ __forceinline__ int ndt_pop_cell(unsigned& mask, const int (&ci)[NOFF
 struct NdtPassShared {
   NdtAngles ang;
   unsigned long long tot[kBlock / 64][kAccNdt * 4];  // per wave: digit sums of the tiles since the last flush
-  unsigned long long w[kAccNdt * 4 + 4];             // finish: the problem's totals (+ contributions, ticket, overflow)
-  unsigned contrib[kBlock / 64];                     // per wave: lanes that went through the digit code since the last flush
+  unsigned long long w[kAccNdt * 4 + 4];             // finish: the problem's totals (+ ticket, overflow)
   double acc[kAccNdt];
   double svd[72];
   unsigned long long next;
@@ -851,19 +847,16 @@ struct NdtPassShared {
 
 // The block that completed problem b's tile count: totals -> doubles, Newton step.  All threads of the block call it.
 __device__ __noinline__ void ndt_finish_problem(NdtPassShared& S, NdtAccum& A, NdtState& st, NdtAngles& angles_b, const NdtConsts& c, int debug, Progress prog) {
-  __threadfence();
   const int t = (int)threadIdx.x;
   // read-and-clear (the next pass starts from zero), one exchange per thread so that they are all in flight together
   if (t < kAccNdt * 4) S.w[t] = atomicExch(&A.w[t], 0ull);
-  else if (t == kAccNdt * 4) S.w[t] = atomicExch(&A.contrib, 0ull);
   else if (t == kAccNdt * 4 + 1) S.w[t] = atomicExch(&A.tiles_done, 0u);
   else if (t == kAccNdt * 4 + 2) S.w[t] = atomicExch(&A.overflow, 0u);
   __syncthreads();
   if (t < kAccNdt) {
-    // every lane that went through the digit code added 2^26 to each high-digit total; chunk = high * 2^25 + low ; V = chunk0 * 2^50 + chunk1
-    const __int128 off = (__int128)S.w[kAccNdt * 4] * ((__int128)1 << 26);
-    const __int128 q0 = ((__int128)S.w[t * 4 + 2] - off) * ((__int128)1 << 25) + (__int128)S.w[t * 4];
-    const __int128 q1 = ((__int128)S.w[t * 4 + 3] - off) * ((__int128)1 << 25) + (__int128)S.w[t * 4 + 1];
+    // chunk = (signed) high digits * 2^25 + low digits ; V = chunk0 * 2^50 + chunk1
+    const __int128 q0 = (__int128)(long long)S.w[t * 4 + 2] * ((__int128)1 << 25) + (__int128)S.w[t * 4];
+    const __int128 q1 = (__int128)(long long)S.w[t * 4 + 3] * ((__int128)1 << 25) + (__int128)S.w[t * 4 + 1];
     S.acc[t] = S.w[kAccNdt * 4 + 2] ? __longlong_as_double(0x7ff8000000000000ll) : ndt_i128_to_double(q0 * ((__int128)1 << kNdtChunkBits) + q1, ndt_sum_exponent(t));
   }
   __syncthreads();
@@ -897,15 +890,14 @@ __device__ __noinline__ bool ndt_flush(NdtPassShared& S, NdtAccum& A, int tiles,
 #pragma unroll
     for (int w = 0; w < kBlock / 64; w++) v += S.tot[w][t], S.tot[w][t] = 0;
     if (v) atomicAdd(&A.w[t], v);
-  } else if (t == kAccNdt * 4) {
-    unsigned v = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; w++) v += S.contrib[w], S.contrib[w] = 0;
-    if (v) atomicAdd(&A.contrib, (unsigned long long)v);
   } else if (t == kAccNdt * 4 + 1) {
     if (S.out_of_range) atomicOr(&A.overflow, 1u), S.out_of_range = 0;
   }
-  __threadfence();
+  // The ticket below must not overtake the additions above.  Everything involved is a device-scope atomic read-modify-write
+  // (performed at the coherence point, never cached), so it is enough that this thread's have been acknowledged before the
+  // barrier: no __threadfence() here — on gfx950 its L2 write-back + invalidate would throw the cell table out of the
+  // XCD's L2 for every block of the kernel, several times per tile.
+  HGS_WAIT_VMEM();
   __syncthreads();
   if (t == 0) S.last = atomicAdd(&A.tiles_done, (unsigned)tiles) + (unsigned)tiles == (unsigned)tiles_total ? 1 : 0;
   __syncthreads();
@@ -919,7 +911,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
   __shared__ NdtPassShared S;
   const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
   for (int k = threadIdx.x; k < (kBlock / 64) * kAccNdt * 4; k += kBlock) (&S.tot[0][0])[k] = 0;
-  if (threadIdx.x < kBlock / 64) S.contrib[threadIdx.x] = 0;
   if (threadIdx.x == 0) S.out_of_range = 0, S.next = atomicAdd(queue, (unsigned long long)chunk);
   __syncthreads();
   const unsigned long long end = base + (unsigned long long)tile_base[B];
@@ -1030,22 +1021,41 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
         }
       }
       // ---- exact accumulation: per-point doubles -> four unsigned digits -> rows of the wave -> this wave's totals in LDS ----
-      // digits of a chunk q (|q| < 2^49, carried as the mantissa field 2^51 + q): q mod 2^25 and 2^26 + floor(q / 2^25), both
-      // non-negative; the 2^26 of every lane that goes through here is counted (S.contrib) and taken off once at the end.
-      // The last 16 -> 1 step of the wave sum is the LDS atomic itself (ds_add_u64, 16 lanes per address): it runs on the LDS
-      // pipe next to the VALU work of the other waves instead of four dependent DPP adds.  A wave none of whose points met a
-      // cell has nothing but zeros to add and skips all of it.
+      // digits of a chunk q (|q| < 2^49, carried as the mantissa field 2^51 + q): q mod 2^25 (the 64 lanes' sum stays below
+      // 2^31) and 2^26 + floor(q / 2^25) — the 2^26 of the 64 lanes add up to 2^32 and vanish from the 32-bit wave sum, which
+      // read as a signed integer is the sum of the floors (|.| < 2^30).
+      // The last 16 -> 1 steps are DPP row shifts (LDS atomics with 16 lanes per address were measured at ~500 cycles each);
+      // the row-end lanes then add into the wave's totals in LDS.  A wave none of whose points met a cell has nothing but
+      // zeros to add and skips all of it.
       if (any_cell) {
         bool bad = false;
 #pragma unroll
-        for (int k = 0; k < kAccNdt; k++) {
-          double m0, m1;
-          if (!ndt_exact_split(acc[k], ndt_sum_exponent(k), &m0, &m1)) bad = true;
-          const unsigned long long b0 = (unsigned long long)__double_as_longlong(m0), b1 = (unsigned long long)__double_as_longlong(m1);
-          const unsigned z = wave_rows4_u32((unsigned)b0 & 0x1ffffffu, (unsigned)(b0 >> 25) & 0x7ffffffu, (unsigned)b1 & 0x1ffffffu, (unsigned)(b1 >> 25) & 0x7ffffffu);
-          atomicAdd(&S.tot[wave][k * 4 + (lane >> 4)], (unsigned long long)z);  // rows: chunk0 low, chunk1 low, chunk0 high, chunk1 high
+        for (int k0 = 0; k0 < kAccNdt; k0 += 4) {
+          // four accumulators side by side: their dependent DPP chains fill each other's wait states
+          unsigned z[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int k = k0 + j < kAccNdt ? k0 + j : kAccNdt - 1;
+            double m0, m1;
+            if (!ndt_exact_split(acc[k], ndt_sum_exponent(k), &m0, &m1)) bad = true;
+            const unsigned long long b0 = (unsigned long long)__double_as_longlong(m0), b1 = (unsigned long long)__double_as_longlong(m1);
+            z[j] = wave_rows4_u32((unsigned)b0 & 0x1ffffffu, (unsigned)(b0 >> 25) & 0x7ffffffu, (unsigned)b1 & 0x1ffffffu, (unsigned)(b1 >> 25) & 0x7ffffffu);
+          }
+          // row_shr:1, 2, 4, 8: lane 15 of each 16-lane row ends up with the row's sum
+#pragma unroll
+          for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x111, 0xf, 0xf, true);
+#pragma unroll
+          for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x112, 0xf, 0xf, true);
+#pragma unroll
+          for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x114, 0xf, 0xf, true);
+#pragma unroll
+          for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x118, 0xf, 0xf, true);
+          if ((lane & 15) == 15) {  // rows: chunk0 low, chunk1 low, chunk0 high, chunk1 high
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (k0 + j < kAccNdt) S.tot[wave][(k0 + j) * 4 + (lane >> 4)] += lane < 32 ? (unsigned long long)z[j] : (unsigned long long)(long long)(int)z[j];
+          }
         }
-        if (lane == 0) S.contrib[wave] += 64u;
         if (__ballot(bad) != 0ull && lane == 0) S.out_of_range = 1;
       }
     }

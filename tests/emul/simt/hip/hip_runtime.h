@@ -13,6 +13,9 @@
 #endif
 #define HGS_SIMT_EMULATION 1
 #define HGS_OPAQUE_POINTER(p) asm volatile("" : "+r"(p))
+#define HGS_WAIT_VMEM() ((void)0)
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 
 #include <math.h>
 #include <stdint.h>
@@ -148,6 +151,7 @@ static inline void wave_barrier(int site = 0) {
 #define __lane_id() ((unsigned)simt::g_cur->lane)
 #define __builtin_amdgcn_readlane(v, l) simt::readlane((v), (l), __LINE__)
 #define __builtin_amdgcn_wave_barrier() simt::wave_barrier(__LINE__)
+#define __builtin_amdgcn_readfirstlane(v) (v)  /* only used on values that are wave-uniform by construction */
 #define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) simt::permlane_swap((a), (b), 32, __LINE__)
 #define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) simt::permlane_swap((a), (b), 16, __LINE__)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt::update_dpp_row_shr((src), (ctrl), __LINE__)
