@@ -14,8 +14,13 @@
 // align() builds in initCompute(); callers that want them on the device use fitnessScoreHIP() / nearestTargetHIP() below
 // (LoopDetector's batched path in INTEGRATION.md does).
 //
-// Not compilable in this repository's image (no PCL / ROS); tests/test_adapter_compiles.py compiles it against a minimal
-// stand-in of the pcl::Registration interface to keep it honest.
+// Not compilable against the real PCL in this repository's image (no PCL / ROS); tests/test_adapter_cpp.py compiles it against
+// a minimal stand-in of the pcl::Registration interface (tests/mock_pcl) and runs it on the GPU through the real library.
+//
+// Life cycle: a setter that changes an engine parameter after the engine exists re-creates the engine (recreate()); the
+// adapter's own target / source are uploaded again, but hgs_cloud handles a caller obtained through nativeHandle() belong to
+// the destroyed engine — hgs_destroy orphans them (safe to hgs_cloud_destroy, rejected by every other call), so configure the
+// object fully (the factory does) before caching device clouds.
 #pragma once
 
 #include <cstring>

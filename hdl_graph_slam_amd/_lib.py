@@ -13,13 +13,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhgs_hip.so")
 
 HGS_OK = 0
+HGS_ERR_INVALID_ARGUMENT, HGS_ERR_NO_TARGET, HGS_ERR_NO_SOURCE, HGS_ERR_HIP, HGS_ERR_NO_DEVICE, HGS_ERR_UNSUPPORTED, HGS_ERR_OUT_OF_MEMORY, HGS_ERR_INTERNAL = range(1, 9)
 HGS_FAST_GICP, HGS_FAST_VGICP, HGS_NDT_OMP = 0, 1, 2
 HGS_KDTREE, HGS_DIRECT1, HGS_DIRECT7, HGS_DIRECT27 = 0, 1, 2, 3
 HGS_REG_FROBENIUS, HGS_REG_PLANE, HGS_REG_MIN_EIG, HGS_REG_NORMALIZED_MIN_EIG, HGS_REG_NONE = 0, 1, 2, 3, 4
 STAGES = ["upload", "index", "covariance", "voxelize", "linearize", "error", "solve", "fitness", "prefilter"]
 DBL_MAX = float(np.finfo(np.float64).max)
 
-STATUS = {1: "invalid argument", 2: "no target set", 3: "no source set", 4: "HIP runtime error", 5: "no usable HIP device", 6: "unsupported"}
+STATUS = {1: "invalid argument", 2: "no target set", 3: "no source set", 4: "HIP runtime error", 5: "no usable HIP device", 6: "unsupported",
+          7: "out of host memory inside the backend", 8: "internal error (C++ exception caught at the C boundary)"}
 
 
 class HgsParams(C.Structure):

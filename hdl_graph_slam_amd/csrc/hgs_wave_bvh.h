@@ -164,9 +164,6 @@ struct PacketWalk {
 // record in VGPRs, L2-hit latency ~200 cycles instead of ~1000.
 __device__ __forceinline__ void fetch_record(const hgs_f16v* rec, float* slot /* wave-private, 128-byte aligned, 32 floats */, hgs_f16v& lo, hgs_f16v& hi) {
   const int l = (int)(__lane_id() & 31u);
-#ifdef HGS_SIMT_EMULATION  // host emulation of tests/emul only: packet-walk steps per launch (scripts/walk_steps_emulated.py)
-  if (__lane_id() == 0) simt::g_record_fetches++;
-#endif
   const float v = reinterpret_cast<const float*>(rec)[l];
   __builtin_amdgcn_wave_barrier();  // the previous record's reads are issued before the slot is overwritten
   slot[l] = v;

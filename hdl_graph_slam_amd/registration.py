@@ -52,9 +52,10 @@ class DeviceCloud:
             self._h = C.c_void_p()
 
     def __del__(self):
+        # also after the engine has been closed: hgs_destroy orphans the clouds it created (their device memory goes with the
+        # engine) and hgs_cloud_destroy of an orphan only frees the host-side object
         try:
-            if self._reg._h:
-                self.close()
+            self.close()
         except Exception:
             pass
 

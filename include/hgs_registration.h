@@ -109,6 +109,9 @@ typedef struct hgs_cloud hgs_cloud;   /* a point cloud resident in HBM (a KeyFra
 int hgs_params_default(int32_t method, hgs_params* p);
 /* Replaces `new fast_gicp::FastGICP / pclomp::NormalDistributionsTransform` + setters, registrations.cpp:27-36,101-120. */
 int hgs_create(const hgs_params* p, hgs_handle** out);
+/* Destroys the engine.  Clouds created on it that the caller has not destroyed yet are ORPHANED: their device memory is
+ * released with the engine, the hgs_cloud objects stay valid for exactly one more call — hgs_cloud_destroy — and every other
+ * entry point rejects them with HGS_ERR_INVALID_ARGUMENT (hgs_cloud_size reports 0).  Either order of destruction is safe. */
 int hgs_destroy(hgs_handle* h);
 const char* hgs_last_error(const hgs_handle* h); /* h may be NULL: error of the last failed hgs_create on this thread */
 int hgs_abi_version(void);

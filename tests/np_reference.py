@@ -143,6 +143,107 @@ def ndt_score(src, cells, p, res, direct7=True, freeze_p=None):
     return score
 
 
+def _rot_parts(r, snap=True):
+    """Rx, Ry, Rz and their first / second derivatives with respect to their own angle.  snap: ndt_omp's
+    computeAngleDerivatives treats |angle| < 10e-5 as exactly 0 (cos 1, sin 0)."""
+    out = []
+    for axis, a in enumerate(r):
+        if snap and abs(a) < 10e-5:
+            c, s = 1.0, 0.0
+        else:
+            c, s = np.cos(a), np.sin(a)
+        i, j = [(1, 2), (2, 0), (0, 1)][axis]
+        R, dR, ddR = np.eye(3), np.zeros((3, 3)), np.zeros((3, 3))
+        R[i, i], R[i, j], R[j, i], R[j, j] = c, -s, s, c
+        dR[i, i], dR[i, j], dR[j, i], dR[j, j] = -s, -c, c, -s
+        ddR[i, i], ddR[i, j], ddR[j, i], ddR[j, j] = -c, s, -s, -c
+        out.append((R, dR, ddR))
+    return out
+
+
+def ndt_derivatives(src, cells, p, res, direct7=True, upstream_hd1_sign=True, outlier_ratio=0.55):
+    """Score, gradient (6) and Hessian (6x6) of ndt_omp's objective at p = (t, rx, ry, rz), T(p) = Trans(t) Rx Ry Rz — an
+    INDEPENDENT float64 restatement of computeDerivatives / updateDerivatives (Magnusson 2009 eq. 6.12 / 6.13): the Jacobian and
+    the second derivatives of T(p) x come from products of elementary rotation derivatives, not from ndt_omp's j_ang / h_ang
+    tables (which is what oracle/ndt.hpp and the device restate), so a transcription error in those tables shows up here.
+    upstream_hd1_sign reproduces the one known quirk of those tables: the z entry of h_ang_d1 is +sin(ry) instead of -sin(ry).
+    Cells are assigned from the float32 transformed point like ndt_omp does."""
+    d1, d2 = ndt_gauss(res, outlier_ratio)
+    p = np.asarray(p, np.float64)
+    (Rx, dRx, ddRx), (Ry, dRy, ddRy), (Rz, dRz, ddRz) = _rot_parts(p[3:6], snap=True)   # derivative tables: snapped angles
+    R = ndt_pose(p)[:3, :3]                                                               # the transform itself: exact angles
+    dR = [dRx @ Ry @ Rz, Rx @ dRy @ Rz, Rx @ Ry @ dRz]
+    ddR = [[ddRx @ Ry @ Rz, dRx @ dRy @ Rz, dRx @ Ry @ dRz],
+           [None, Rx @ ddRy @ Rz, Rx @ dRy @ dRz],
+           [None, None, Rx @ Ry @ ddRz]]
+    if upstream_hd1_sign:
+        # d2(T x)_x / dry2 = (-cy cz, cy sz, -sy) . x ; ndt_omp's table carries +sy in the last slot
+        sy = 0.0 if abs(p[4]) < 10e-5 else np.sin(p[4])
+        ddR[1][1] = ddR[1][1].copy()
+        ddR[1][1][0, 2] += 2.0 * sy
+    for a in range(3):
+        for b in range(a):
+            ddR[a][b] = ddR[b][a]
+    T32 = np.eye(4, dtype=np.float32)
+    T32[:3, :3], T32[:3, 3] = R.astype(np.float32), p[:3].astype(np.float32)
+    src32 = np.asarray(src, np.float32)
+    # the float transform as a chain of fused multiply-adds, fmaf(T2, z, fmaf(T1, y, fmaf(T0, x, T3))) (a float product is exact
+    # in double, so each fma is one double multiply-add rounded to float): points near a cell face must land in the same cell
+    t64, x64 = T32.astype(np.float64), src32.astype(np.float64)
+    q32 = np.empty((len(src32), 3), np.float32)
+    for r_ in range(3):
+        acc = (t64[r_, 0] * x64[:, 0] + t64[r_, 3]).astype(np.float32).astype(np.float64)
+        acc = (t64[r_, 1] * x64[:, 1] + acc).astype(np.float32).astype(np.float64)
+        q32[:, r_] = (t64[r_, 2] * x64[:, 2] + acc).astype(np.float32)
+    ijk = np.floor(q32 * (np.float32(1.0) / np.float32(res))).astype(np.int64)
+    offs = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)] if direct7 else [(0, 0, 0)]
+    xs = np.asarray(src, np.float64)
+    xt = q32.astype(np.float64)   # ndt_omp evaluates the residual on the FLOAT transformed cloud (4e-6 m at 50 m: 1e-3 of a score term)
+    score, g, H = 0.0, np.zeros(6), np.zeros((6, 6))
+    for i in range(len(xs)):
+        x = xs[i]
+        J = np.zeros((3, 6))
+        J[:, :3] = np.eye(3)
+        for a in range(3):
+            J[:, 3 + a] = dR[a] @ x
+        for o in offs:
+            c = cells.get((ijk[i, 0] + o[0], ijk[i, 1] + o[1], ijk[i, 2] + o[2]))
+            if c is None:
+                continue
+            q = xt[i] - c[1]
+            S = c[2]
+            e = np.exp(-d2 / 2 * q @ S @ q)
+            if not (0 <= d2 * e <= 1):
+                continue
+            score += -d1 * e
+            w = d1 * d2 * e
+            qSJ = q @ S @ J
+            g += w * qSJ
+            Hp = -d2 * np.outer(qSJ, qSJ) + J.T @ S @ J
+            for a in range(3):
+                for b in range(3):
+                    Hp[3 + a, 3 + b] += q @ S @ (ddR[a][b] @ x)
+            H += w * Hp
+    return score, g, H
+
+
+def ndt_newton_step(g, H, step_size=0.1, trans_eps=0.01):
+    """One iteration of ndt_omp's computeTransformation as it actually runs (the More-Thuente loop never executes): the
+    Newton direction by SVD (pseudo-inverse), normalised, flipped if it is not a descent direction of -score, with the step
+    length min(max(|dp|, eps / 2), step_size).  Returns (unit direction, step length)."""
+    dp = np.linalg.pinv(H, rcond=1e-15) @ (-g)
+    n = np.linalg.norm(dp)
+    if n == 0 or not np.isfinite(n):
+        return dp, 0.0
+    dp = dp / n
+    d_phi_0 = -(g @ dp)
+    if d_phi_0 >= 0:
+        if d_phi_0 == 0:
+            return dp, 0.0
+        dp = -dp
+    return dp, max(min(n, step_size), trans_eps / 2)
+
+
 def vgicp_linearize(src, tgt, cov_s, cov_t, T, resolution, offsets=((0, 0, 0),)):
     """fast_gicp::FastVGICP (ADDITIVE voxels, SURVEY Appendix A.3): voxel = {n, mean of the points, mean of their
     covariances}, key floor(p / res - 0.5); every source point is matched against the voxel(s) of T a_i with weight

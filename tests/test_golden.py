@@ -129,3 +129,52 @@ def test_hip_reproduces_golden_v2():
         assert np.array_equal(np.stack([got["x"], got["y"], got["z"], got["intensity"]], axis=1), G2[name])
     _check_vgicp(e, tol_pose=1e-5, rel_stage=2e-5)
     e.close()
+
+
+# ---- a long NDT run, iteration by iteration (tests/golden/make_golden_ndt_trace.py) ------------------------------------------
+GN = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vlp16_ndt_long_run.npz"))
+
+
+def _ndt_params():
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution = 1.0
+    return p
+
+
+def test_oracle_reproduces_the_long_ndt_trace():
+    """Every iteration of a long NDT run: parameters, score and step length of the oracle's exact-sum mode equal the
+    committed trace (the arithmetic is a fixed sequence of IEEE operations: no libm exp, no order-dependent sums)."""
+    o = O.OracleRegistration(_ndt_params()).set_ndt_sum_mode(1)
+    o.setInputTarget(GN["target_xyz"])
+    o.setInputSource(GN["source_xyz"])
+    r = o.align(GN["guess"])
+    assert r.iterations == int(GN["iterations"]) >= 20 and r.lm_tries == int(GN["passes"])
+    tr = o.trace()
+    assert tr.shape == GN["trace"].shape and np.abs(tr - GN["trace"]).max() <= 1e-12 * max(1.0, np.abs(GN["trace"]).max())
+    assert np.array_equal(np.array(r.final_transformation, np.float32), GN["final"])
+    # the serial (ndt_omp) sum ends within the north-star tolerance of it
+    dt, dr = synth.pose_error(GN["final"].reshape(4, 4).T.astype(np.float64), GN["final_serial_sum"].reshape(4, 4).T.astype(np.float64))
+    assert dt <= 1e-3 and dr <= 1e-3
+
+
+def _check_long_ndt_run(make):
+    e = make(_ndt_params())
+    e.setInputTarget(GN["target_xyz"])
+    e.setInputSource(GN["source_xyz"])
+    r = e.align(GN["guess"])
+    assert r.iterations == int(GN["iterations"]) and r.lm_tries == int(GN["passes"]) and bool(r.converged) == bool(GN["converged"])
+    assert np.array_equal(np.array(r.final_transformation, np.float32), GN["final"])   # the same float matrix, bit for bit
+    e.close()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_the_long_ndt_run():
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    from hdl_graph_slam_amd import _lib as L
+
+    def make(params):
+        p = L.HgsParams()
+        for name, _ in L.HgsParams._fields_:
+            setattr(p, name, getattr(params, name))
+        return RegistrationHIP(p)
+    _check_long_ndt_run(make)

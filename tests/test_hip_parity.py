@@ -289,3 +289,24 @@ def test_batch_rejects_duplicate_candidates_and_foreign_clouds(gicp_case):
     rec, best = e.loop_match_batch([c], [np.eye(4, dtype=np.float32)])
     assert len(rec) == 1 and best in (0, -1)
     c.close()
+
+
+def test_clouds_outlive_their_engine_safely(gicp_case):
+    """hgs_destroy orphans the clouds the caller still holds: destroying or using them afterwards is defined —
+    hgs_cloud_destroy frees the orphan, everything else rejects it — instead of a use-after-free of the engine."""
+    import ctypes as C
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import HgsError
+    e, o, tgt, src, T = gicp_case
+    p = O.default_params(O.HGS_FAST_GICP)
+    a = _hip(p)
+    c = a.upload(src)
+    assert c.size == len(src)
+    a.close()                                     # engine first ...
+    assert L.lib().hgs_cloud_size(c._h) == 0      # ... the cloud is an orphan now
+    out = np.zeros(4, np.float32)
+    assert L.lib().hgs_cloud_download(c._h, out.ctypes.data_as(C.c_void_p), 16) == L.HGS_ERR_INVALID_ARGUMENT
+    with pytest.raises(HgsError):
+        e.setInputSource(c)                       # another engine rejects it as well
+    c.close()                                     # ... and destroying it afterwards is fine
+    e.setInputSource(src)

@@ -224,3 +224,53 @@ def test_ndt_line_search_tames_the_clamped_newton_steps(medium_pair):
     assert plain.lm_tries == plain.iterations + 1                      # one derivative pass per iteration
     assert searched.converged and searched.iterations < plain.iterations and searched.lm_tries > searched.iterations + 1
     assert synth.pose_error(searched.matrix(), T)[0] <= synth.pose_error(plain.matrix(), T)[0] + 1e-3
+
+
+@pytest.mark.parametrize("search,hd1", [(O.HGS_DIRECT7, 1), (O.HGS_DIRECT7, 0), (O.HGS_DIRECT1, 1)])
+def test_ndt_derivatives_and_newton_step_match_the_independent_numpy_restatement(search, hd1):
+    """Second pin of the NDT engine: score, gradient, Hessian and the clamped Newton step of oracle/ndt.hpp
+    against tests/np_reference.ndt_derivatives — float64, rotation derivatives from elementary rotation matrices instead of
+    ndt_omp's j_ang / h_ang tables — at several poses including large angles, angles inside the small-angle snap and the
+    upstream h_ang_d1 quirk; then one full oracle iteration (trace) against the numpy step from the numpy derivatives."""
+    from hdl_graph_slam_amd import synth as S
+    tgt, src, T = S.make_pair("VLP-16", 1, downsample=0.15)
+    src = src[::9]
+    r = _ndt(tgt, src, neighbor_search=search, ndt_upstream_hd1_sign=hd1)
+    cells = NP.ndt_cells(S.xyz_of(tgt), 1.0)
+    xs = S.xyz_of(src)
+    yaw = np.arctan2(T[1, 0], T[0, 0])
+    poses = [np.array([T[0, 3] + 0.03, T[1, 3] - 0.02, T[2, 3] + 0.01, 0.004, -0.006, yaw + 0.003]),
+             np.array([T[0, 3], T[1, 3], T[2, 3], 0.2, -0.35, yaw + 0.1]),          # large roll / pitch: the h_ang terms matter
+             np.array([T[0, 3], T[1, 3], T[2, 3], 5e-5, -2e-5, yaw]),              # inside the small-angle snap
+             np.zeros(6)]
+    for p0 in poses:
+        s0, g, H = r.ndt_derivatives(p0)
+        s1, g1, H1 = NP.ndt_derivatives(xs, cells, p0, 1.0, direct7=(search == O.HGS_DIRECT7), upstream_hd1_sign=bool(hd1))
+        # the oracle evaluates per-point terms in float like ndt_omp: agreement at the float level (1e-4 relative), far
+        # below any table or sign error (which shows up at O(1))
+        assert abs(s0 - s1) <= 2e-5 * abs(s1), (s0, s1)
+        assert np.abs(g - g1).max() <= 3e-4 * np.abs(g1).max(), np.abs(g - g1).max() / np.abs(g1).max()
+        assert np.abs(H - H1).max() <= 3e-4 * np.abs(H1).max(), np.abs(H - H1).max() / np.abs(H1).max()
+        # exact-sum mode of the oracle: the same numbers up to the rounding of the serial sum it replaces
+        rx = _ndt(tgt, src, neighbor_search=search, ndt_upstream_hd1_sign=hd1).set_ndt_sum_mode(1)
+        sx, gx, Hx = rx.ndt_derivatives(p0)
+        assert abs(sx - s0) <= 1e-12 * abs(s0) and np.abs(Hx - H).max() <= 1e-12 * np.abs(H).max() and np.abs(gx - g).max() <= 1e-11 * np.abs(g).max() + 1e-12
+    # one iteration: guess -> p1 = p0 + dp * a_t
+    guess = T @ S.pose_matrix([0.05, 0.02, 0.0], [0.0, 0.0, 0.004])
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution, p.neighbor_search, p.ndt_upstream_hd1_sign, p.max_iterations = 1.0, search, hd1, 0
+    r1 = O.OracleRegistration(p)
+    r1.setInputTarget(tgt)
+    r1.setInputSource(src)
+    r1.align(guess)
+    tr = r1.trace()
+    g32 = guess.astype(np.float32).astype(np.float64)             # ndt_omp reads the guess as a float matrix
+    # R = Rx Ry Rz on the principal branch (Eigen's eulerAngles(0,1,2) may return the other branch of the same rotation; the
+    # Newton step is invariant under that affine change of angles, so poses are compared, not parameter vectors)
+    p_start = np.array([g32[0, 3], g32[1, 3], g32[2, 3], np.arctan2(-g32[1, 2], g32[2, 2]), np.arcsin(g32[0, 2]), np.arctan2(-g32[0, 1], g32[0, 0])])
+    p_start[3:] = p_start[3:].astype(np.float32).astype(np.float64)   # ... and keeps the angles in float
+    _, g1, H1 = NP.ndt_derivatives(xs, cells, p_start, 1.0, direct7=(search == O.HGS_DIRECT7), upstream_hd1_sign=bool(hd1))
+    dp, a_t = NP.ndt_newton_step(g1, H1, step_size=p.ndt_step_size, trans_eps=p.transformation_epsilon)
+    first = tr[0, :6]     # trace rows: p (6), score, step
+    assert abs(tr[0, 7] - a_t) <= 1e-6 * a_t, (tr[0, 7], a_t)
+    assert np.abs(NP.ndt_pose(first) - NP.ndt_pose(p_start + dp * a_t)).max() <= 2e-5, (first, p_start + dp * a_t)

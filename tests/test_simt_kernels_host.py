@@ -439,3 +439,29 @@ def test_batch_records_do_not_depend_on_the_lane_count(monkeypatch):
         records.append((rec.tobytes(), best))
         reg.close()
     assert records[0] == records[1]
+
+
+def test_clouds_outlive_their_engine_safely():
+    """hgs_destroy orphans the clouds the caller still holds: hgs_cloud_destroy frees the orphan, every other call rejects it."""
+    import ctypes as C
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import HgsError
+    tgt, src, T = _pair("vlp16")
+    p = O.default_params(O.HGS_FAST_GICP)
+    a, b = _engine(p), _engine(p)
+    c = a.upload(src)
+    assert c.size == len(src)
+    a.close()
+    assert L.lib().hgs_cloud_size(c._h) == 0
+    out = np.zeros(4, np.float32)
+    assert L.lib().hgs_cloud_download(c._h, out.ctypes.data_as(C.c_void_p), 16) == L.HGS_ERR_INVALID_ARGUMENT
+    with pytest.raises(HgsError):
+        b.setInputSource(c)
+    c.close()
+    b.close()
+
+
+def test_long_ndt_run_ends_on_the_golden_float_matrix():
+    """66 iterations of the emulated k_ndt_pass end bit for bit where the committed oracle trace (exact-sum mode) ends."""
+    from test_golden import _check_long_ndt_run
+    _check_long_ndt_run(_engine)
