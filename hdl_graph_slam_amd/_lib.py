@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhgs_hip.so")
 
 HGS_OK = 0
-HGS_ERR_INVALID_ARGUMENT, HGS_ERR_NO_TARGET, HGS_ERR_NO_SOURCE, HGS_ERR_HIP, HGS_ERR_NO_DEVICE, HGS_ERR_UNSUPPORTED, HGS_ERR_OUT_OF_MEMORY, HGS_ERR_INTERNAL = range(1, 9)
+HGS_ERR_INVALID_ARGUMENT, HGS_ERR_NO_TARGET, HGS_ERR_NO_SOURCE, HGS_ERR_HIP, HGS_ERR_NO_DEVICE, HGS_ERR_UNSUPPORTED, HGS_ERR_OUT_OF_MEMORY, HGS_ERR_INTERNAL, HGS_ERR_COMM = range(1, 10)
 HGS_FAST_GICP, HGS_FAST_VGICP, HGS_NDT_OMP = 0, 1, 2
 HGS_KDTREE, HGS_DIRECT1, HGS_DIRECT7, HGS_DIRECT27 = 0, 1, 2, 3
 HGS_REG_FROBENIUS, HGS_REG_PLANE, HGS_REG_MIN_EIG, HGS_REG_NORMALIZED_MIN_EIG, HGS_REG_NONE = 0, 1, 2, 3, 4
@@ -21,7 +21,7 @@ STAGES = ["upload", "index", "covariance", "voxelize", "linearize", "error", "so
 DBL_MAX = float(np.finfo(np.float64).max)
 
 STATUS = {1: "invalid argument", 2: "no target set", 3: "no source set", 4: "HIP runtime error", 5: "no usable HIP device", 6: "unsupported",
-          7: "out of host memory inside the backend", 8: "internal error (C++ exception caught at the C boundary)"}
+          7: "out of host memory inside the backend", 8: "internal error (C++ exception caught at the C boundary)", 9: "communicator error (RCCL)"}
 
 
 class HgsParams(C.Structure):
@@ -75,6 +75,7 @@ EXPORTS = [
     "hgs_set_target", "hgs_set_target_cloud", "hgs_set_source", "hgs_set_source_cloud",
     "hgs_align", "hgs_transform_source", "hgs_fitness", "hgs_nn_target",
     "hgs_loop_match_batch", "hgs_select_best", "hgs_calc_fitness_score",
+    "hgs_comm_get_unique_id", "hgs_comm_init", "hgs_comm_finalize", "hgs_loop_match_batch_sharded",
     "hgs_prefilter_params_default", "hgs_prefilter", "hgs_cloud_download", "hgs_map_cloud_generate",
     "hgs_profile_enable", "hgs_profile_read", "hgs_synchronize",
     "hgs_debug_target_covariances", "hgs_debug_gicp_linearize", "hgs_debug_ndt_cells", "hgs_debug_ndt_derivatives",
@@ -112,6 +113,10 @@ def lib():
     L.hgs_nn_target.argtypes = [vp, vp, sz, sz, vp, vp]
     L.hgs_loop_match_batch.argtypes = [vp, C.POINTER(vp), sz, vp, C.c_double, vp, C.POINTER(C.c_int32)]
     L.hgs_select_best.argtypes = [vp, sz, C.POINTER(C.c_int32)]
+    L.hgs_comm_get_unique_id.argtypes = [vp]
+    L.hgs_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    L.hgs_comm_finalize.argtypes = [vp]
+    L.hgs_loop_match_batch_sharded.argtypes = [vp, C.POINTER(vp), sz, vp, vp, sz, C.c_double, vp, C.POINTER(C.c_int32)]
     L.hgs_calc_fitness_score.argtypes = [vp, vp, vp, fp, C.c_double, C.POINTER(C.c_double)]
     L.hgs_prefilter_params_default.argtypes = [C.POINTER(HgsPrefilterParams)]
     L.hgs_prefilter.argtypes = [vp, vp, sz, sz, C.POINTER(HgsPrefilterParams), C.POINTER(vp)]

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhgs_hip.so")
-SOURCES = ["hgs_sort.hip", "hgs_kernels.hip", "hgs_engine.hip"]
+SOURCES = ["hgs_sort.hip", "hgs_kernels.hip", "hgs_engine.hip", "hgs_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -44,7 +44,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

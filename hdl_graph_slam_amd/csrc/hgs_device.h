@@ -110,6 +110,10 @@ void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out,
 void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks, int B,
                     int use_seed, int qpw);
 void launch_fitness_final(hipStream_t s, const CloudDesc* descs, const double* partials, int max_blocks, DevResult* out, int B, int tile_pts);
+}  // namespace hgs
+struct hgs_result;  // include/hgs_registration.h
+namespace hgs {
+void launch_results_to_records(hipStream_t s, const DevResult* res, const int* candidate_ids, int n, int n_slots, ::hgs_result* out);
 void launch_nn_query(hipStream_t s, TargetView tgt, const float4* q, int nq, int* idx, float* d2);
 void launch_transform(hipStream_t s, const float4* raw, int n, const float* T16_colmajor_dev, float4* out);
 

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/hgs_registration.h"
+#include "hgs_comm.h"
 #include "hgs_device.h"
 #include "hgs_sort.h"
 
@@ -143,6 +144,8 @@ struct hgs_handle {
   DeviceBuffer staging, sort_keys[2], sort_vals[2], sort_tmp, descs, states, angles, partials, partials_err, results, guesses, done, misc;
   DeviceBuffer lane_partials[3], lane_partials_err[3];
   DeviceBuffer ndt_accum;  // NdtAccum per problem of the running NDT batch
+  hgs::Comm* comm = nullptr;            // hgs_comm_init: the ranks of a sharded loop-closure batch
+  DeviceBuffer comm_send, comm_recv, comm_ids;
   DeviceBuffer ndt_plan;         // per lane: work queue head + tile prefix sums of the running NDT batch
   int ndt_resident_blocks = 512; // blocks per k_ndt_pass launch (2 per CU); HGS_NDT_RESIDENT (A/B runs)
   int ndt_chunk = 0;             // items per queue grab (0: the default, 2); HGS_NDT_CHUNK (A/B runs)
@@ -975,6 +978,7 @@ int hgs_destroy(hgs_handle* h) try {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (hipStream_t ls : h->lane_stream)
     if (ls) (void)hipStreamSynchronize(ls);
+  if (h->comm) hgs::comm_destroy(h->comm), h->comm = nullptr;
   if (h->own_target) cloud_free(h->target);
   if (h->own_source) cloud_free(h->source);
   // clouds the caller still holds (hgs_cloud_create / hgs_prefilter results, cached keyframes): their device memory goes with
@@ -987,7 +991,8 @@ int hgs_destroy(hgs_handle* h) try {
   h->live_clouds.clear();
   DeviceBuffer* bufs[] = {&h->staging, &h->sort_keys[0], &h->sort_keys[1], &h->sort_vals[0], &h->sort_vals[1], &h->sort_tmp, &h->descs, &h->states,
                           &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc,
-                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum,    &h->ndt_plan};
+                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum,    &h->ndt_plan,
+                          &h->comm_send, &h->comm_recv,    &h->comm_ids};
   for (DeviceBuffer* b : bufs) b->release();
   for (int i = 0; i < 3; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
   for (hipEvent_t ev : h->lane_event)
@@ -1271,6 +1276,103 @@ int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_c
   HGS_TRY(fetch_results(h, (int)n_candidates, r));
   for (size_t i = 0; i < n_candidates; i++) to_public(r[i], (int)i, true, &out[i]);
   if (best) HGS_TRY(hgs_select_best(out, n_candidates, best));
+  return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
+}
+
+// ---- multi-GPU: candidate-sharded loop-closure batch, one process per GPU ---------------------------------------
+int hgs_comm_get_unique_id(void* id_out) try {
+  if (!id_out) return HGS_ERR_INVALID_ARGUMENT;
+  char err[256] = "";
+  if (hgs::comm_unique_id(id_out, err, sizeof(err)) != 0) {
+    g_create_error = err;
+    return HGS_ERR_COMM;
+  }
+  return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(nullptr);
+}
+
+int hgs_comm_init(hgs_handle* h, int32_t rank, int32_t world, const void* unique_id) try {
+  if (!h || !unique_id || world < 1 || rank < 0 || rank >= world) return HGS_ERR_INVALID_ARGUMENT;
+  HGS_TRY(set_device(h));
+  if (h->comm) hgs::comm_destroy(h->comm), h->comm = nullptr;
+  char err[256] = "";
+  if (hgs::comm_create(&h->comm, rank, world, unique_id, h->device, err, sizeof(err)) != 0) {
+    h->err = err;
+    return HGS_ERR_COMM;
+  }
+  return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
+}
+
+int hgs_comm_finalize(hgs_handle* h) try {
+  if (!h) return HGS_ERR_INVALID_ARGUMENT;
+  if (h->comm) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    hgs::comm_destroy(h->comm);
+    h->comm = nullptr;
+  }
+  return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
+}
+
+int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, size_t n_mine, const int32_t* candidate_ids, const float* guesses,
+                                 size_t n_total, double max_range, hgs_result* all_out, int32_t* best) try {
+  if (!h || !all_out || n_total == 0 || n_total > (size_t)1 << 24 || (n_mine > 0 && (!candidates || !candidate_ids || !guesses))) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h->comm) {
+    h->err = "hgs_loop_match_batch_sharded: hgs_comm_init has not been called on this engine";
+    return HGS_ERR_COMM;
+  }
+  if (!h->target) return HGS_ERR_NO_TARGET;
+  if (best) *best = -1;
+  HGS_TRY(set_device(h));
+  const int world = hgs::comm_world(h->comm);
+  // Records every rank sends: its own, then padding.  n_total slots, so that ANY partition works without a second collective
+  // to agree on the largest shard — keyframes are cached on the GPU of keyframe_id mod world, and the candidates of one
+  // detection need not spread evenly.  512 candidates x 8 ranks x 112 B = 458 KB per batch: still a latency-bound exchange.
+  const size_t per = n_total;
+  if (n_mine > per) return HGS_ERR_INVALID_ARGUMENT;
+  std::vector<hgs_cloud*> src(candidates, candidates + n_mine);
+  for (size_t i = 0; i < n_mine; i++)
+    if (!src[i] || src[i]->owner != h || candidate_ids[i] < 0 || (size_t)candidate_ids[i] >= n_total) return HGS_ERR_INVALID_ARGUMENT;
+  {
+    std::vector<hgs_cloud*> sorted(src);
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) {
+      h->err = "hgs_loop_match_batch_sharded: candidate clouds must be distinct";
+      return HGS_ERR_INVALID_ARGUMENT;
+    }
+  }
+  if (n_mine > 0) HGS_TRY(run_batch(h, src, guesses, &max_range));
+  // records of this rank, built on the device from the batch's results and gathered from there: no host copy in between
+  HGS_HIP(h, h->results.reserve(sizeof(DevResult)));
+  HGS_HIP(h, h->comm_send.reserve(per * sizeof(hgs_result)));
+  HGS_HIP(h, h->comm_recv.reserve((size_t)world * per * sizeof(hgs_result)));
+  HGS_HIP(h, h->comm_ids.reserve(std::max<size_t>(n_mine, 1) * sizeof(int32_t)));
+  if (n_mine > 0) HGS_HIP(h, hipMemcpyAsync(h->comm_ids.p, candidate_ids, n_mine * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  launch_results_to_records(h->stream, h->results.as<DevResult>(), h->comm_ids.as<int>(), (int)n_mine, (int)per, h->comm_send.as<hgs_result>());
+  HGS_HIP(h, hipGetLastError());
+  char err[256] = "";
+  if (hgs::comm_all_gather(h->comm, h->comm_send.p, h->comm_recv.p, per * sizeof(hgs_result), h->stream, err, sizeof(err)) != 0) {
+    h->err = err;
+    return HGS_ERR_COMM;
+  }
+  std::vector<hgs_result> gathered((size_t)world * per);
+  HGS_HIP(h, hipMemcpyAsync(gathered.data(), h->comm_recv.p, gathered.size() * sizeof(hgs_result), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < n_total; i++) {  // a candidate no rank reported stays "not converged"
+    std::memset(&all_out[i], 0, sizeof(hgs_result));
+    all_out[i].candidate_id = (int32_t)i;
+    all_out[i].fitness_score = std::numeric_limits<double>::max();
+  }
+  for (const hgs_result& r : gathered)
+    if (r.candidate_id >= 0 && (size_t)r.candidate_id < n_total) all_out[r.candidate_id] = r;
+  if (best) HGS_TRY(hgs_select_best(all_out, n_total, best));
   return HGS_OK;
 } catch (...) {
   return status_of_current_exception(h);

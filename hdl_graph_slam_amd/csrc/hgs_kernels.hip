@@ -15,6 +15,7 @@
 // (hgs_wave_bvh.h), the per-point algebra by HBM: no MFMA (the contraction is 6x6), coalesced float4 loads, wave64
 // shuffle reductions, deterministic two-stage sums.
 #include <hip/hip_runtime.h>
+#include "../../include/hgs_registration.h"
 #include "hgs_device.h"
 #include "hgs_wave_bvh.h"
 
@@ -630,6 +631,34 @@ __global__ __launch_bounds__(64) void k_fitness_final(const CloudDesc* descs, co
 }
 void launch_fitness_final(hipStream_t s, const CloudDesc* descs, const double* partials, int max_blocks, DevResult* out, int B, int tile_pts) {
   hipLaunchKernelGGL(k_fitness_final, dim3(B), dim3(64), 0, s, descs, partials, max_blocks, out, tile_pts);
+}
+
+// DevResult -> the public per-candidate record (hgs_result, include/hgs_registration.h), written where the all-gather of a
+// sharded batch sends from: slot s < n_slots, padded with candidate_id -1 records beyond this rank's n candidates.
+__global__ void k_results_to_records(const DevResult* __restrict__ res, const int* __restrict__ candidate_ids, int n, int n_slots, hgs_result* __restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  hgs_result r;
+  if (s < n) {
+    const DevResult d = res[s];
+#pragma unroll
+    for (int k = 0; k < 16; k++) r.final_transformation[k] = d.T[k];
+    r.converged = d.converged, r.iterations = d.iterations;
+    r.error = d.error;
+    r.num_inliers = d.fit_count;
+    r.fitness_score = d.fit_count > 0 ? d.fit_sum / (double)d.fit_count : DBL_MAX;
+    r.candidate_id = candidate_ids[s];
+    r.lm_tries = d.lm_tries, r.reserved = 0;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) r.final_transformation[k] = 0.f;
+    r.converged = 0, r.iterations = 0, r.error = 0.0, r.fitness_score = DBL_MAX, r.num_inliers = 0, r.candidate_id = -1, r.lm_tries = 0, r.reserved = 0;
+  }
+  out[s] = r;
+}
+void launch_results_to_records(hipStream_t s, const DevResult* res, const int* candidate_ids, int n, int n_slots, hgs_result* out) {
+  if (n_slots <= 0) return;
+  hipLaunchKernelGGL(k_results_to_records, dim3((n_slots + 63) / 64), dim3(64), 0, s, res, candidate_ids, n, n_slots, out);
 }
 
 __global__ __launch_bounds__(kBlock) void k_nn_query(TargetView tgt, const float4* __restrict__ q, int nq, int* __restrict__ idx, float* __restrict__ d2out) {

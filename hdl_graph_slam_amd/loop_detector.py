@@ -27,6 +27,7 @@ class KeyFrame:
     estimate: np.ndarray              # node->estimate(): 4x4 float64
     accum_distance: float
     device_cloud: Optional[DeviceCloud] = None   # resident copy (uploaded once, reused for every later detection)
+    id: int = -1                      # KeyFrame::id(): the pose-graph node id — the stable identity multi-GPU sharding uses
 
 
 @dataclasses.dataclass(eq=False)
@@ -114,8 +115,13 @@ class LoopDetector:
         reg.setInputTarget(self._resident(new_keyframe))                                  # loop_detector.hpp:122
         guesses = [loop_guess(new_keyframe.estimate, c.estimate) for c in candidates]
         if self.shard is not None:
-            records, best = self.shard.match(reg, [self._resident(c) if self.shard.owns(i) else None for i, c in enumerate(candidates)], guesses,
-                                             self.fitness_score_max_range)
+            # shard by the keyframe's id, not by its position in this detection's list: the resident cloud (and its index /
+            # covariances) of a keyframe then lives on one rank for good
+            from .distributed import owner_of
+            ids = [c.id if c.id >= 0 else i for i, c in enumerate(candidates)]
+            mine = [owner_of(k, self.shard.world_size) == self.shard.rank for k in ids]
+            records, best = self.shard.match(reg, [self._resident(c) if m else None for c, m in zip(candidates, mine)], guesses,
+                                             self.fitness_score_max_range, keyframe_ids=ids)
         else:
             records, best = reg.loop_match_batch([self._resident(c) for c in candidates], guesses, self.fitness_score_max_range)
         self.last_records = records

@@ -193,6 +193,36 @@ class RegistrationHIP:
                                                  C.byref(best)))
         return out, best.value
 
+    # ---- sharded batch: one process per GPU, records all-gathered by RCCL on the engine's stream (include/hgs_registration.h)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the 128-byte RCCL id every rank passes to comm_init (hand it over with whatever launched the processes)."""
+        buf = (C.c_ubyte * 128)()
+        rc = L.lib().hgs_comm_get_unique_id(buf)
+        if rc != L.HGS_OK:
+            raise HgsError(f"hgs_comm_get_unique_id: {L.STATUS.get(rc, rc)}")
+        return bytes(buf)
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self._check(L.lib().hgs_comm_init(self._h, int(rank), int(world), buf))
+
+    def comm_finalize(self):
+        self._check(L.lib().hgs_comm_finalize(self._h))
+
+    def loop_match_batch_sharded(self, candidates, candidate_ids, guesses, n_total: int, max_range: float = L.DBL_MAX):
+        """This rank's candidates (DeviceClouds, their positions in the detection's candidate list, their guesses) -> the records of
+        ALL n_total candidates in candidate order and the index the sequential rule selects.  Collective over the communicator."""
+        n = len(candidates)
+        ptrs = (C.c_void_p * max(n, 1))(*[c._h for c in candidates])
+        ids = np.ascontiguousarray(np.asarray(candidate_ids, np.int32).reshape(-1))
+        g = np.ascontiguousarray(np.stack([L.colmajor16(T) for T in guesses]) if n else np.zeros((0, 16), np.float32))
+        out = np.zeros(int(n_total), dtype=L.RESULT_DTYPE)
+        best = C.c_int32(-1)
+        self._check(L.lib().hgs_loop_match_batch_sharded(self._h, ptrs, n, ids.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), int(n_total),
+                                                         float(max_range), out.ctypes.data_as(C.c_void_p), C.byref(best)))
+        return out, best.value
+
     def calc_fitness_score(self, cloud1: DeviceCloud, cloud2: DeviceCloud, relpose, max_range: float = L.DBL_MAX) -> float:
         """InformationMatrixCalculator::calc_fitness_score (src/hdl_graph_slam/information_matrix_calculator.cpp:49-80)."""
         g = L.colmajor16(relpose)

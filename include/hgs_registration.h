@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 2
+#define HGS_ABI_VERSION 3
 
 enum hgs_status {
   HGS_OK = 0,
@@ -37,7 +37,8 @@ enum hgs_status {
   HGS_ERR_NO_DEVICE = 5,
   HGS_ERR_UNSUPPORTED = 6,
   HGS_ERR_OUT_OF_MEMORY = 7, /* host allocation failed inside the backend (std::bad_alloc caught at the boundary) */
-  HGS_ERR_INTERNAL = 8       /* any other C++ exception caught at the boundary; hgs_last_error() has the text */
+  HGS_ERR_INTERNAL = 8,      /* any other C++ exception caught at the boundary; hgs_last_error() has the text */
+  HGS_ERR_COMM = 9           /* RCCL call failed / hgs_comm_init missing; hgs_last_error() has the text */
 };
 
 /* registration_method strings of registrations.cpp:26-121 that this backend implements. */
@@ -154,6 +155,29 @@ int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_c
 /* Pure host helper: the sequential selection rule above applied to an arbitrary record list (used after the
  * multi-GPU all-gather of per-candidate records). */
 int hgs_select_best(const hgs_result* records, size_t n, int32_t* best);
+
+/* ---- the same batch sharded over the GPUs of a node, one process (one engine) per GPU — SURVEY §8e --------------------
+ * The caller partitions the n_total candidates of a detection over the ranks any way it likes — typically by a stable keyframe
+ * identity (keyframe id mod world), so that a keyframe's resident cloud, index and covariances stay on one GPU across
+ * detections; a rank may hold none.  Every rank holds the query keyframe as its target
+ * (hgs_set_target*: replicated, rebuilding its 1 MB index per rank is cheaper than broadcasting it), registers ITS candidates
+ * and contributes their records to ONE all-gather of fixed-size hgs_result records (RCCL ncclAllGather over xGMI, issued on the
+ * engine's stream directly behind the kernels that produced the records: no torch, no host staging); afterwards every rank
+ * holds all n_total records in candidate order and applies the sequential rule of loop_detector.hpp:146-153 to them.
+ * This replaces the loop of loop_detector.hpp:135-154 on a multi-GPU node.
+ *
+ * hgs_comm_get_unique_id: rank 0 creates the 128-byte RCCL id and hands it to the other ranks out of band (MPI, a file,
+ * torch.distributed.broadcast_object_list — whatever launched the processes).  hgs_comm_init is collective over the ranks. */
+#define HGS_COMM_UNIQUE_ID_BYTES 128
+int hgs_comm_get_unique_id(void* id_out /* HGS_COMM_UNIQUE_ID_BYTES */);
+int hgs_comm_init(hgs_handle* h, int32_t rank, int32_t world, const void* unique_id /* HGS_COMM_UNIQUE_ID_BYTES */);
+int hgs_comm_finalize(hgs_handle* h); /* also done by hgs_destroy */
+/* candidates / candidate_ids / guesses describe THIS rank's n_mine candidates (candidate_ids[i] in [0, n_total) is the position
+ * of candidates[i] in the detection's candidate list); all_out receives n_total records, all_out[c].candidate_id == c;
+ * *best as hgs_loop_match_batch.  Collective: every rank of the communicator must call it, with the same n_total. */
+int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, size_t n_mine, const int32_t* candidate_ids,
+                                 const float* guesses /* 16*n_mine */, size_t n_total, double max_range, hgs_result* all_out,
+                                 int32_t* best);
 
 /* ---- "next" row f1: InformationMatrixCalculator::calc_fitness_score (information_matrix_calculator.cpp:49-80) */
 int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, const float relpose[16], double max_range, double* score);

@@ -289,3 +289,31 @@ extern "C" void simt_read_counters(unsigned long long* out2) {
   out2[0] = simt::g_record_fetches, out2[1] = simt::g_waves_launched;
   simt::g_record_fetches = 0, simt::g_waves_launched = 0;
 }
+
+// ------------------------------------------------------------------------------------------------ hgs_comm.h on the host
+// single-rank stand-in for the RCCL exchange step: the "all-gather" of one rank is a copy
+#include "../../hdl_graph_slam_amd/csrc/hgs_comm.h"
+namespace hgs {
+struct Comm {
+  int rank, world;
+};
+int comm_unique_id(void* id_out, char*, size_t) {
+  memset(id_out, 0x5a, kCommUniqueIdBytes);
+  return 0;
+}
+int comm_create(Comm** out, int rank, int world, const void*, int, char* err, size_t cap) {
+  if (world != 1) {
+    if (err && cap) snprintf(err, cap, "the host emulation has one rank");
+    return 1;
+  }
+  *out = new Comm{rank, world};
+  return 0;
+}
+void comm_destroy(Comm* c) { delete c; }
+int comm_rank(const Comm* c) { return c->rank; }
+int comm_world(const Comm* c) { return c->world; }
+int comm_all_gather(Comm*, const void* send, void* recv, size_t bytes_per_rank, hipStream_t, char*, size_t) {
+  memmove(recv, send, bytes_per_rank);
+  return 0;
+}
+}  // namespace hgs

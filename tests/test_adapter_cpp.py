@@ -52,3 +52,42 @@ def test_adapter_matches_python_mirror(tmp_path, method):
     assert np.array_equal(Tc, r.matrix())                       # same library, same inputs: identical bits
     assert abs(float(out[2].split()[1]) - reg.getFitnessScore()) < 1e-9      # printed with 12 significant digits
     reg.close()
+
+
+@pytest.mark.gpu
+def test_cpp_loop_matcher_on_the_gpu(tmp_path):
+    """adapters/loop_match_hip.hpp (the replacement of the loop body of LoopDetector::matching, loop_detector.hpp:135-154)
+    compiled against the REAL libhgs_hip.so and run on the GPU: two detections over resident keyframes, against the Python
+    mirror's batches, bit for bit."""
+    from hdl_graph_slam_amd import build as hip_build, workloads, _lib as L
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    lib = hip_build.build_lib()
+    exe = os.path.join(ROOT, "tests", "cpp", "loop_match_main")
+    src_cpp = os.path.join(ROOT, "tests", "cpp", "loop_match_main.cpp")
+    deps = [src_cpp, os.path.join(ROOT, "adapters", "loop_match_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"), lib]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), src_cpp, "-o", exe, "-L", os.path.dirname(lib), "-lhgs_hip",
+                        f"-Wl,-rpath,{os.path.dirname(lib)}"], check=True)
+    wl = workloads.make_loop_closure_set("VLP-16", 3, n_candidates=5, n_distinct=3, downsample=0.4)
+    wl.target.tofile(tmp_path / "t.bin")
+    np.stack([L.colmajor16(g) for g in wl.guesses]).astype(np.float32).tofile(tmp_path / "g.bin")
+    files = []
+    for i, c in enumerate(wl.candidates):
+        c.tofile(tmp_path / f"c{i}.bin")
+        files.append(str(tmp_path / f"c{i}.bin"))
+    out = subprocess.run([exe, "0", "1", str(tmp_path / "t.bin"), str(tmp_path / "g.bin"), *files], check=True, capture_output=True, text=True).stdout.splitlines()
+    reg = select_registration_method({"registration_method": "FAST_GICP"})
+    reg.setInputTarget(wl.target)
+    clouds = [reg.upload(c) for c in wl.candidates]
+    line = 0
+    for order in (list(range(5)), [4, 3, 2, 1]):
+        rec, best = reg.loop_match_batch([clouds[c] for c in order], [wl.guesses[c] for c in order], 4.0)
+        head = out[line].split()
+        assert head[0] == "best" and int(head[1]) == best and int(head[3]) == 5
+        for k, c in enumerate(order):
+            f = out[line + 1 + k].split()
+            assert int(f[0]) == c and int(f[1]) == rec["converged"][k] and int(f[2]) == rec["iterations"][k]
+            assert float(f[3]) == rec["fitness_score"][k]
+            assert np.array_equal(np.array([float(v) for v in f[4:]], np.float32), rec["final_transformation"][k])
+        line += 1 + len(order)
+    reg.close()

@@ -465,3 +465,10 @@ def test_long_ndt_run_ends_on_the_golden_float_matrix():
     """66 iterations of the emulated k_ndt_pass end bit for bit where the committed oracle trace (exact-sum mode) ends."""
     from test_golden import _check_long_ndt_run
     _check_long_ndt_run(_engine)
+
+
+def test_sharded_batch_entry_point_world_one():
+    """hgs_comm_init / hgs_loop_match_batch_sharded through the emulated library (its exchange step is a one-rank copy): record
+    packing on the device, padding, scatter into candidate order, selection."""
+    from test_distributed import _sharded_equals_unsharded
+    _sharded_equals_unsharded(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
