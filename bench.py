@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — registrations/sec of the MI355X scan-matching backend on BASELINE.json's metric.
+"""bench.py — registrations/sec of the MI355X scan-matching backend on BASELINE.json's metric and configurations.
 
-Workload (config.workload): the loop-closure batch of LoopDetector::matching (include/hdl_graph_slam/loop_detector.hpp:117-171)
-on 64-beam ~120 k-point keyframes: per step every rank registers `--candidates` candidate keyframes (cold: search index +
-20-NN covariances are recomputed for the target and every candidate, as the reference does per setInputSource) against one
-query keyframe with FAST_GICP at the launch-file parameters (launch/hdl_graph_slam.launch:73-82,127-136: eps 0.01,
-max_iterations 64, max_correspondence_distance 2.5, k 20) and evaluates getFitnessScore for each.  Inputs are resident in HBM
-before the timed region.  N > 1: candidates are sharded over the ranks (weak scaling: per-GPU work fixed) and the per-candidate
-records are all-gathered over RCCL once per step (the path's only exchange step).
+Default workload (the configuration the metric is quoted on, config.workload): the loop-closure batch of LoopDetector::matching
+(include/hdl_graph_slam/loop_detector.hpp:117-171) on 64-beam ~120 k-point keyframes: per step every rank registers
+`--candidates` candidate keyframes (cold: search index + 20-NN covariances are recomputed for the target and every candidate, as
+the reference does per setInputSource) against one query keyframe with FAST_GICP at the launch-file parameters
+(launch/hdl_graph_slam.launch:73-82,127-136: eps 0.01, max_iterations 64, max_correspondence_distance 2.5, k 20) and evaluates
+getFitnessScore for each.  Inputs are resident in HBM before the timed region.  N > 1: candidates are sharded over the ranks
+(weak scaling: per-GPU work fixed) and the per-candidate records are all-gathered once per step (the path's only exchange step).
 
-One JSON line on rank 0:  value = registrations/sec over all ranks (whole job)."""
+--config 2..5 run the other BASELINE.json configurations, each as its own JSON line with roofline + cpu_baseline:
+  2  HDL-32E pair (~60 k points), FAST_GICP, single cold align (index + both covariance passes) — and warm (target cached)
+  3  HDL-64E odometry stream, NDT_OMP (the factory default), host buffer in -> pose out per sweep (H2D INCLUDED), p50 / p99
+  4  loop-closure batch: 1 query x 512 HDL-32E candidate keyframes, sharded over the ranks (all 512 on one GPU at N = 1)
+  5  1 M-point dense cloud, FAST_GICP, single align with the per-stage roofline
+--method NDT_OMP / FAST_VGICP switch the engine of the default workload and of config 4.
+
+One JSON line on rank 0:  value = units/sec over all ranks (whole job)."""
 from __future__ import annotations
 
 import argparse
@@ -24,29 +31,106 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_BYTES = {  # algorithmic bytes per unit of work
-    "covariance": ("k_knn_cov", 360.0),    # per point (16 query + 20*16 neighbours + 24 covariance out)
+    "covariance": ("k_knn_cov", 360.0),       # per point (16 query + 20*16 neighbours + 24 covariance out)
     "linearize": ("k_gicp_linearize", 84.0),  # per source point per linearisation
-    "error": ("k_gicp_error", 84.0),       # per source point per LM trial
-    "fitness": ("k_fitness", 32.0),        # per source point
+    "error": ("k_gicp_error", 84.0),          # per source point per LM trial
+    "fitness": ("k_fitness", 32.0),           # per source point
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: measured float4-copy ceiling (SURVEY 8d asks for both)
+LIMITER = {"FAST_GICP": "instruction issue (VALU+SALU) of the exact tree search, not HBM: see DESIGN.md section 4",
+           "FAST_VGICP": "VALU + dependent L2 round trips of the voxel hash probes, not HBM: see DESIGN.md section 4",
+           "NDT_OMP": "VALU issue of the per-cell derivative terms and of the exact integer reduction (~650 instructions per visited cell, ~1100 per 64-point "
+                      "tile), not HBM: see DESIGN.md section 4"}
+
+
+def percentiles(ms):
+    a = np.asarray(ms, np.float64)
+    return {"p10": round(float(np.percentile(a, 10)), 3), "p50": round(float(np.percentile(a, 50)), 3), "p90": round(float(np.percentile(a, 90)), 3),
+            "min": round(float(a.min()), 3), "max": round(float(a.max()), 3)}
+
+
+def stage_table(method):
+    t = dict(ALG_BYTES)
+    if method == "NDT_OMP":
+        t["linearize"] = ("k_ndt_pass", 296.0)
+    if method == "FAST_VGICP":
+        t["linearize"], t["error"] = ("k_vgicp_linearize", 80.0), ("k_vgicp_error", 80.0)
+    return t
+
+
+def roofline_of(method, prof, units, prof_steps, launch_config, pmc_ok=True):
+    """Dominant stage by measured time (HIP events on the engine's stream around every launch of the stage) against HBM."""
+    table = stage_table(method)
+    live = [s for s in table if prof[s][1] > 0 and units.get(s, 0) > 0]
+    dom = max(live, key=lambda s: prof[s][0])
+    ms, launches = prof[dom]
+    kname, bytes_per_unit = table[dom]
+    achieved = units[dom] * bytes_per_unit / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    # HBM traffic of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per dispatch, collected in separate passes over the
+    # default workload (scripts/gpu_pmc.sh) and committed as profiles/pmc_<method>.json; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    # prescribes for gfx950.  null when no committed counters match this workload.
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{method.lower()}.json")
+    if pmc_ok and os.path.exists(pmc_path):
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
+        for kn, cv in pmc.get("kernels", {}).items():
+            if kn.split("<")[0].endswith(kname) and "FETCH_SIZE" in cv:
+                traffic = (2.0 * cv["FETCH_SIZE"] + cv.get("WRITE_SIZE", 0.0)) * 1024.0
+                traffic_src = os.path.relpath(pmc_path, ROOT)
+    return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5), "traffic": None if traffic is None else round(traffic, 1),
+            "traffic_source": traffic_src, "limiter": LIMITER[method], "launch_config": launch_config,
+            "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches": launches,
+            "algorithmic_bytes_per_launch": round(units[dom] * bytes_per_unit / max(launches, 1), 1),
+            "stage_ms_per_step": {s: round(prof[s][0] / prof_steps, 3) for s in prof}}
+
+
+def oracle_params(reg):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    p = O.HgsParams()
+    for name, _ in O.HgsParams._fields_:
+        setattr(p, name, getattr(reg.params, name))
+    return O, p
+
+
+def best_cpu(run_sample, unit, sample_text):
+    """The oracle (a port of fast_gicp / ndt_omp, OpenMP over points) on a bounded sample, at the best of a few thread counts:
+    reg_num_threads = 0 means "all cores" upstream, which oversubscribes badly on a 2 x 128-thread host."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+        O.set_num_threads(nt)
+        rate, extra = run_sample(O)
+        if best is None or rate > best[0]:
+            best = (rate, nt, extra)
+    out = {"value": round(best[0], 4), "unit": unit, "cores": best[1], "kind": "port", "host_threads_available": ncpu,
+           "sample": sample_text + "; best of OMP thread counts 8/16/32/64"}
+    out.update(best[2])
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (0: a per-config default that runs for about a second)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--candidates", type=int, default=16, help="candidate keyframes per GPU per step")
-    ap.add_argument("--sensor", default="HDL-64E")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="0: the metric's configuration (default); 2..5: BASELINE.json configs")
+    ap.add_argument("--candidates", type=int, default=0, help="candidate keyframes per GPU per step (default 64; config 4: 512 / ranks)")
+    ap.add_argument("--sensor", default="")
     ap.add_argument("--distinct", type=int, default=8, help="distinct ray-cast scans behind the candidates")
-    ap.add_argument("--method", default="FAST_GICP", choices=["FAST_GICP", "FAST_VGICP", "NDT_OMP"])
-    ap.add_argument("--downsample", type=float, default=0.0, help="voxel size applied to every keyframe (0 = raw scans, the metric's configuration)")
+    ap.add_argument("--method", default="", choices=["", "FAST_GICP", "FAST_VGICP", "NDT_OMP"])
+    ap.add_argument("--downsample", type=float, default=0.0, help="voxel size applied to every cloud (0 = raw scans, the metric's configuration)")
+    ap.add_argument("--seeds", type=int, default=-1, help="scene seeds: the timed region runs on seed 0, the others are reported next to it "
+                    "(default 3 at one GPU, 1 otherwise)")
     ap.add_argument("--ndt-line-search", action="store_true", help="NDT_OMP with the opt-in More-Thuente search (NOT the reference's behaviour; "
                     "the line then says so in config.workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=3, help="candidates registered by the CPU oracle for cpu_baseline")
+    ap.add_argument("--cpu-sample", type=int, default=3, help="units registered by the CPU oracle for cpu_baseline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,65 +171,118 @@ def main():
     from hdl_graph_slam_amd.registration import select_best
     from hdl_graph_slam_amd.distributed import CandidateShard
 
-    pnh = {"registration_method": args.method}
-    if args.method in ("NDT_OMP", "FAST_VGICP"):
-        pnh["reg_resolution"] = 1.0   # launch files use 1.0 (NDT factory default 0.5)
-    if args.ndt_line_search and args.method == "NDT_OMP":
-        pnh["reg_ndt_line_search"] = True
-    B = args.candidates
-    # every rank holds the query keyframe (replicated target) and its own shard of the N*B candidates
-    wl = workloads.make_loop_closure_set(args.sensor, scene_seed=0, n_candidates=B, n_distinct=min(args.distinct, B), downsample=args.downsample or None)
-    rng = np.random.default_rng(100 + rank)
-    if rank > 0:  # different guesses per rank so that the shards are not identical problems
-        for g in wl.guesses:
-            g[:3, 3] += rng.normal(0, 0.05, 3).astype(np.float32)
-            g[2, 3] = 0.0
+    ctx = dict(args=args, rank=rank, local_rank=local_rank, world=world, torch=torch, emulated=emulated, dist=dist, coll_device=coll_device, sharded=sharded,
+               synth=synth, workloads=workloads, L=L, select_registration_method=select_registration_method, select_best=select_best, CandidateShard=CandidateShard)
+    n_seeds = args.seeds if args.seeds >= 0 else (3 if world == 1 and not emulated else 1)
+    ctx["n_seeds"] = max(1, n_seeds)
+    if args.config in (0, 4):
+        out = run_loop_batch(ctx)
+    elif args.config in (2, 5):
+        out = run_single_align(ctx)
+    else:
+        out = run_odometry(ctx)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
 
-    reg = select_registration_method(pnh, device_id=local_rank)
-    d_target = reg.upload(wl.target)
-    d_cands = [reg.upload(c) for c in wl.candidates]
-    n_pts = [len(c) for c in wl.candidates]
-    shard = CandidateShard(rank, world, device=coll_device) if sharded else None
 
-    def step(cold=True):
-        d_target.invalidate()           # the query keyframe is new in every detection
-        if cold:
-            for c in d_cands:           # reference behaviour: setInputSource rebuilds tree + covariances of every candidate
-                c.invalidate()
-        reg.setInputTarget(d_target)
-        rec, best = reg.loop_match_batch(d_cands, wl.guesses, L.DBL_MAX)
-        if shard is not None:
-            rec["candidate_id"] = np.arange(rank, world * B, world, dtype=np.int32)
-            allrec = shard.gather_records(rec, world * B)
-            best = select_best(allrec)
-        return rec, best
+def make_barrier(ctx, reg):
+    torch, dist = ctx["torch"], ctx["dist"]
 
     def barrier():
         reg.synchronize()
-        if not emulated:
+        if not ctx["emulated"]:
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+    return barrier
 
-    for _ in range(args.warmup):
+
+def max_over_ranks(ctx, dt):
+    if ctx["dist"] is None:
+        return dt
+    t = ctx["torch"].tensor([dt], device=ctx["coll_device"], dtype=ctx["torch"].float64)
+    ctx["dist"].all_reduce(t, op=ctx["dist"].ReduceOp.MAX)
+    return float(t.item())
+
+
+def base_line(ctx, value, unit, steps, dt, dtype, workload, extra_config):
+    a = ctx["args"]
+    return {"metric": "registrations/sec (64-beam ~120k-pt pair), loop-closure batch" if a.config == 0 else "registrations/sec", "value": round(value, 3), "unit": unit,
+            "n_gpus": ctx["world"], "steps": steps, "warmup": a.warmup, "ms_per_step": round(dt / max(steps, 1) * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic" if not ctx["emulated"] else "synthetic (EMULATED ON THE CPU - not a measurement)",
+            "config": dict({"workload": workload, "baseline_config": a.config if a.config else "metric (config 3's scan size in config 4's batch shape)"}, **extra_config)}
+
+
+# ============================================================================================== loop-closure batch (default, config 4)
+def run_loop_batch(ctx):
+    a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
+    cfg4 = a.config == 4
+    method = a.method or "FAST_GICP"
+    sensor = a.sensor or ("HDL-32E" if cfg4 else "HDL-64E")
+    B = a.candidates or ((512 + world - 1) // world if cfg4 else 64)
+    steps = a.steps or (6 if cfg4 else 40)
+    pnh = {"registration_method": method}
+    if method in ("NDT_OMP", "FAST_VGICP"):
+        pnh["reg_resolution"] = 1.0   # launch files use 1.0 (NDT factory default 0.5)
+    if a.ndt_line_search and method == "NDT_OMP":
+        pnh["reg_ndt_line_search"] = True
+    reg = ctx["select_registration_method"](pnh, device_id=ctx["local_rank"])
+    shard = ctx["CandidateShard"](rank, world, device=ctx["coll_device"]) if ctx["sharded"] else None
+    barrier = make_barrier(ctx, reg)
+
+    def load(seed):
+        # every rank holds the query keyframe (replicated target) and its own shard of the N*B candidates
+        wl = ctx["workloads"].make_loop_closure_set(sensor, scene_seed=seed, n_candidates=B, n_distinct=min(a.distinct, B), downsample=a.downsample or None)
+        rng = np.random.default_rng(100 + rank)
+        if rank > 0:  # different guesses per rank so that the shards are not identical problems
+            for g in wl.guesses:
+                g[:3, 3] += rng.normal(0, 0.05, 3).astype(np.float32)
+                g[2, 3] = 0.0
+        return wl, reg.upload(wl.target), [reg.upload(c) for c in wl.candidates]
+
+    def make_step(wl, d_target, d_cands):
+        def step(cold=True):
+            d_target.invalidate()           # the query keyframe is new in every detection
+            if cold:
+                for c in d_cands:           # reference behaviour: setInputSource rebuilds tree + covariances of every candidate
+                    c.invalidate()
+            reg.setInputTarget(d_target)
+            rec, best = reg.loop_match_batch(d_cands, wl.guesses, L.DBL_MAX)
+            if shard is not None:
+                rec["candidate_id"] = np.arange(rank, world * B, world, dtype=np.int32)
+                allrec = shard.gather_records(rec, world * B)
+                best = ctx["select_best"](allrec)
+            return rec, best
+        return step
+
+    def timed(step, n):
+        per = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ts = time.perf_counter()
+            rec, best = step()
+            per.append((time.perf_counter() - ts) * 1e3)
+        barrier()
+        return time.perf_counter() - t0, per, rec, best
+
+    wl, d_target, d_cands = load(0)
+    n_pts = [len(c) for c in wl.candidates]
+    step = make_step(wl, d_target, d_cands)
+    for _ in range(a.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec, best = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, per_step, rec, best = timed(step, steps)
+    dt = max_over_ranks(ctx, dt)
 
-    # ---- informational: the same batch with the candidate keyframes' index + covariances kept resident between
-    # detections (what a keyframe device cache gives; never `value`)
+    # ---- informational: the same batch with the candidate keyframes' index + covariances kept resident between detections
+    # (what a keyframe device cache gives; never `value`)
     step(cold=False)
     barrier()
     tw = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(cold=False)
     barrier()
     dt_warm = time.perf_counter() - tw
@@ -164,63 +301,37 @@ def main():
     prof = reg.profile_read(reset=True)
     reg.profile_enable(False)
     total_pts = sum(n_pts) + len(wl.target)
-    units = {
-        "covariance": prof_steps * total_pts,
-        "linearize": prof_steps * float(np.sum(rec_p["iterations"].astype(np.float64) * np.array(n_pts))),
-        "error": prof_steps * float(np.sum(rec_p["lm_tries"].astype(np.float64) * np.array(n_pts))),
-        "fitness": prof_steps * sum(n_pts),
-    }
-    if args.method == "NDT_OMP":
-        ALG_BYTES["linearize"] = ("k_ndt_pass", 296.0)
+    units = {"covariance": prof_steps * total_pts,
+             "linearize": prof_steps * float(np.sum(rec_p["iterations"].astype(np.float64) * np.array(n_pts))),
+             "error": prof_steps * float(np.sum(rec_p["lm_tries"].astype(np.float64) * np.array(n_pts))),
+             "fitness": prof_steps * sum(n_pts)}
+    if method == "NDT_OMP":
         units["linearize"] = prof_steps * float(np.sum(rec_p["lm_tries"].astype(np.float64) * np.array(n_pts)))
         units["covariance"] = units["error"] = 0.0
-    if args.method == "FAST_VGICP":
-        ALG_BYTES["linearize"] = ("k_vgicp_linearize", 80.0)
-        ALG_BYTES["error"] = ("k_vgicp_error", 80.0)
-    dom = max((s for s in ALG_BYTES if prof[s][1] > 0), key=lambda s: prof[s][0])
-    ms, launches = prof[dom]
-    kname, bytes_per_unit = ALG_BYTES[dom]
-    achieved = units[dom] * bytes_per_unit / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    # HBM traffic of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per dispatch, collected in separate passes over this
-    # same command (scripts/gpu_pmc.sh) and committed as profiles/pmc_<method>.json; FETCH_SIZE doubled as
-    # MI355X_MICROARCH.md prescribes for gfx950 (calibrated there for wide coalesced reads only — our reads are 128-byte
-    # records and 16-byte gathers, so treat it as an upper estimate).  null when no committed counters match.
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.method.lower()}.json")
-    default_workload = args.sensor == "HDL-64E" and B == 16 and not args.downsample   # what the committed counters were collected on
-    if os.path.exists(pmc_path) and default_workload:
-        with open(pmc_path) as fh:
-            pmc = json.load(fh)
-        for kn, cv in pmc.get("kernels", {}).items():
-            if kn.split("<")[0].endswith(kname) and "FETCH_SIZE" in cv:
-                traffic = (2.0 * cv["FETCH_SIZE"] + cv.get("WRITE_SIZE", 0.0)) * 1024.0
-                traffic_src = os.path.relpath(pmc_path, ROOT)
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5), "traffic": None if traffic is None else round(traffic, 1), "traffic_source": traffic_src,
-                "limiter": {"FAST_GICP": "instruction issue (VALU+SALU) of the exact tree search, not HBM: see DESIGN.md section 4",
-                            "FAST_VGICP": "VALU + dependent L2 round trips of the voxel hash probes, not HBM: see DESIGN.md section 4",
-                            "NDT_OMP": "VALU issue of the per-cell derivative terms (packed fp32 + fp64 accumulation, ~300 instructions per visited cell), not HBM: see DESIGN.md section 4"}[args.method],
-                "launch_config": "whole-device launches (all candidates of the rank in one launch, HIP events on the engine's stream); the timed region "
-                                 "runs the same kernels split over 4 concurrent lanes, whose launches overlap each other",
-                "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches": launches,
-                "algorithmic_bytes_per_launch": round(units[dom] * bytes_per_unit / max(launches, 1), 1),
-                "stage_ms_per_step": {s: round(prof[s][0] / prof_steps, 3) for s in prof}}
+    roofline = roofline_of(method, prof, units, prof_steps,
+                           "whole-device launches (all candidates of the rank in one launch, HIP events on the engine's stream); the timed region "
+                           "runs the same kernels split over up to 4 concurrent lanes, whose launches overlap each other",
+                           pmc_ok=(sensor == "HDL-64E" and B == 64 and not a.downsample))
 
-    # ---- CPU baseline: the oracle (port of fast_gicp / ndt_omp, OpenMP over points) on a bounded sample, rank 0, N == 1
+    # ---- the other scene seeds (informational: spread of the metric over scenes)
+    by_seed = [round(world * B * steps / dt, 1)]
+    for seed in range(1, ctx["n_seeds"]):
+        for c in d_cands:
+            c.close()
+        d_target.close()
+        wl_s, d_target, d_cands = load(seed)
+        step_s = make_step(wl_s, d_target, d_cands)
+        step_s()
+        dts, _, _, _ = timed(step_s, steps)
+        by_seed.append(round(world * B * steps / max_over_ranks(ctx, dts), 1))
+
+    # ---- CPU baseline: rank 0, N == 1
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as O
-        p = O.HgsParams()
-        for name, _ in O.HgsParams._fields_:
-            setattr(p, name, getattr(reg.params, name))
-        # reg_num_threads = 0 means "all cores" upstream; on many-core hosts that oversubscribes badly (256 threads are
-        # ~40x slower than 32 on a 2 x EPYC 9575F box), so the baseline is the BEST of a few thread counts.
-        ncpu = os.cpu_count() or 1
-        k = min(args.cpu_sample, B)
-        best_cpu = None
-        for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
-            O.set_num_threads(nt)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        O, p = oracle_params(reg)
+        k = min(a.cpu_sample, B)
+
+        def sample(O):
             o = O.OracleRegistration(p)
             o.setInputTarget(wl.target)   # target structures are built once per batch in the reference too
             o.setInputSource(wl.candidates[0])
@@ -232,36 +343,229 @@ def main():
                 ro = o.align(wl.guesses[i])
                 o.getFitnessScore()
                 dpose.append(synth.pose_error(np.array(rec[i]["final_transformation"]).reshape(4, 4).T, ro.matrix()))
-            tcpu = time.perf_counter() - tc
-            if best_cpu is None or k / tcpu > best_cpu[0]:
-                best_cpu = (k / tcpu, nt, dpose)
-        cpu = {"value": round(best_cpu[0], 4), "unit": "registrations/sec", "cores": best_cpu[1], "kind": "port", "host_threads_available": ncpu,
-               "sample": f"{k} of the {B} candidate registrations (setInputSource + align + getFitnessScore), target structures prebuilt; "
-                         f"best of OMP thread counts 8/16/32/64",
-               "max_pose_diff_vs_gpu_m": float(max(d[0] for d in best_cpu[2])), "max_pose_diff_vs_gpu_rad": float(max(d[1] for d in best_cpu[2]))}
+            return k / (time.perf_counter() - tc), {"max_pose_diff_vs_gpu_m": float(max(d[0] for d in dpose)), "max_pose_diff_vs_gpu_rad": float(max(d[1] for d in dpose))}
+        cpu = best_cpu(sample, "registrations/sec", f"{k} of the {B} candidate registrations (setInputSource + align + getFitnessScore), target structures prebuilt")
 
-    if rank == 0:
-        regs = world * B * args.steps
-        out = {
-            "metric": "registrations/sec (64-beam ~120k-pt pair), loop-closure batch", "value": round(regs / dt, 3), "unit": "registrations/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.method == "NDT_OMP" else "f64",
-            "data": "synthetic" if not emulated else "synthetic (EMULATED ON THE CPU - not a measurement)",
-            "config": {"workload": f"loop-closure batch: {B} candidate keyframes/GPU x {args.sensor} (~{int(np.mean(n_pts))} pts) vs 1 query keyframe, "
-                                   f"{args.method}{' with the opt-in More-Thuente line search (not the reference behaviour)' if pnh.get('reg_ndt_line_search') else ''}"
-                                   f" + getFitnessScore, cold (index + covariances rebuilt every step)",
-                       "candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": args.method,
-                       "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU"},
-            "pose_rmse_vs_ground_truth": {"translation_m": round(rmse_t, 5), "rotation_rad": round(rmse_r, 6)},
-            "resident_keyframes_value": round(world * B * args.steps / dt_warm, 3) if world == 1 else None,
-            "converged": int(np.sum(rec["converged"])), "mean_iterations": float(np.mean(rec["iterations"])),
-            "mean_linearizations": float(np.mean(rec["lm_tries"])), "best_candidate": int(best),
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        print(json.dumps(out))
+    out = base_line(ctx, world * B * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
+                    f"loop-closure batch: {B} candidate keyframes/GPU x {sensor} (~{int(np.mean(n_pts))} pts) vs 1 query keyframe, "
+                    f"{method}{' with the opt-in More-Thuente line search (not the reference behaviour)' if pnh.get('reg_ndt_line_search') else ''}"
+                    f" + getFitnessScore, cold (index + covariances rebuilt every step)",
+                    {"candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": method,
+                     "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU"})
+    out.update({"step_ms": percentiles(per_step), "timed_region_s": round(dt, 3),
+                "value_by_scene_seed": by_seed, "value_mean_std_over_seeds": [round(float(np.mean(by_seed)), 1), round(float(np.std(by_seed)), 1)],
+                "pose_rmse_vs_ground_truth": {"translation_m": round(rmse_t, 5), "rotation_rad": round(rmse_r, 6)},
+                "resident_keyframes_value": round(world * B * steps / dt_warm, 3) if world == 1 else None,
+                "converged": int(np.sum(rec["converged"])), "mean_iterations": float(np.mean(rec["iterations"])),
+                "mean_linearizations": float(np.mean(rec["lm_tries"])), "best_candidate": int(best),
+                "roofline": roofline, "cpu_baseline": cpu})
     reg.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
+
+
+# ============================================================================================== single align (configs 2 and 5)
+def run_single_align(ctx):
+    """Config 2: one HDL-32E pair, FAST_GICP, cold align (index + covariances of BOTH clouds + iterations), as the first align
+    after setInputTarget / setInputSource costs in the reference; warm = the target's structures cached (the odometry case:
+    the keyframe persists).  Config 5: the 1 M-point dense pair (max_correspondence_distance 1.0).  Replicas at N > 1."""
+    a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
+    dense = a.config == 5
+    method = a.method or "FAST_GICP"
+    sensor = a.sensor or "HDL-32E"
+    pnh = {"registration_method": method}
+    if dense:
+        pnh["reg_max_correspondence_distance"] = 1.0
+    if method in ("NDT_OMP", "FAST_VGICP"):
+        pnh["reg_resolution"] = 1.0
+    reg = ctx["select_registration_method"](pnh, device_id=ctx["local_rank"])
+    barrier = make_barrier(ctx, reg)
+    steps = a.steps or (30 if dense else 150)
+
+    def load(seed):
+        if dense:
+            tgt, src, T = synth.make_dense_pair(seed, 1_000_000)
+            guess = T @ synth.pose_matrix([0.1, 0.05, 0.0], [0.0, 0.0, 0.005])
+        else:
+            tgt, src, T = synth.make_pair(sensor, seed, downsample=a.downsample or None)
+            guess = np.eye(4)           # the first frame after a keyframe (scan_matching_odometry_nodelet.cpp:210)
+        return tgt, src, T, guess, reg.upload(tgt), reg.upload(src)
+
+    def make_step(d_tgt, d_src, guess):
+        def step(cold=True):
+            if cold:
+                d_tgt.invalidate()
+            d_src.invalidate()
+            reg.setInputTarget(d_tgt)
+            reg.setInputSource(d_src)
+            return reg.align(guess)
+        return step
+
+    def timed(step, n, cold=True):
+        per = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ts = time.perf_counter()
+            r = step(cold)
+            per.append((time.perf_counter() - ts) * 1e3)
+        barrier()
+        return time.perf_counter() - t0, per, r
+
+    tgt, src, T, guess, d_tgt, d_src = load(0)
+    step = make_step(d_tgt, d_src, guess)
+    for _ in range(a.warmup):
+        step()
+    dt, per_step, r = timed(step, steps)
+    dt = max_over_ranks(ctx, dt)
+    step(False)
+    dt_warm, per_warm, _ = timed(step, steps, cold=False)
+    err_t, err_r = synth.pose_error(r.matrix(), T)
+
+    reg.profile_enable(True)
+    reg.profile_read(reset=True)
+    prof_steps = 3
+    for _ in range(prof_steps):
+        rp = step()
+    prof = reg.profile_read(reset=True)
+    reg.profile_enable(False)
+    units = {"covariance": prof_steps * (len(tgt) + len(src)), "linearize": prof_steps * float(rp.iterations) * len(src),
+             "error": prof_steps * float(rp.lm_tries) * len(src), "fitness": 0.0}
+    if method == "NDT_OMP":
+        units = {"covariance": 0.0, "linearize": prof_steps * float(rp.lm_tries) * len(src), "error": 0.0, "fitness": 0.0}
+    roofline = roofline_of(method, prof, units, prof_steps, "one registration per launch (HIP events on the engine's stream)", pmc_ok=False)
+    # per-stage roofline (config 5's purpose): algorithmic GB/s of every stage that ran
+    table = stage_table(method)
+    roofline["stages"] = {s: {"kernel": table[s][0], "ms_per_align": round(prof[s][0] / prof_steps, 4), "launches_per_align": prof[s][1] / prof_steps,
+                              "achieved_GBps": round(units[s] * table[s][1] / (prof[s][0] * 1e-3) / 1e9, 1),
+                              "frac_of_8TBps": round(units[s] * table[s][1] / (prof[s][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                          for s in table if prof[s][0] > 0 and units.get(s, 0) > 0}
+
+    by_seed = [round(world * steps / dt, 2)]
+    for seed in range(1, ctx["n_seeds"]):
+        d_tgt.close(), d_src.close()
+        _, _, _, g_s, d_tgt, d_src = load(seed)
+        st = make_step(d_tgt, d_src, g_s)
+        st()
+        dts, _, _ = timed(st, steps)
+        by_seed.append(round(world * steps / max_over_ranks(ctx, dts), 2))
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        O, p = oracle_params(reg)
+        k = 1 if dense else max(1, min(a.cpu_sample, 3))
+
+        def sample(O):
+            o = O.OracleRegistration(p)
+            tc = time.perf_counter()
+            for _ in range(k):
+                o.setInputTarget(tgt)
+                o.setInputSource(src)
+                ro = o.align(guess)
+            el = time.perf_counter() - tc
+            d = synth.pose_error(r.matrix(), ro.matrix())
+            return k / el, {"max_pose_diff_vs_gpu_m": float(d[0]), "max_pose_diff_vs_gpu_rad": float(d[1])}
+        cpu = best_cpu(sample, "registrations/sec", f"{k} cold align(s) of the same pair (setInputTarget + setInputSource + align)")
+
+    out = base_line(ctx, world * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
+                    (f"config 5: dense 1 M-point pair, {method}, max_correspondence_distance 1.0, single cold align" if dense else
+                     f"config 2: {sensor} pair (~{len(src)} pts), {method}, single cold align from the identity guess (index + both covariance passes + iterations)"),
+                    {"points_per_cloud": int(len(src)), "method": method, "parallelism": f"{world} replicas" if world > 1 else "single GPU"})
+    out.update({"step_ms": percentiles(per_step), "timed_region_s": round(dt, 3), "warm_align_ms": percentiles(per_warm),
+                "warm_value": round(world * steps / dt_warm, 2), "value_by_scene_seed": by_seed,
+                "value_mean_std_over_seeds": [round(float(np.mean(by_seed)), 2), round(float(np.std(by_seed)), 2)],
+                "iterations": int(r.iterations), "lm_tries": int(r.lm_tries), "converged": int(r.converged),
+                "pose_error_vs_ground_truth": {"translation_m": round(err_t, 5), "rotation_rad": round(err_r, 6)},
+                "roofline": roofline, "cpu_baseline": cpu})
+    reg.close()
+    return out
+
+
+# ============================================================================================== odometry stream (config 3)
+def run_odometry(ctx):
+    """Config 3: ScanMatchingOdometryNodelet::matching (apps/scan_matching_odometry_nodelet.cpp:165-262) on a 64-beam stream with
+    the keyframe rule of launch/hdl_graph_slam_kitti.launch:41-43; a step = one sweep, host buffer in -> pose out (upload, index /
+    voxelisation when the keyframe switches, align, result download ALL inside the timed step).  The path is sequential in time:
+    replicas only at N > 1."""
+    a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
+    from hdl_graph_slam_amd.odometry import ScanMatchingOdometry
+    method = a.method or "NDT_OMP"
+    sensor = a.sensor or "HDL-64E"
+    steps = a.steps or 60
+    speed = 3.0   # m/s at 10 Hz: 0.3 m per sweep (at KITTI's 0.8 m per sweep the NDT basin at resolution 1.0 loses track on this scene; the oracle does identically)
+    pnh = {"registration_method": method, "reg_resolution": 1.0}
+    kf = dict(keyframe_delta_trans=5.0, keyframe_delta_angle=2.0, keyframe_delta_time=10000.0)
+    reg = ctx["select_registration_method"](pnh, device_id=ctx["local_rank"])
+    barrier = make_barrier(ctx, reg)
+
+    def run(seed, n_warm, n):
+        stream = ctx["workloads"].make_odometry_stream(sensor, seed, n_warm + n + 1, speed=speed, downsample=a.downsample or None)
+        od = ScanMatchingOdometry(reg, **kf)
+        est, its = [], []
+        for t, c in zip(stream.stamps[:n_warm + 1], stream.scans[:n_warm + 1]):   # the first call only sets the keyframe
+            est.append(od.matching(t, c))
+        per = []
+        barrier()
+        t0 = time.perf_counter()
+        for t, c in zip(stream.stamps[n_warm + 1:], stream.scans[n_warm + 1:]):
+            ts = time.perf_counter()
+            est.append(od.matching(t, c))
+            per.append((time.perf_counter() - ts) * 1e3)
+            its.append(int(od.last_result.iterations))
+        barrier()
+        dt = time.perf_counter() - t0
+        gt0 = np.linalg.inv(stream.poses[0])
+        err = [synth.pose_error(e, gt0 @ p) for e, p in zip(est, stream.poses)]
+        return dt, per, its, err, stream, od
+
+    dt, per_step, its, err, stream, od = run(0, a.warmup, steps)
+    dt = max_over_ranks(ctx, dt)
+    n_pts = int(np.mean([len(c) for c in stream.scans]))
+
+    # roofline: a few more sweeps against the current keyframe with the stage timers on
+    reg.profile_enable(True)
+    reg.profile_read(reset=True)
+    prof_sweeps, passes = 4, 0
+    for c in stream.scans[-prof_sweeps:]:
+        reg.setInputSource(c)
+        rp = reg.align(od.prev_trans)
+        passes += int(rp.lm_tries if method == "NDT_OMP" else rp.iterations)
+    prof = reg.profile_read(reset=True)
+    reg.profile_enable(False)
+    units = {"covariance": prof_sweeps * n_pts if method != "NDT_OMP" else 0.0, "linearize": float(passes) * n_pts, "error": 0.0, "fitness": 0.0}
+    roofline = roofline_of(method, prof, units, prof_sweeps, "one registration per launch (HIP events on the engine's stream)", pmc_ok=False)
+
+    by_seed = [round(world * steps / dt, 2)]
+    n_extra = max(10, steps // 3)
+    for seed in range(1, ctx["n_seeds"]):
+        dts, _, _, _, _, _ = run(seed, 1, n_extra)
+        by_seed.append(round(world * n_extra / max_over_ranks(ctx, dts), 2))
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        O, p = oracle_params(reg)
+        k = max(2, min(a.cpu_sample, 4))
+
+        def sample(O):
+            oo = ScanMatchingOdometry(O.OracleRegistration(p), **kf)
+            oo.matching(stream.stamps[0], stream.scans[0])
+            tc = time.perf_counter()
+            for t, c in zip(stream.stamps[1:k + 1], stream.scans[1:k + 1]):
+                oo.matching(t, c)
+            return k / (time.perf_counter() - tc), {}
+        cpu = best_cpu(sample, "registrations/sec", f"the first {k} sweeps of the same stream through the same caller (setInputSource + align per sweep)")
+
+    out = base_line(ctx, world * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
+                    f"config 3: {sensor} odometry stream (~{n_pts} pts/sweep, {speed} m/s at 10 Hz), {method}, frame-to-keyframe with the KITTI keyframe rule "
+                    f"(5 m / 2 rad), host buffer in -> pose out per sweep: H2D upload INCLUDED in every step",
+                    {"points_per_cloud": n_pts, "method": method, "parallelism": f"{world} replicas (the path is sequential in time)" if world > 1 else "single GPU"})
+    out.update({"latency_ms": dict(percentiles(per_step), p99=round(float(np.percentile(per_step, 99)), 3)), "step_ms": percentiles(per_step), "timed_region_s": round(dt, 3),
+                "mean_iterations": float(np.mean(its)), "max_iterations": int(max(its)), "keyframes": od.num_keyframes,
+                "value_by_scene_seed": by_seed, "value_mean_std_over_seeds": [round(float(np.mean(by_seed)), 2), round(float(np.std(by_seed)), 2)],
+                "trajectory_error_vs_ground_truth": {"final_translation_m": round(err[-1][0], 4), "rmse_translation_m": round(float(np.sqrt(np.mean([e[0] ** 2 for e in err]))), 4),
+                                                     "rmse_rotation_rad": round(float(np.sqrt(np.mean([e[1] ** 2 for e in err]))), 5)},
+                "roofline": roofline, "cpu_baseline": cpu})
+    reg.close()
+    return out
 
 
 if __name__ == "__main__":

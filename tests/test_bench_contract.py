@@ -52,7 +52,8 @@ def test_single_rank_line():
     _check(rec, 1, 2, 1, 2)
     cpu = rec["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "registrations/sec" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
-    assert rec["roofline"]["kernel"] in ("k_gicp_linearize", "k_knn_cov", "k_ndt_derivatives", "k_fitness", "k_gicp_error")
+    assert rec["roofline"]["kernel"] in ("k_gicp_linearize", "k_knn_cov", "k_ndt_pass", "k_fitness", "k_gicp_error")
+    assert {"p10", "p50", "p90"} <= set(rec["step_ms"]) and len(rec["value_by_scene_seed"]) == 1
 
 
 def test_two_ranks_through_torch_distributed_run():
@@ -68,3 +69,18 @@ def test_two_ranks_through_torch_distributed_run():
     _check(rec, 2, 2, 1, 2)
     assert "More-Thuente" in rec["config"]["workload"] and rec["mean_linearizations"] >= rec["mean_iterations"] + 1
     assert rec["cpu_baseline"] is None and "x2" in rec["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("config,extra", [(2, ["--sensor", "VLP-16", "--downsample", "0.5"]), (3, ["--sensor", "VLP-16", "--downsample", "0.5"]),
+                                          (4, ["--candidates", "3", "--distinct", "2", "--sensor", "VLP-16", "--downsample", "0.5"])])
+def test_other_baseline_configs_emit_the_same_contract(config, extra):
+    """--config 2 / 3 / 4 (5 is config 2's code path on a 1 M-point pair): one JSON line each with roofline, cpu_baseline and the
+    per-step percentiles."""
+    rec = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config", str(config), *extra, "--cpu-sample", "2"])
+    for key, typ in REQUIRED.items():
+        assert key in rec, key
+    assert rec["unit"] == "registrations/sec" and rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["value"] > 0
+    assert rec["config"]["baseline_config"] == config and f"config {config}" in rec["config"]["workload"] or config == 4
+    assert ROOFLINE <= set(rec["roofline"]) and rec["cpu_baseline"]["value"] > 0 and {"p10", "p50", "p90"} <= set(rec["step_ms"])
+    if config == 3:
+        assert "p99" in rec["latency_ms"] and "H2D" in rec["config"]["workload"]
