@@ -129,6 +129,9 @@ def main():
                     "(default 3 at one GPU, 1 otherwise)")
     ap.add_argument("--ndt-line-search", action="store_true", help="NDT_OMP with the opt-in More-Thuente search (NOT the reference's behaviour; "
                     "the line then says so in config.workload)")
+    ap.add_argument("--regularization", default="", choices=["", "FROBENIUS", "PLANE", "MIN_EIG", "NORMALIZED_MIN_EIG", "NONE"],
+                    help="fast_gicp RegularizationMethod of the GICP covariances (default: FROBENIUS, the constructor default hdl_graph_slam runs with; the "
+                         "others take k_knn_cov's second instantiation with a 3x3 eigen-decomposition per point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=3, help="units registered by the CPU oracle for cpu_baseline")
     args = ap.parse_args()
@@ -229,6 +232,8 @@ def run_loop_batch(ctx):
         pnh["reg_resolution"] = 1.0   # launch files use 1.0 (NDT factory default 0.5)
     if a.ndt_line_search and method == "NDT_OMP":
         pnh["reg_ndt_line_search"] = True
+    if a.regularization:
+        pnh["reg_regularization_method"] = a.regularization
     reg = ctx["select_registration_method"](pnh, device_id=ctx["local_rank"])
     shard = ctx["CandidateShard"](rank, world, device=ctx["coll_device"]) if ctx["sharded"] else None
     barrier = make_barrier(ctx, reg)
@@ -349,6 +354,7 @@ def run_loop_batch(ctx):
     out = base_line(ctx, world * B * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
                     f"loop-closure batch: {B} candidate keyframes/GPU x {sensor} (~{int(np.mean(n_pts))} pts) vs 1 query keyframe, "
                     f"{method}{' with the opt-in More-Thuente line search (not the reference behaviour)' if pnh.get('reg_ndt_line_search') else ''}"
+                    f"{' (covariance regularisation ' + a.regularization + ')' if a.regularization else ''}"
                     f" + getFitnessScore, cold (index + covariances rebuilt every step)",
                     {"candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": method,
                      "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU"})

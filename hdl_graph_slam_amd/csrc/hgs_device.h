@@ -123,12 +123,12 @@ void launch_ndt_build_cells(hipStream_t s, CloudDesc desc, const unsigned long l
                             int* hash_keys, int* hash_vals, int hash_mask, NdtCellRec* cells);
 void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog);
 void launch_ndt_pack_hash(hipStream_t s, const int* keys, const int* vals, int2* kv, int cap);
-// one Newton iteration of B problems in one launch: `blocks` resident blocks pull chunks of `chunk` consecutive (problem, tile)
-// items — numbered by tile_base[B + 1], the prefix sums of the problems' tile counts — from *queue, whose values
-// [base, base + tile_base[B]) belong to this pass; sorted: read the sources in Hilbert order (they have a search index);
-// debug: only leave the totals in accum[].out
+// one Newton iteration of B problems in one launch: `blocks` resident blocks pull runs of consecutive (problem, tile) items —
+// numbered by tile_base[B + 1], the prefix sums of the problems' tile counts — from queues[parity & 1] (zero at the start of the
+// pass; the kernel zeroes the other head for the next pass, so the caller alternates parity), at most `chunk` items per grab;
+// sorted: read the sources in Hilbert order (they have a search index); debug: only leave the totals in accum[].out
 void launch_ndt_pass(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c, NdtAccum* accum, const int* tile_base,
-                     unsigned long long* queue, int B, unsigned long long base, int blocks, int chunk, int sorted, int debug, Progress prog);
+                     unsigned long long* queues, int B, int parity, int blocks, int chunk, int sorted, int debug, Progress prog);
 void launch_ndt_results(hipStream_t s, const CloudDesc* descs, const NdtState* states, DevResult* out, int B);
 
 void launch_vgicp_grid_params(hipStream_t s, CloudDesc desc, double resolution);

@@ -148,7 +148,7 @@ struct hgs_handle {
   DeviceBuffer comm_send, comm_recv, comm_ids;
   DeviceBuffer ndt_plan;         // per lane: work queue head + tile prefix sums of the running NDT batch
   int ndt_resident_blocks = 512; // blocks per k_ndt_pass launch (2 per CU); HGS_NDT_RESIDENT (A/B runs)
-  int ndt_chunk = 0;             // items per queue grab (0: the default, 2); HGS_NDT_CHUNK (A/B runs)
+  int ndt_chunk = 0;             // largest queue grab in items (0: the default, 8; 1 = one tile per grab); HGS_NDT_CHUNK (A/B runs)
   int ndt_sort = -1;       // NDT source order: -1 Hilbert order if the source has an index, 1 build the index first, 0 input order (HGS_NDT_SORT, A/B runs)
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_descs, h_results, h_small, h_flags;  // h_flags: host-mapped progress mirror (Progress)
@@ -775,8 +775,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     HGS_HIP(h, hipMemsetAsync(h->ndt_accum.p, 0, (size_t)B * sizeof(NdtAccum), h->stream));
     NdtAccum* accum = h->ndt_accum.as<NdtAccum>();
     // work plan of every lane: the (problem, tile) items of a pass are numbered by the prefix sums of the problems' tile counts
-    // (from n_input: an upper bound of the finite points), and pulled from a queue in HBM whose values advance by `stride`
-    // per pass (k_ndt_pass)
+    // (from n_input: an upper bound of the finite points), and pulled from a queue head in HBM (k_ndt_pass)
     // one derivative pass per iteration as ndt_omp runs; up to 1 + 10 with the More-Thuente search
     const long max_rounds = ((long)c.max_iterations + 4) * (c.line_search ? 11 : 1);
     std::vector<BatchLane> lanes;
@@ -787,8 +786,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     };
     struct LanePlan {
       int* tile_base;
-      unsigned long long* queue;
-      unsigned long long stride;
+      unsigned long long* queues;  // two heads, used alternately (k_ndt_pass)
       int blocks, chunk;
     };
     std::vector<LanePlan> plans(lanes.size());
@@ -804,12 +802,10 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
         LanePlan& P = plans[li];
         const int total = tb[L.B];
         P.blocks = std::max(1, std::min(total, h->ndt_resident_blocks));
-        // items per queue grab: 2 (measured on the 16 x 119 k batch, 4 lanes: 1 -> 904, 2 -> 1062, 3 -> 980, 4 -> 936, 8 -> 845
-        // registrations/s: small grabs balance the tail of a pass, every change of problem costs a flush of ~170 atomics; a
-        // chunk sized by the kernel itself from the problems still iterating was slower than any fixed one)
-        P.chunk = h->ndt_chunk > 0 ? h->ndt_chunk : 2;
-        P.stride = (unsigned long long)total + (unsigned long long)(P.blocks + 1) * (unsigned long long)P.chunk;  // room for every block's last, failing grab
-        P.queue = reinterpret_cast<unsigned long long*>((char*)h->ndt_plan.p + li * per_lane);
+        // largest queue grab (the kernel sizes each grab by guided self-scheduling, at most this many items).  Fixed grabs
+        // measured on the 16 x 119 k batch with 4 lanes: 1 -> 904, 2 -> 1062, 3 -> 980, 4 -> 936, 8 -> 845 registrations/s
+        P.chunk = h->ndt_chunk > 0 ? h->ndt_chunk : 8;
+        P.queues = reinterpret_cast<unsigned long long*>((char*)h->ndt_plan.p + li * per_lane);
         P.tile_base = reinterpret_cast<int*>((char*)h->ndt_plan.p + li * per_lane + 16);
       }
       HGS_HIP(h, hipMemcpy(h->ndt_plan.p, host.data(), host.size(), hipMemcpyHostToDevice));  // synchronous: `host` is pageable and dies here
@@ -818,8 +814,8 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       StageTimer tm(h, HGS_STAGE_LINEARIZE);
       const LanePlan& P = plans[&L - lanes.data()];
-      launch_ndt_pass(L.stream, d_descs + L.b0, tv, st + L.b0, ang + L.b0, c, accum + L.b0, P.tile_base, P.queue, L.B, (unsigned long long)L.round * P.stride, P.blocks,
-                      P.chunk, sorted ? 1 : 0, 0, L.prog);
+      launch_ndt_pass(L.stream, d_descs + L.b0, tv, st + L.b0, ang + L.b0, c, accum + L.b0, P.tile_base, P.queues, L.B, (int)(L.round & 1), P.blocks, P.chunk,
+                      sorted ? 1 : 0, 0, L.prog);
     }, finish_lane);
     HGS_TRY(close_lanes(h, lanes));
   }
@@ -1867,7 +1863,7 @@ int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, 
   } plan{0, 0, {0, max_blocks}};
   HGS_HIP(h, hipMemcpy(h->ndt_plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice));
   launch_ndt_pass(h->stream, d_descs, ndt_target_view(h, t), h->states.as<NdtState>(), h->angles.as<NdtAngles>(), c, h->ndt_accum.as<NdtAccum>(),
-                  reinterpret_cast<const int*>((char*)h->ndt_plan.p + 16), reinterpret_cast<unsigned long long*>(h->ndt_plan.p), 1, 0ull, std::min(max_blocks, 96),
+                  reinterpret_cast<const int*>((char*)h->ndt_plan.p + 16), reinterpret_cast<unsigned long long*>(h->ndt_plan.p), 1, 0, std::min(max_blocks, 96),
                   2 /* several tiles per block, several grabs per block */, (h->ndt_sort != 0 && s->has_index) ? 1 : 0, 1, none);
   double acc[kAccNdt];
   HGS_HIP(h, hipMemcpyAsync(acc, h->ndt_accum.as<NdtAccum>()->out, sizeof(acc), hipMemcpyDeviceToHost, h->stream));

@@ -871,7 +871,7 @@ struct NdtPassShared {
   double acc[kAccNdt];
   double svd[72];
   unsigned long long next;
-  int last, out_of_range;
+  int next_chunk, last, out_of_range;
 };
 
 // The block that completed problem b's tile count: totals -> doubles, Newton step.  All threads of the block call it.
@@ -935,14 +935,22 @@ __device__ __noinline__ bool ndt_flush(NdtPassShared& S, NdtAccum& A, int tiles,
 
 template <int NOFF>
 __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restrict__ descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c,
-                                                         NdtAccum* accum, const int* __restrict__ tile_base /* [B + 1] */, unsigned long long* queue, int B,
-                                                         unsigned long long base, int chunk, int sorted, int debug, Progress prog) {
+                                                         NdtAccum* accum, const int* __restrict__ tile_base /* [B + 1] */, unsigned long long* queues /* [2] */, int B,
+                                                         int parity, int chunk, int sorted, int debug, Progress prog) {
   __shared__ NdtPassShared S;
   const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
   for (int k = threadIdx.x; k < (kBlock / 64) * kAccNdt * 4; k += kBlock) (&S.tot[0][0])[k] = 0;
-  if (threadIdx.x == 0) S.out_of_range = 0, S.next = atomicAdd(queue, (unsigned long long)chunk);
+  // two queue heads used alternately: this pass counts on queues[parity] from 0 and zeroes the other one for the next pass
+  // (which starts after this kernel has ended, and the pass before, which used it, has)
+  unsigned long long* queue = queues + parity;
+  if (blockIdx.x == 0 && threadIdx.x == 0) queues[parity ^ 1] = 0ull;
+  const unsigned long long base = 0ull, end = (unsigned long long)tile_base[B];
+  // Guided self-scheduling: a grab takes (items left) / (2 * blocks) items, between 1 and `chunk` — long runs of one problem's
+  // tiles while there is plenty of work (every change of problem costs a flush: ~170 atomics and a ticket round trip), single
+  // tiles at the end of the pass (when the blocks must finish together).  "Items left" is judged from this block's last grab.
+  const int first_chunk = max(1, min(chunk, tile_base[B] / (2 * (int)gridDim.x)));
+  if (threadIdx.x == 0) S.out_of_range = 0, S.next = atomicAdd(queue, (unsigned long long)first_chunk), S.next_chunk = first_chunk;
   __syncthreads();
-  const unsigned long long end = base + (unsigned long long)tile_base[B];
   const CloudMeta* m = tgt.meta;
   const int mnx = m->ndt_min_b[0], mny = m->ndt_min_b[1], mnz = m->ndt_min_b[2];
   const int mxx = m->ndt_max_b[0], mxy = m->ndt_max_b[1], mxz = m->ndt_max_b[2];
@@ -954,8 +962,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
   while (w < end) {
     __syncthreads();  // everybody has read S.next
     unsigned long long nxt = 0;
-    if (threadIdx.x == 0) nxt = atomicAdd(queue, (unsigned long long)chunk);  // the next chunk's grab is in flight during this chunk
-    const unsigned long long lo = w < base ? base : w, hi = w + (unsigned long long)chunk < end ? w + (unsigned long long)chunk : end;
+    const int my_chunk = S.next_chunk;
+    const long long left = (long long)(end - w) - my_chunk;
+    const int nxt_chunk = (int)max(1ll, min((long long)chunk, left / (2 * (long long)gridDim.x)));
+    if (threadIdx.x == 0) nxt = atomicAdd(queue, (unsigned long long)nxt_chunk);  // the next grab is in flight during this chunk
+    const unsigned long long lo = w < base ? base : w, hi = w + (unsigned long long)my_chunk < end ? w + (unsigned long long)my_chunk : end;
     for (unsigned long long it = lo; it < hi; it++) {
       const int item = (int)(it - base);
       if (item < cur_first || item >= cur_end) {
@@ -1088,7 +1099,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
         if (__ballot(bad) != 0ull && lane == 0) S.out_of_range = 1;
       }
     }
-    if (threadIdx.x == 0) S.next = nxt;
+    __syncthreads();  // everybody has read S.next_chunk
+    if (threadIdx.x == 0) S.next = nxt, S.next_chunk = nxt_chunk;
     __syncthreads();
     w = S.next;
   }
@@ -1096,12 +1108,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
     ndt_finish_problem(S, accum[cur_b], states[cur_b], angles[cur_b], c, debug, prog);
 }
 void launch_ndt_pass(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c, NdtAccum* accum, const int* tile_base,
-                     unsigned long long* queue, int B, unsigned long long base, int blocks, int chunk, int sorted, int debug, Progress prog) {
+                     unsigned long long* queues, int B, int parity, int blocks, int chunk, int sorted, int debug, Progress prog) {
   const dim3 grid(blocks < 1 ? 1 : blocks), block(kBlock);
   if (chunk < 1) chunk = 1;
-  if (c.search == 1) hipLaunchKernelGGL(k_ndt_pass<1>, grid, block, 0, s, descs, tgt, states, angles, c, accum, tile_base, queue, B, base, chunk, sorted, debug, prog);
-  else if (c.search == 2) hipLaunchKernelGGL(k_ndt_pass<7>, grid, block, 0, s, descs, tgt, states, angles, c, accum, tile_base, queue, B, base, chunk, sorted, debug, prog);
-  else hipLaunchKernelGGL(k_ndt_pass<27>, grid, block, 0, s, descs, tgt, states, angles, c, accum, tile_base, queue, B, base, chunk, sorted, debug, prog);
+  parity &= 1;
+  if (c.search == 1) hipLaunchKernelGGL(k_ndt_pass<1>, grid, block, 0, s, descs, tgt, states, angles, c, accum, tile_base, queues, B, parity, chunk, sorted, debug, prog);
+  else if (c.search == 2) hipLaunchKernelGGL(k_ndt_pass<7>, grid, block, 0, s, descs, tgt, states, angles, c, accum, tile_base, queues, B, parity, chunk, sorted, debug, prog);
+  else hipLaunchKernelGGL(k_ndt_pass<27>, grid, block, 0, s, descs, tgt, states, angles, c, accum, tile_base, queues, B, parity, chunk, sorted, debug, prog);
 }
 
 __global__ void k_ndt_results(const CloudDesc* descs, const NdtState* states, DevResult* out, int B) {
