@@ -49,7 +49,7 @@ class HgsPrefilterParams(C.Structure):
     ]
 
 
-HGS_DOWNSAMPLE_NONE, HGS_DOWNSAMPLE_VOXELGRID = 0, 1
+HGS_DOWNSAMPLE_NONE, HGS_DOWNSAMPLE_VOXELGRID, HGS_DOWNSAMPLE_APPROX_VOXELGRID = 0, 1, 2
 HGS_OUTLIER_NONE, HGS_OUTLIER_STATISTICAL, HGS_OUTLIER_RADIUS = 0, 1, 2
 
 

@@ -166,6 +166,11 @@ constexpr unsigned long long kVoxelInvalidKey = 0xffffffffull;  // prefilter vox
 constexpr unsigned long long kMapInvalidKey = ~0ull;            // map cloud: up to 2^62 lattice cells
 void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* slot,
                                int cap, float4* out, int* count_out);
+void launch_pf_approx_keys(hipStream_t s, const float4* pts, const int* count, float inv_leaf, int cap, unsigned long long* keys, unsigned* vals);
+void launch_pf_approx_heads(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, float inv_leaf, int cap, unsigned* head, unsigned* evict,
+                            unsigned* bucket_used /* [512], zeroed */, unsigned* bucket_rank /* [513] */);
+void launch_pf_approx_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* evict,
+                                const unsigned* evict_rank, const unsigned* bucket_rank, int cap, float4* out, int* count_out);
 void launch_pf_radius_flags(hipStream_t s, CloudDesc d, float r2, int min_neighbors, unsigned* keep);
 void launch_pf_mean_knn_dist(hipStream_t s, CloudDesc d, int mean_k, double* dist);
 void launch_pf_statistical(hipStream_t s, const double* dist, int n, double* stats, double stddev_mul, unsigned* keep);

@@ -1439,8 +1439,8 @@ extern "C" int hgs_prefilter_params_default(hgs_prefilter_params* p) try {
 
 extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, hgs_cloud** out) try {
   if (!h || !p || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
-  if (p->downsample_method < HGS_DOWNSAMPLE_NONE || p->downsample_method > HGS_DOWNSAMPLE_VOXELGRID || p->outlier_removal_method < HGS_OUTLIER_NONE ||
-      p->outlier_removal_method > HGS_OUTLIER_RADIUS || (p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID && !(p->downsample_resolution > 0)) ||
+  if (p->downsample_method < HGS_DOWNSAMPLE_NONE || p->downsample_method > HGS_DOWNSAMPLE_APPROX_VOXELGRID || p->outlier_removal_method < HGS_OUTLIER_NONE ||
+      p->outlier_removal_method > HGS_OUTLIER_RADIUS || (p->downsample_method != HGS_DOWNSAMPLE_NONE && !(p->downsample_resolution > 0)) ||
       (p->outlier_removal_method == HGS_OUTLIER_STATISTICAL && (p->statistical_mean_k < 1 || p->statistical_mean_k > 62)) ||
       (p->outlier_removal_method == HGS_OUTLIER_RADIUS && (!(p->radius_radius > 0) || p->radius_min_neighbors < 0)))
     return HGS_ERR_INVALID_ARGUMENT;
@@ -1499,6 +1499,40 @@ extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t st
     HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));
     launch_pf_voxel_centroids(h->stream, cur, h->sort_keys[1].as<unsigned long long>(), h->sort_vals[1].as<unsigned>(), h->pf_keep.as<unsigned>(),
                               h->pf_slot.as<unsigned>(), (int)n, other, d_count);
+    std::swap(cur, other);
+  }
+  if (n > 0 && p->downsample_method == HGS_DOWNSAMPLE_APPROX_VOXELGRID) {
+    // pcl::ApproximateVoxelGrid: stable sort by history bucket, runs of equal voxel, eviction order (k_pf_approx_*)
+    const float inv_leaf = 1.0f / (float)p->downsample_resolution;
+    for (int i = 0; i < 2; i++) {
+      HGS_HIP(h, h->sort_keys[i].reserve(n * sizeof(uint64_t)));
+      HGS_HIP(h, h->sort_vals[i].reserve(n * sizeof(uint32_t)));
+    }
+    const size_t o_bucket = align_up(n * sizeof(uint32_t), 256);
+    HGS_HIP(h, h->misc.reserve(o_bucket + 2048 * sizeof(uint32_t)));
+    unsigned* d_head = h->misc.as<unsigned>();
+    unsigned* d_bucket_used = reinterpret_cast<unsigned*>(h->misc.as<char>() + o_bucket);
+    unsigned* d_bucket_rank = d_bucket_used + 512;
+    launch_pf_approx_keys(h->stream, cur, d_count, inv_leaf, (int)n, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
+    size_t tmp_bytes = 0;
+    int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                    h->sort_vals[1].as<uint32_t>(), n, 0, 10, h->stream);
+    if (rc == 0) {
+      HGS_HIP(h, h->sort_tmp.reserve(tmp_bytes));
+      rc = hgs_sort_pairs_u64_u32(h->sort_tmp.p, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
+                                  h->sort_vals[1].as<uint32_t>(), n, 0, 10, h->stream);
+    }
+    if (rc != 0) {
+      h->err = "rocprim radix_sort_pairs failed";
+      return HGS_ERR_HIP;
+    }
+    HGS_HIP(h, hipMemsetAsync(h->pf_keep.p, 0, n * sizeof(uint32_t), h->stream));
+    HGS_HIP(h, hipMemsetAsync(d_bucket_used, 0, 1025 * sizeof(uint32_t), h->stream));
+    launch_pf_approx_heads(h->stream, cur, h->sort_keys[1].as<unsigned long long>(), h->sort_vals[1].as<unsigned>(), inv_leaf, (int)n, d_head, h->pf_keep.as<unsigned>(),
+                           d_bucket_used, d_bucket_rank);
+    HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));
+    launch_pf_approx_centroids(h->stream, cur, h->sort_keys[1].as<unsigned long long>(), h->sort_vals[1].as<unsigned>(), d_head, h->pf_keep.as<unsigned>(),
+                               h->pf_slot.as<unsigned>(), d_bucket_rank, (int)n, other, d_count);
     std::swap(cur, other);
   }
   HGS_HIP(h, hipGetLastError());

@@ -1425,6 +1425,113 @@ void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned 
     hipLaunchKernelGGL(k_pf_voxel_centroids, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, keys, vals, head, slot, cap, out, count_out);
 }
 
+// ---- pcl::ApproximateVoxelGrid (apps/prefiltering_nodelet.cpp:59-63, scan_matching_odometry_nodelet.cpp:91-96) ------------------
+// PCL walks the points in input order through a 512-entry history table (hash of the voxel coordinates); a point that finds
+// another voxel in its bucket flushes that voxel's running centroid to the output.  Per bucket the subsequence of its points
+// is therefore cut into RUNS of equal voxel, each run is one output, a run that is followed by another run of its bucket is
+// emitted when that next run's first point arrives (so evictions come out in the order of those points' input indices), and
+// the last run of every bucket is emitted at the end in bucket order.  Parallel form: stable sort by bucket, run heads, one
+// scan over the evicting points' input indices for the output slots, one thread per run for the float centroid in sequence
+// order — the same output, in the same order, as the sequential filter.
+__device__ __forceinline__ void approx_voxel_of(const float4& p, float inv_leaf, int* ix, int* iy, int* iz, unsigned* hash) {
+  *ix = (int)floorf(p.x * inv_leaf), *iy = (int)floorf(p.y * inv_leaf), *iz = (int)floorf(p.z * inv_leaf);
+  *hash = ((unsigned)*ix * 7171u + (unsigned)*iy * 3079u + (unsigned)*iz * 4231u) & 511u;
+}
+constexpr unsigned long long kApproxInvalidBucket = 1023ull;
+__global__ __launch_bounds__(kBlock) void k_pf_approx_keys(const float4* __restrict__ pts, const int* __restrict__ count, float inv_leaf, int cap,
+                                                           unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= cap) return;
+  unsigned long long key = kApproxInvalidBucket;
+  if (i < *count) {
+    const float4 p = pts[i];
+    if (finite3(p)) {
+      int ix, iy, iz;
+      unsigned h;
+      approx_voxel_of(p, inv_leaf, &ix, &iy, &iz, &h);
+      key = h;
+    }
+  }
+  keys[i] = key;
+  vals[i] = (unsigned)i;
+}
+// sorted position j: head[j] = 1 if a run starts there; evict[input index of that point] = 1 if the run is not the first of its
+// bucket (its first point evicts the previous run); bucket_used[h] = 1 for every bucket that holds points
+__global__ __launch_bounds__(kBlock) void k_pf_approx_heads(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                            float inv_leaf, int cap, unsigned* __restrict__ head, unsigned* __restrict__ evict,
+                                                            unsigned* __restrict__ bucket_used) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= cap) return;
+  const unsigned long long h = keys[j];
+  unsigned is_head = 0;
+  if (h != kApproxInvalidBucket) {
+    const bool first_of_bucket = j == 0 || keys[j - 1] != h;
+    int ix, iy, iz, jx, jy, jz;
+    unsigned hh;
+    approx_voxel_of(pts[vals[j]], inv_leaf, &ix, &iy, &iz, &hh);
+    bool other_voxel = false;
+    if (!first_of_bucket) {
+      approx_voxel_of(pts[vals[j - 1]], inv_leaf, &jx, &jy, &jz, &hh);
+      other_voxel = ix != jx || iy != jy || iz != jz;
+    }
+    is_head = (first_of_bucket || other_voxel) ? 1u : 0u;
+    if (other_voxel) evict[vals[j]] = 1u;
+    if (first_of_bucket) bucket_used[h] = 1u;
+  }
+  head[j] = is_head;
+}
+// bucket_rank[h] = number of used buckets below h (512 entries: one block), total in bucket_rank[512]
+__global__ __launch_bounds__(512) void k_pf_approx_bucket_ranks(const unsigned* __restrict__ bucket_used, unsigned* __restrict__ bucket_rank) {
+  __shared__ unsigned s[512];
+  const int t = threadIdx.x;
+  s[t] = bucket_used[t];
+  __syncthreads();
+  unsigned r = 0;
+  for (int k = 0; k < t; k++) r += s[k];
+  bucket_rank[t] = r;
+  if (t == 511) bucket_rank[512] = r + s[511];
+}
+// one thread per run: float sums in sequence order, then the slot: the eviction rank of the point that ends the run, or behind
+// all evictions in bucket order
+__global__ __launch_bounds__(kBlock) void k_pf_approx_centroids(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                                const unsigned* __restrict__ head, const unsigned* __restrict__ evict, const unsigned* __restrict__ evict_rank,
+                                                                const unsigned* __restrict__ bucket_rank, int cap, int n_points, float4* __restrict__ out,
+                                                                int* __restrict__ count_out) {
+  HGS_FP_STRICT
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= cap) return;
+  const unsigned n_evictions = n_points > 0 ? evict_rank[n_points - 1] + evict[n_points - 1] : 0u;
+  if (j == 0) *count_out = (int)(n_evictions + bucket_rank[512]);
+  if (!head[j]) return;
+  const unsigned long long h = keys[j];
+  float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+  int n = 0, e = j;
+  for (; e < cap && keys[e] == h && (e == j || !head[e]); e++) {
+    const float4 p = pts[vals[e]];
+    sx += p.x, sy += p.y, sz += p.z, si += p.w;
+    n++;
+  }
+  const bool evicted = e < cap && keys[e] == h;  // another run of this bucket follows: its first point flushed this one
+  const unsigned slot = evicted ? evict_rank[vals[e]] : n_evictions + bucket_rank[h];
+  const float fn = (float)n;
+  out[slot] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+}
+void launch_pf_approx_keys(hipStream_t s, const float4* pts, const int* count, float inv_leaf, int cap, unsigned long long* keys, unsigned* vals) {
+  if (cap > 0) hipLaunchKernelGGL(k_pf_approx_keys, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, count, inv_leaf, cap, keys, vals);
+}
+void launch_pf_approx_heads(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, float inv_leaf, int cap, unsigned* head, unsigned* evict,
+                            unsigned* bucket_used, unsigned* bucket_rank) {
+  if (cap <= 0) return;
+  hipLaunchKernelGGL(k_pf_approx_heads, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, keys, vals, inv_leaf, cap, head, evict, bucket_used);
+  hipLaunchKernelGGL(k_pf_approx_bucket_ranks, dim3(1), dim3(512), 0, s, bucket_used, bucket_rank);
+}
+void launch_pf_approx_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* evict,
+                                const unsigned* evict_rank, const unsigned* bucket_rank, int cap, float4* out, int* count_out) {
+  if (cap > 0)
+    hipLaunchKernelGGL(k_pf_approx_centroids, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, keys, vals, head, evict, evict_rank, bucket_rank, cap, cap, out,
+                       count_out);
+}
+
 // pcl::RadiusOutlierRemoval (:85-93): keep p iff more than min_neighbors points (p included) lie strictly within the
 // radius.  One thread per Hilbert-sorted point, packet walk on the cloud's own tree; the flag lands at the point's
 // ORIGINAL index so that the compaction keeps the input order.

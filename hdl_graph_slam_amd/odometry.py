@@ -15,20 +15,19 @@ import numpy as np
 def make_downsample(registration, downsample_method: str = "VOXELGRID", downsample_resolution: float = 0.1):
     """The downsample filter of the odometry nodelet (scan_matching_odometry_nodelet.cpp:84-104, applied at :147-157).
 
-    VOXELGRID runs on the device through hgs_prefilter (distance filter and outlier removal off) and returns a RESIDENT
-    cloud, so the sweep is uploaded once and registered in place; NONE is the pass-through filter the launch files select
-    for this nodelet; APPROX_VOXELGRID is not implemented on the device (its output depends on PCL's hash eviction order)."""
+    VOXELGRID (pcl::VoxelGrid) and APPROX_VOXELGRID (pcl::ApproximateVoxelGrid, :91-96) run on the device through hgs_prefilter
+    (distance filter and outlier removal off) and return a RESIDENT cloud, so the sweep is uploaded once and registered in
+    place; NONE is the pass-through filter the launch files select for this nodelet."""
     method = downsample_method.upper()
-    if method == "VOXELGRID":
+    if method in ("VOXELGRID", "APPROX_VOXELGRID"):
         from . import _lib as L
         import ctypes as C
         p = L.HgsPrefilterParams()
         L.lib().hgs_prefilter_params_default(C.byref(p))
         p.use_distance_filter, p.outlier_removal_method = 0, L.HGS_OUTLIER_NONE
-        p.downsample_method, p.downsample_resolution = L.HGS_DOWNSAMPLE_VOXELGRID, downsample_resolution
+        p.downsample_method = L.HGS_DOWNSAMPLE_VOXELGRID if method == "VOXELGRID" else L.HGS_DOWNSAMPLE_APPROX_VOXELGRID
+        p.downsample_resolution = downsample_resolution
         return lambda cloud: registration.prefilter(cloud, p)
-    if method == "APPROX_VOXELGRID":
-        raise NotImplementedError("APPROX_VOXELGRID is left to PCL (INTEGRATION.md)")
     return lambda cloud: cloud   # NONE / unknown -> passthrough (:97-103)
 
 

@@ -183,7 +183,7 @@ int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, si
 int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, const float relpose[16], double max_range, double* score);
 
 /* ---- "next" row f2: the prefilter in front of the path (apps/prefiltering_nodelet.cpp:131-182) -------------------- */
-enum hgs_downsample_method { HGS_DOWNSAMPLE_NONE = 0, HGS_DOWNSAMPLE_VOXELGRID = 1 };          /* :51-72  */
+enum hgs_downsample_method { HGS_DOWNSAMPLE_NONE = 0, HGS_DOWNSAMPLE_VOXELGRID = 1, HGS_DOWNSAMPLE_APPROX_VOXELGRID = 2 }; /* :51-72; pcl::VoxelGrid / pcl::ApproximateVoxelGrid */
 enum hgs_outlier_removal { HGS_OUTLIER_NONE = 0, HGS_OUTLIER_STATISTICAL = 1, HGS_OUTLIER_RADIUS = 2 }; /* :73-93 */
 typedef struct hgs_prefilter_params {
   int32_t use_distance_filter;     /* use_distance_filter   (true)   :94                                  */

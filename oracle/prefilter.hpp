@@ -102,6 +102,41 @@ inline bool pf_voxelgrid(const std::vector<PfPoint>& in, double leaf, std::vecto
   return true;
 }
 
+// pcl::ApproximateVoxelGrid<PointT>::applyFilter (apps/prefiltering_nodelet.cpp:59-63, apps/scan_matching_odometry_nodelet.cpp:91-96)
+// [UPSTREAM-KNOWLEDGE, PCL 1.8-1.12 approximate_voxel_grid.hpp]: a 512-entry history table indexed by
+//   hash = (ix * 7171 + iy * 3079 + iz * 4231) & 511,  (ix, iy, iz) = floor(p * inverse_leaf)  (float)
+// is walked over the points IN INPUT ORDER: a point whose bucket holds another voxel first flushes that bucket's centroid to the
+// output (sum of the fields in float / count) and takes the bucket over; at the end the occupied buckets are flushed in bucket
+// order.  The same voxel can therefore appear several times in the output, and the output order is the order of the evictions.
+// downsample_all_data_ defaults to true: the centroid covers x, y, z and intensity.  Non-finite points are skipped here (PCL
+// converts floor(NaN) to int, which is undefined).
+inline void pf_approx_voxelgrid(const std::vector<PfPoint>& in, double leaf, std::vector<PfPoint>& out) {
+  out.clear();
+  const float inv = 1.0f / (float)leaf;
+  struct Entry {
+    int ix = 0, iy = 0, iz = 0, count = 0;
+    float sx = 0, sy = 0, sz = 0, si = 0;
+  };
+  std::vector<Entry> hist(512);
+  auto flush = [&](Entry& e) {
+    const float n = (float)e.count;
+    out.push_back({e.sx / n, e.sy / n, e.sz / n, e.si / n});
+    e.count = 0, e.sx = e.sy = e.sz = e.si = 0.f;
+  };
+  for (const PfPoint& p : in) {
+    if (!pf_finite(p)) continue;
+    const int ix = (int)std::floor(p.x * inv), iy = (int)std::floor(p.y * inv), iz = (int)std::floor(p.z * inv);
+    const unsigned hash = ((unsigned)ix * 7171u + (unsigned)iy * 3079u + (unsigned)iz * 4231u) & 511u;  // two's-complement wrap of PCL's int arithmetic
+    Entry& e = hist[hash];
+    if (e.count && (ix != e.ix || iy != e.iy || iz != e.iz)) flush(e);
+    e.ix = ix, e.iy = iy, e.iz = iz;
+    e.count++;
+    e.sx += p.x, e.sy += p.y, e.sz += p.z, e.si += p.intensity;
+  }
+  for (Entry& e : hist)
+    if (e.count) flush(e);
+}
+
 inline OCloud pf_tree_of(const std::vector<PfPoint>& in) {
   OCloud c;
   c.assign(in.data(), in.size(), sizeof(PfPoint));
@@ -154,6 +189,10 @@ inline bool prefilter(const std::vector<PfPoint>& in, const PrefilterParams& p, 
   if (p.downsample_method == 1) {
     std::vector<PfPoint> ds;
     if (!pf_voxelgrid(cur, p.downsample_resolution, ds)) return false;
+    cur.swap(ds);
+  } else if (p.downsample_method == 2) {
+    std::vector<PfPoint> ds;
+    pf_approx_voxelgrid(cur, p.downsample_resolution, ds);
     cur.swap(ds);
   }
   if (p.outlier_removal_method == 1) cur = pf_statistical_outlier_removal(cur, p.statistical_mean_k, p.statistical_stddev);

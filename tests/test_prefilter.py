@@ -147,3 +147,74 @@ def test_cloud_download_round_trip():
     for f in ("x", "y", "z", "intensity"):
         assert np.array_equal(got[f], cloud[f], equal_nan=True)
     reg.close()
+
+
+def _py_approx_voxelgrid(cloud, leaf):
+    """pcl::ApproximateVoxelGrid as PCL runs it — a plain sequential loop over the points with the 512-entry history table —
+    independent of oracle/prefilter.hpp and of the device's sort-based form."""
+    inv = np.float32(1.0) / np.float32(leaf)
+    hist = {}
+    out = []
+
+    def flush(e):
+        out.append((e[4] / np.float32(e[3])).astype(np.float32))
+
+    for r in cloud:
+        p = np.array([r["x"], r["y"], r["z"], r["intensity"]], np.float32)
+        if not np.isfinite(p[:3]).all():
+            continue
+        ix, iy, iz = (int(np.floor(np.float32(p[k] * inv))) for k in range(3))
+        h = (ix * 7171 + iy * 3079 + iz * 4231) & 511
+        e = hist.get(h)
+        if e is not None and e[3] and (e[0], e[1], e[2]) != (ix, iy, iz):
+            flush(e)
+            e = None
+        if e is None:
+            e = [ix, iy, iz, 0, np.zeros(4, np.float32)]
+            hist[h] = e
+        e[3] += 1
+        e[4] = (e[4] + p).astype(np.float32)
+    for h in sorted(hist):
+        if hist[h][3]:
+            flush(hist[h])
+    return np.array(out, np.float32).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("leaf", [0.1, 0.5, 2.0])
+def test_oracle_approx_voxelgrid_matches_the_sequential_filter(leaf):
+    cloud = _scan(4)[::3]
+    p = O.default_prefilter_params()
+    p.use_distance_filter, p.outlier_removal_method, p.downsample_method, p.downsample_resolution = 0, 0, 2, leaf
+    got = O.prefilter(cloud, p)
+    ref = _py_approx_voxelgrid(cloud, leaf)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    # the approximate filter emits a voxel once per eviction: never fewer outputs than pcl::VoxelGrid
+    p.downsample_method = 1
+    assert len(got) >= len(O.prefilter(cloud, p))
+
+
+def _check_approx_voxelgrid(make_engine):
+    from hdl_graph_slam_amd import _lib as L
+    reg = make_engine()
+    for seed, leaf, dist in ((5, 0.1, 0), (6, 0.5, 1), (7, 3.0, 0)):
+        cloud = _scan(seed)
+        p = L.HgsPrefilterParams()
+        L.lib().hgs_prefilter_params_default(C.byref(p))
+        p.use_distance_filter, p.outlier_removal_method = dist, 0
+        p.downsample_method, p.downsample_resolution = L.HGS_DOWNSAMPLE_APPROX_VOXELGRID, leaf
+        dc = reg.prefilter(cloud, p)
+        got = dc.download()
+        ref = O.prefilter(cloud, p)
+        g4 = np.stack([got["x"], got["y"], got["z"], got["intensity"]], axis=1)
+        assert g4.shape == ref.shape and np.array_equal(g4, ref), (seed, leaf)   # same centroids in the same (eviction) order
+        dc.close()
+    reg.close()
+
+
+@pytest.mark.gpu
+def test_hip_approx_voxelgrid_matches_oracle_in_order():
+    """Row a3 / f2: APPROX_VOXELGRID (scan_matching_odometry_nodelet.cpp:91-96, prefiltering_nodelet.cpp:59-63) on the device —
+    the sort-and-scan form reproduces the sequential filter's output INCLUDING its order and its repeated voxels."""
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    _check_approx_voxelgrid(lambda: RegistrationHIP(L.default_params(L.HGS_FAST_GICP)))

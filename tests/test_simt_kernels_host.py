@@ -472,3 +472,9 @@ def test_sharded_batch_entry_point_world_one():
     packing on the device, padding, scatter into candidate order, selection."""
     from test_distributed import _sharded_equals_unsharded
     _sharded_equals_unsharded(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
+
+
+def test_approx_voxelgrid_in_eviction_order():
+    """pcl::ApproximateVoxelGrid through the emulated k_pf_approx_* kernels: the oracle's sequential output, in order."""
+    from test_prefilter import _check_approx_voxelgrid
+    _check_approx_voxelgrid(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
