@@ -15,6 +15,7 @@
 #include <cstring>
 #include <exception>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -159,6 +160,10 @@ struct hgs_handle {
   // every cloud this engine has created and not yet destroyed: hgs_destroy orphans them (frees their device memory, clears
   // `owner`) so that a later hgs_cloud_destroy / hgs_cloud_download on a cached pointer is safe instead of a use-after-free
   std::vector<hgs_cloud*> live_clouds;
+  // One call at a time per engine: a handle is meant to be driven by one thread (like the pcl::Registration object it replaces), but a
+  // garbage-collected wrapper may destroy a cloud from another thread while a long call is running on this engine's stream and
+  // buffers — entry points that touch the engine take this lock (different engines never contend).
+  std::recursive_mutex api_mutex;
 
   bool profiling = false;
   std::vector<ProfEvent> prof_events;
@@ -710,7 +715,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   for (hgs_cloud* c : sources) total_q += c->n_input;
   (void)total_q;
   const int qpw = 64;  // measured: 16- or 32-query packets do not shorten a single registration's linearize (97 -> 90 us) and cost the batch
-  const int nn_tile = (kBlock / 64) * qpw;                       // points per block of k_gicp_linearize
+  const int nn_tile = (kBlock / 64) * qpw * kNW;                 // points per block of k_gicp_linearize / k_fitness (their own tiling formula)
   const int max_blocks = std::max(1, (max_n + nn_tile - 1) / nn_tile);  // >= the tile count of every kernel of the loop
   const CloudDesc* d_descs = nullptr;
   HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
@@ -832,7 +837,7 @@ int run_fitness(hgs_handle* h, const std::vector<hgs_cloud*>& sources, double ma
   int max_n = 0;
   for (hgs_cloud* c : sources) max_n = std::max(max_n, (int)c->n_input);
   const int qpw = 64;
-  const int nn_tile = (kBlock / 64) * qpw;
+  const int nn_tile = (kBlock / 64) * qpw * kNW;
   const int max_blocks = std::max(1, (max_n + nn_tile - 1) / nn_tile);
   const CloudDesc* d_descs = nullptr;
   HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
@@ -970,6 +975,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
 
 int hgs_destroy(hgs_handle* h) try {
   if (!h) return HGS_OK;
+  { std::lock_guard<std::recursive_mutex> wait_for_running_call(h->api_mutex); }  // a call still running on another thread finishes first
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (hipStream_t ls : h->lane_stream)
@@ -1013,6 +1019,8 @@ int hgs_destroy(hgs_handle* h) try {
 const char* hgs_last_error(const hgs_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, hgs_cloud** out) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   hgs_cloud* c = nullptr;
@@ -1055,6 +1063,8 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
 }
 
 int hgs_cloud_destroy(hgs_cloud* c) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (c && c->owner) api_lock__ = std::unique_lock<std::recursive_mutex>(c->owner->api_mutex);
   if (!c) return HGS_OK;
   hgs_handle* h = c->owner;
   if (h) {
@@ -1072,6 +1082,8 @@ int hgs_cloud_destroy(hgs_cloud* c) try {
 size_t hgs_cloud_size(const hgs_cloud* c) { return c ? c->n_input : 0; }
 
 int hgs_cloud_invalidate(hgs_cloud* c) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (c && c->owner) api_lock__ = std::unique_lock<std::recursive_mutex>(c->owner->api_mutex);
   if (!c) return HGS_ERR_INVALID_ARGUMENT;
   c->has_index = false, c->has_cov = false, c->has_ndt = false, c->has_vg = false;
   // also forget the correspondences of earlier registrations (they seed the next search): a truly cold cloud
@@ -1085,6 +1097,8 @@ int hgs_cloud_invalidate(hgs_cloud* c) try {
 }
 
 int hgs_set_target_cloud(hgs_handle* h, hgs_cloud* c) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !c || c->owner != h) return HGS_ERR_INVALID_ARGUMENT;  // clouds belong to the engine (stream) that created them
   if (h->own_target && h->target != c) cloud_free(h->target);
   h->target = c;
@@ -1094,6 +1108,8 @@ int hgs_set_target_cloud(hgs_handle* h, hgs_cloud* c) try {
   return status_of_current_exception(h);
 }
 int hgs_set_source_cloud(hgs_handle* h, hgs_cloud* c) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !c || c->owner != h) return HGS_ERR_INVALID_ARGUMENT;
   if (h->own_source && h->source != c) cloud_free(h->source);
   h->source = c;
@@ -1103,6 +1119,8 @@ int hgs_set_source_cloud(hgs_handle* h, hgs_cloud* c) try {
   return status_of_current_exception(h);
 }
 int hgs_set_target(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   hgs_cloud* c = nullptr;
   HGS_TRY(hgs_cloud_create(h, pts, n, stride_bytes, &c));
@@ -1117,6 +1135,8 @@ int hgs_set_target(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes
   return status_of_current_exception(h);
 }
 int hgs_set_source(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   hgs_cloud* c = nullptr;
   HGS_TRY(hgs_cloud_create(h, pts, n, stride_bytes, &c));
@@ -1132,6 +1152,8 @@ int hgs_set_source(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes
 }
 
 int hgs_align(hgs_handle* h, const float guess[16], hgs_result* out) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !guess || !out) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   if (!h->source) return HGS_ERR_NO_SOURCE;
@@ -1148,6 +1170,8 @@ int hgs_align(hgs_handle* h, const float guess[16], hgs_result* out) try {
 }
 
 int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t stride_bytes) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !T || !out_pts || stride_bytes < 12) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->source) return HGS_ERR_NO_SOURCE;
   HGS_TRY(set_device(h));
@@ -1174,6 +1198,8 @@ int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t
 }
 
 int hgs_fitness(hgs_handle* h, const float T[16], double max_range, double* score, uint32_t* num_inliers) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !T || !score) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   if (!h->source) return HGS_ERR_NO_SOURCE;
@@ -1191,6 +1217,8 @@ int hgs_fitness(hgs_handle* h, const float T[16], double max_range, double* scor
 }
 
 int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, const float relpose[16], double max_range, double* score) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !cloud1 || !cloud2 || cloud1->owner != h || cloud2->owner != h || !relpose || !score) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   hgs_cloud* saved_t = h->target;
@@ -1209,6 +1237,8 @@ int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, 
 }
 
 int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_bytes, int32_t* idx, float* d2) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || (nq > 0 && (!q_xyz || !idx || !d2)) || stride_bytes < 12) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   if (nq == 0) return HGS_OK;
@@ -1250,6 +1280,8 @@ int hgs_select_best(const hgs_result* records, size_t n, int32_t* best) try {
 
 int hgs_loop_match_batch(hgs_handle* h, hgs_cloud* const* candidates, size_t n_candidates, const float* guesses, double max_range, hgs_result* out,
                          int32_t* best) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || (n_candidates > 0 && (!candidates || !guesses || !out))) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   if (best) *best = -1;
@@ -1291,6 +1323,8 @@ int hgs_comm_get_unique_id(void* id_out) try {
 }
 
 int hgs_comm_init(hgs_handle* h, int32_t rank, int32_t world, const void* unique_id) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !unique_id || world < 1 || rank < 0 || rank >= world) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   if (h->comm) hgs::comm_destroy(h->comm), h->comm = nullptr;
@@ -1305,6 +1339,8 @@ int hgs_comm_init(hgs_handle* h, int32_t rank, int32_t world, const void* unique
 }
 
 int hgs_comm_finalize(hgs_handle* h) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   if (h->comm) {
     (void)hipSetDevice(h->device);
@@ -1319,6 +1355,8 @@ int hgs_comm_finalize(hgs_handle* h) try {
 
 int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, size_t n_mine, const int32_t* candidate_ids, const float* guesses,
                                  size_t n_total, double max_range, hgs_result* all_out, int32_t* best) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !all_out || n_total == 0 || n_total > (size_t)1 << 24 || (n_mine > 0 && (!candidates || !candidate_ids || !guesses))) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->comm) {
     h->err = "hgs_loop_match_batch_sharded: hgs_comm_init has not been called on this engine";
@@ -1438,6 +1476,8 @@ extern "C" int hgs_prefilter_params_default(hgs_prefilter_params* p) try {
 }
 
 extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, hgs_cloud** out) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !p || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
   if (p->downsample_method < HGS_DOWNSAMPLE_NONE || p->downsample_method > HGS_DOWNSAMPLE_APPROX_VOXELGRID || p->outlier_removal_method < HGS_OUTLIER_NONE ||
       p->outlier_removal_method > HGS_OUTLIER_RADIUS || (p->downsample_method != HGS_DOWNSAMPLE_NONE && !(p->downsample_resolution > 0)) ||
@@ -1589,6 +1629,8 @@ extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t st
 }
 
 extern "C" int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_bytes) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (c && c->owner) api_lock__ = std::unique_lock<std::recursive_mutex>(c->owner->api_mutex);
   if (!c || !c->owner || stride_bytes < 12 || (stride_bytes % 4) != 0 || (c->n_input > 0 && !out_pts)) return HGS_ERR_INVALID_ARGUMENT;
   hgs_handle* h = c->owner;
   HGS_TRY(set_device(h));
@@ -1613,6 +1655,8 @@ extern "C" int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_byt
 // ---- map cloud (src/hdl_graph_slam/map_cloud_generator.cpp:13-51) --------------------------------------------
 extern "C" int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes, const float* poses /* 16 * n, column-major */, size_t n_keyframes,
                                       double resolution, hgs_cloud** out) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !out || (n_keyframes > 0 && (!keyframes || !poses))) return HGS_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   size_t total = 0;
@@ -1705,6 +1749,8 @@ extern "C" int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes
 }
 
 int hgs_profile_enable(hgs_handle* h, int enabled) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   h->profiling = enabled != 0;
   return HGS_OK;
@@ -1713,6 +1759,8 @@ int hgs_profile_enable(hgs_handle* h, int enabled) try {
 }
 
 int hgs_profile_read(hgs_handle* h, double* ms, uint64_t* launches, int reset) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
@@ -1736,6 +1784,8 @@ int hgs_profile_read(hgs_handle* h, double* ms, uint64_t* launches, int reset) t
 }
 
 int hgs_synchronize(hgs_handle* h) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
@@ -1746,6 +1796,8 @@ int hgs_synchronize(hgs_handle* h) try {
 
 // ---- stage-level hooks for the parity tests ---------------------------------------------------------------
 int hgs_debug_target_covariances(hgs_handle* h, float* out6) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !out6) return HGS_ERR_INVALID_ARGUMENT;
   if (!h->target) return HGS_ERR_NO_TARGET;
   HGS_TRY(set_device(h));
@@ -1773,6 +1825,8 @@ int hgs_debug_target_covariances(hgs_handle* h, float* out6) try {
 }
 
 int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, double* b6, double* err, int32_t* corr) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !T12 || !H36 || !b6 || !err) return HGS_ERR_INVALID_ARGUMENT;
   if (h->prm.method != HGS_FAST_GICP && h->prm.method != HGS_FAST_VGICP) return HGS_ERR_UNSUPPORTED;
   if (!h->target) return HGS_ERR_NO_TARGET;
@@ -1833,6 +1887,8 @@ int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, d
 }
 
 int hgs_debug_ndt_cells(hgs_handle* h, int32_t cap, int32_t* ijk3, double* mean3, float* icov6, int32_t* npts, int32_t* n_cells) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !n_cells) return HGS_ERR_INVALID_ARGUMENT;
   if (h->prm.method != HGS_NDT_OMP) return HGS_ERR_UNSUPPORTED;
   if (!h->target) return HGS_ERR_NO_TARGET;
@@ -1870,6 +1926,8 @@ int hgs_debug_ndt_cells(hgs_handle* h, int32_t cap, int32_t* ijk3, double* mean3
 }
 
 int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, double* g6, double* H36) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !p6 || !score || !g6 || !H36) return HGS_ERR_INVALID_ARGUMENT;
   if (h->prm.method != HGS_NDT_OMP) return HGS_ERR_UNSUPPORTED;
   if (!h->target) return HGS_ERR_NO_TARGET;

@@ -948,8 +948,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
   // Guided self-scheduling: a grab takes (items left) / (2 * blocks) items, between 1 and `chunk` — long runs of one problem's
   // tiles while there is plenty of work (every change of problem costs a flush: ~170 atomics and a ticket round trip), single
   // tiles at the end of the pass (when the blocks must finish together).  "Items left" is judged from this block's last grab.
+  // The first run of every block is static (block x starts at item x * first_chunk): no atomic round trip in front of the
+  // first tile; the queue head counts from gridDim.x * first_chunk on.
   const int first_chunk = max(1, min(chunk, tile_base[B] / (2 * (int)gridDim.x)));
-  if (threadIdx.x == 0) S.out_of_range = 0, S.next = atomicAdd(queue, (unsigned long long)first_chunk), S.next_chunk = first_chunk;
+  const unsigned long long static_items = (unsigned long long)gridDim.x * (unsigned long long)first_chunk;
+  if (threadIdx.x == 0) S.out_of_range = 0, S.next = (unsigned long long)blockIdx.x * (unsigned long long)first_chunk, S.next_chunk = first_chunk;
   __syncthreads();
   const CloudMeta* m = tgt.meta;
   const int mnx = m->ndt_min_b[0], mny = m->ndt_min_b[1], mnz = m->ndt_min_b[2];
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
     const int my_chunk = S.next_chunk;
     const long long left = (long long)(end - w) - my_chunk;
     const int nxt_chunk = (int)max(1ll, min((long long)chunk, left / (2 * (long long)gridDim.x)));
-    if (threadIdx.x == 0) nxt = atomicAdd(queue, (unsigned long long)nxt_chunk);  // the next grab is in flight during this chunk
+    if (threadIdx.x == 0) nxt = static_items + atomicAdd(queue, (unsigned long long)nxt_chunk);  // the next grab is in flight during this chunk
     const unsigned long long lo = w < base ? base : w, hi = w + (unsigned long long)my_chunk < end ? w + (unsigned long long)my_chunk : end;
     for (unsigned long long it = lo; it < hi; it++) {
       const int item = (int)(it - base);

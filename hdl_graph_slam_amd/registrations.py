@@ -10,8 +10,10 @@ import sys
 from . import _lib as L
 from .registration import RegistrationHIP
 
-# engines the reference factory builds from third-party CPU libraries and that are NOT rebuilt here
-_CPU_ONLY = ("ICP", "GICP", "GICP_OMP", "NDT")
+# Engines the reference factory builds from third-party CPU libraries and that are NOT rebuilt here.  The
+# reference routes by substring (registrations.cpp:57-99): "ICP" exactly -> pcl::IterativeClosestPoint; any other name containing
+# "GICP" -> pcl / pclomp GeneralizedIterativeClosestPoint; everything else -> NDT, pclomp's if the name contains "OMP", PCL's
+# single-threaded pcl::NormalDistributionsTransform (another algorithm: KDTREE neighbourhoods, its own line search) otherwise.
 
 
 _REGULARIZATION = {"FROBENIUS": L.HGS_REG_FROBENIUS, "PLANE": L.HGS_REG_PLANE, "MIN_EIG": L.HGS_REG_MIN_EIG,
@@ -47,10 +49,17 @@ def params_from_rosparams(pnh) -> L.HgsParams:
         p.correspondence_randomness = int(get("reg_correspondence_randomness", 20))
         p.regularization_method = _regularization(pnh)
         return p
-    if method in _CPU_ONLY:
-        raise NotImplementedError(f"registration_method={method} stays on the reference's CPU engine (pcl / pclomp); "
-                                  "the MI355X backend implements FAST_GICP, FAST_VGICP and NDT_OMP")
-    if "NDT" not in method:                                                         # registrations.cpp:88-91
+    cpu_engine = None
+    if method == "ICP":                                                             # registrations.cpp:57-64
+        cpu_engine = "pcl::IterativeClosestPoint"
+    elif "GICP" in method:                                                          # registrations.cpp:65-87 (GICP, GICP_OMP, GICP_FOO, ...)
+        cpu_engine = "pclomp::GeneralizedIterativeClosestPoint" if "OMP" in method else "pcl::GeneralizedIterativeClosestPoint"
+    elif "OMP" not in method and method != "NDT_HIP":                               # registrations.cpp:94-100 (NDT, MY_NDT, typos, ...)
+        cpu_engine = "pcl::NormalDistributionsTransform"
+    if cpu_engine is not None:
+        raise NotImplementedError(f"registration_method={method}: the reference's factory builds {cpu_engine} for this name, a CPU engine this backend "
+                                  "does not replace (it implements FAST_GICP, FAST_VGICP and NDT_OMP); running the device NDT_OMP instead would change the result silently")
+    if "NDT" not in method:                                                         # registrations.cpp:88-91 (then "... _OMP": pclomp's NDT)
         print(f"warning: unknown registration type({method})\n       : use NDT", file=sys.stderr)
     p = L.default_params(L.HGS_NDT_OMP)                                             # registrations.cpp:93,101-120
     p.resolution = float(get("reg_resolution", 0.5))

@@ -66,10 +66,14 @@ def test_rosparam_mapping_follows_registrations_cpp(L):
     assert params_from_rosparams({"registration_method": "FAST_VGICP", "reg_regularization_method": "plane"}).regularization_method == L.HGS_REG_PLANE
     with pytest.raises(ValueError):
         params_from_rosparams({"registration_method": "FAST_GICP", "reg_regularization_method": "bogus"})
-    p = params_from_rosparams({"registration_method": "bogus"})      # unknown -> NDT with a warning (registrations.cpp:88-91)
-    assert p.method == L.HGS_NDT_OMP
-    with pytest.raises(NotImplementedError):
-        params_from_rosparams({"registration_method": "GICP_OMP"})
+    # the reference routes by substring (registrations.cpp:57-99): anything with "OMP" that is not a GICP is pclomp's NDT (with the
+    # "unknown registration type" warning when the name has no "NDT" in it) ...
+    assert params_from_rosparams({"registration_method": "bogus_OMP"}).method == L.HGS_NDT_OMP
+    assert params_from_rosparams({"registration_method": "NDT_HIP"}).method == L.HGS_NDT_OMP
+    # ... and every other name selects a CPU engine this backend does not replace: refuse instead of silently running another algorithm
+    for name in ("GICP_OMP", "GICP", "GICP_FOO", "ICP", "NDT", "MY_NDT", "bogus"):
+        with pytest.raises(NotImplementedError):
+            params_from_rosparams({"registration_method": name})
     # stale un-prefixed keys of launch/hdl_graph_slam_imu.launch:70-77 are ignored -> factory defaults
     p = params_from_rosparams({"registration_method": "NDT_OMP", "ndt_resolution": 2.0, "transformation_epsilon": 0.5})
     assert (p.resolution, p.transformation_epsilon) == (0.5, 0.01)

@@ -175,3 +175,40 @@ def test_loop_batch_one_rank_share_of_512():
         assert dt < 1e-5 and dr < 1e-5 and rec["iterations"][i] == ro.iterations
         assert abs(rec["fitness_score"][i] - o.getFitnessScore(1.0, T=a)) <= 1e-9 * rec["fitness_score"][i]   # at the device's pose
     e.close()
+
+
+def test_loop_batch_all_512_candidates_on_one_gpu():
+    """Config 4 at its full size on ONE GPU: 1 query keyframe x 512 HDL-32E candidate keyframes (~3 GB resident) in a single
+    hgs_loop_match_batch.  The 512 records equal, bit for bit, the union of the eight 64-candidate shards of the 8-GPU partition
+    (candidate c -> rank c mod 8) run one after the other, the selected candidate is the sequential rule's over all 512, and
+    sampled candidates agree with the oracle."""
+    from hdl_graph_slam_amd import workloads
+    from hdl_graph_slam_amd.distributed import owner_of
+    from hdl_graph_slam_amd.registration import select_best
+    n = 512
+    wl = workloads.make_loop_closure_set("HDL-32E", 12, n_candidates=n, n_distinct=4)
+    p = O.default_params(O.HGS_FAST_GICP)
+    e = _hip(p)
+    e.setInputTarget(wl.target)
+    clouds = [e.upload(c) for c in wl.candidates]
+    rec, best = e.loop_match_batch(clouds, wl.guesses, 4.0)
+    assert len(rec) == n and best == select_best(rec) and rec["converged"].sum() >= 0.85 * n
+    merged = rec.copy()
+    merged["fitness_score"] = -1.0
+    for rank in range(8):
+        mine = [i for i in range(n) if owner_of(i, 8) == rank]
+        part, _ = e.loop_match_batch([clouds[i] for i in mine], [wl.guesses[i] for i in mine], 4.0)
+        for name in ("final_transformation", "fitness_score", "converged", "iterations", "num_inliers"):
+            merged[name][mine] = part[name]
+    for name in ("final_transformation", "fitness_score", "converged", "iterations", "num_inliers"):
+        assert np.array_equal(merged[name], rec[name]), name
+    o = O.OracleRegistration(p)
+    o.setInputTarget(wl.target)
+    for i in (0, 255, 511, int(best)):
+        o.setInputSource(wl.candidates[i])
+        ro = o.align(wl.guesses[i])
+        a = rec["final_transformation"][i].reshape(4, 4).T.astype(np.float64)
+        dt, dr = synth.pose_error(a, ro.matrix())
+        assert dt < 1e-5 and dr < 1e-5 and rec["iterations"][i] == ro.iterations
+        assert abs(rec["fitness_score"][i] - o.getFitnessScore(4.0, T=a)) <= 1e-9 * rec["fitness_score"][i]
+    e.close()

@@ -94,17 +94,19 @@ def test_hip_stream_follows_the_oracle_stream(method):
 
 
 @pytest.mark.gpu
-def test_hip_stream_with_device_voxelgrid_downsample():
-    """Row a3: the nodelet's VOXELGRID downsample on the device (resident result registered in place) gives the same
-    odometry as downsampling with the oracle's pcl::VoxelGrid restatement on the host and uploading the result."""
+@pytest.mark.parametrize("filter_name,method_id", [("VOXELGRID", 1), ("APPROX_VOXELGRID", 2)])
+def test_hip_stream_with_device_voxelgrid_downsample(filter_name, method_id):
+    """Row a3: the nodelet's VOXELGRID / APPROX_VOXELGRID downsample on the device (resident result registered in place) gives the
+    same odometry as downsampling with the oracle's pcl::VoxelGrid / pcl::ApproximateVoxelGrid restatement on the host and
+    uploading the result."""
     from hdl_graph_slam_amd.odometry import make_downsample
     from hdl_graph_slam_amd.registrations import select_registration_method
     stream = workloads.make_odometry_stream("VLP-16", scene_seed=1, n_scans=4, speed=4.0)
     kf = dict(keyframe_delta_trans=0.5, keyframe_delta_angle=0.15, keyframe_delta_time=1e9)
     reg = select_registration_method({"registration_method": "FAST_GICP"}, device_id=0)
-    a = ScanMatchingOdometry(reg, downsample=make_downsample(reg, "VOXELGRID", 0.25), **kf)
+    a = ScanMatchingOdometry(reg, downsample=make_downsample(reg, filter_name, 0.25), **kf)
     pf = O.default_prefilter_params()
-    pf.use_distance_filter, pf.outlier_removal_method, pf.downsample_resolution = 0, 0, 0.25
+    pf.use_distance_filter, pf.outlier_removal_method, pf.downsample_resolution, pf.downsample_method = 0, 0, 0.25, method_id
     reg2 = select_registration_method({"registration_method": "FAST_GICP"}, device_id=0)
     b = ScanMatchingOdometry(reg2, downsample=lambda c: synth.to_xyzi(O.prefilter(c, pf)[:, :3]), **kf)
     for t, c in zip(stream.stamps, stream.scans):
