@@ -187,3 +187,33 @@ def tie_heavy_cloud(seed: int = 0) -> np.ndarray:
     rnd = rng.normal(0, 6, (3000, 3)).astype(np.float32)
     out = np.concatenate([single, double, double, lat, lat, lat, lines.astype(np.float32), rnd])
     return synth.to_xyzi(out[rng.permutation(len(out))])
+
+
+def check_ndt_edge_cases(make_engine):
+    """NDT inputs the nodelets can produce at the borders: an empty source, a source that meets no target cell at all, a target
+    without a single valid cell (fewer than 6 points per voxel everywhere), non-finite points, and a one-point source.  The
+    engine must terminate, agree with the oracle's exact-sum mode on convergence flag, iteration count and pose, and survive."""
+    tgt, src, T = synth.make_pair("VLP-16", 1, downsample=0.4)
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution = 1.0
+    far = src.copy()
+    far["x"] += 500.0                                   # outside the target's voxel grid: no point meets a cell
+    sparse_tgt = tgt[::60]                              # ~70 points over 100 m: no voxel reaches 6 points
+    with_nan = src.copy()
+    with_nan["x"][::7] = np.nan
+    with_nan["z"][3::11] = np.inf
+    cases = [("empty source", tgt, src[:0], np.eye(4)), ("source outside the grid", tgt, far, np.eye(4)), ("target without valid cells", sparse_tgt, src, T),
+             ("non-finite source points", tgt, with_nan, T), ("one-point source", tgt, src[100:101], T), ("non-finite target points", with_nan, src, np.eye(4))]
+    e = make_engine(p)
+    for name, t, s, guess in cases:
+        o = make_oracle(p).set_ndt_sum_mode(1)
+        for r in (e, o):
+            r.setInputTarget(t)
+            r.setInputSource(s)
+        re, ro = e.align(guess), o.align(guess)
+        assert bool(re.converged) == bool(ro.converged) and re.iterations == ro.iterations, (name, re.converged, ro.converged, re.iterations, ro.iterations)
+        a, b = re.matrix(), ro.matrix()
+        assert np.array_equal(np.isnan(a), np.isnan(b)), name
+        if not np.isnan(b).any():
+            assert bytes(re.final_transformation) == bytes(ro.final_transformation), (name, synth.pose_error(a, b))
+    e.close()

@@ -310,3 +310,8 @@ def test_clouds_outlive_their_engine_safely(gicp_case):
         e.setInputSource(c)                       # another engine rejects it as well
     c.close()                                     # ... and destroying it afterwards is fine
     e.setInputSource(src)
+
+
+def test_ndt_edge_cases():
+    """Empty / out-of-grid / cell-less / non-finite / one-point NDT inputs: same flags, counts and pose as the oracle."""
+    PC.check_ndt_edge_cases(_hip)

@@ -478,3 +478,7 @@ def test_approx_voxelgrid_in_eviction_order():
     """pcl::ApproximateVoxelGrid through the emulated k_pf_approx_* kernels: the oracle's sequential output, in order."""
     from test_prefilter import _check_approx_voxelgrid
     _check_approx_voxelgrid(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
+
+
+def test_ndt_edge_cases():
+    PC.check_ndt_edge_cases(_engine)
