@@ -80,50 +80,79 @@ HGS_HD Sym3 gicp_mahalanobis(const double* R /*3x3 row-major*/, const Sym3& ca, 
   return sym3_inverse(rcr);
 }
 
-// residual e = b - T a, returns e^T M e; optionally adds J^T M J, J^T M e (J = [skew(Ta) | -I]) to acc[28]
+// One correspondence's contribution to the normal equations, in pieces (J = [skew(Ta) | -I], e = b - T a):
+//   gicp_point_residual : T a, M e, e^T M e
+//   gicp_terms_b        : J^T M e and the error        -> acc[21..27]
+//   gicp_terms_tt       : the translation block M      -> acc[15..20]
+//   gicp_terms_rt       : the rotation-translation block -> acc[3,4,5, 8,9,10, 12,13,14]
+//   gicp_terms_rr       : the rotation block (upper triangle) -> acc[0,1,2, 6,7, 11]
+// k_gicp_linearize reduces them over the wave piece by piece (only one piece's values are live at a time); gicp_point_terms
+// below adds all of them to acc[28] with the same arithmetic.
+struct GicpPointResidual {
+  double x, y, z;        // T a
+  double mex, mey, mez;  // M e
+  double err;            // e^T M e
+};
+HGS_HD GicpPointResidual gicp_point_residual(const Pose& T, const Sym3& M, float ax, float ay, float az, double bx, double by, double bz) {
+  GicpPointResidual r;
+  r.x = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];
+  r.y = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
+  r.z = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
+  const double ex = bx - r.x, ey = by - r.y, ez = bz - r.z;
+  r.mex = M.xx * ex + M.xy * ey + M.xz * ez;
+  r.mey = M.xy * ex + M.yy * ey + M.yz * ez;
+  r.mez = M.xz * ex + M.yz * ey + M.zz * ez;
+  r.err = ex * r.mex + ey * r.mey + ez * r.mez;
+  return r;
+}
+// b = J^T M e = [ S^T Me ; -Me ], then the error
+HGS_HD void gicp_terms_b(const GicpPointResidual& r, double* o /*[7]*/) {
+  o[0] = r.z * r.mey - r.y * r.mez;
+  o[1] = -r.z * r.mex + r.x * r.mez;
+  o[2] = r.y * r.mex - r.x * r.mey;
+  o[3] = -r.mex, o[4] = -r.mey, o[5] = -r.mez;
+  o[6] = r.err;
+}
+HGS_HD void gicp_terms_tt(const Sym3& M, double* o /*[6]*/) { o[0] = M.xx, o[1] = M.xy, o[2] = M.xz, o[3] = M.yy, o[4] = M.yz, o[5] = M.zz; }
+// H_rt = -S^T M, S = skew(Ta): (S^T X)[0][j] = z X[1][j] - y X[2][j]; [1][j] = -z X[0][j] + x X[2][j]; [2][j] = y X[0][j] - x X[1][j]
+HGS_HD void gicp_terms_rt(const GicpPointResidual& r, const Sym3& M, double* o /*[9] row-major*/) {
+  const double x = r.x, y = r.y, z = r.z;
+  const double Mr[3][3] = {{M.xx, M.xy, M.xz}, {M.xy, M.yy, M.yz}, {M.xz, M.yz, M.zz}};
+  for (int j = 0; j < 3; j++) {
+    o[0 + j] = -(z * Mr[1][j] - y * Mr[2][j]);
+    o[3 + j] = -(-z * Mr[0][j] + x * Mr[2][j]);
+    o[6 + j] = -(y * Mr[0][j] - x * Mr[1][j]);
+  }
+}
+// H_rr = S^T (M S), upper triangle (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+HGS_HD void gicp_terms_rr(const GicpPointResidual& r, const Sym3& M, double* o /*[6]*/) {
+  const double x = r.x, y = r.y, z = r.z;
+  const double Mr[3][3] = {{M.xx, M.xy, M.xz}, {M.xy, M.yy, M.yz}, {M.xz, M.yz, M.zz}};
+  double A[3][3];  // A = M S: S[:,0]=(0,z,-y) S[:,1]=(-z,0,x) S[:,2]=(y,-x,0)
+  for (int q = 0; q < 3; q++) {
+    A[q][0] = Mr[q][1] * z - Mr[q][2] * y;
+    A[q][1] = -Mr[q][0] * z + Mr[q][2] * x;
+    A[q][2] = Mr[q][0] * y - Mr[q][1] * x;
+  }
+  o[0] = z * A[1][0] - y * A[2][0], o[1] = z * A[1][1] - y * A[2][1], o[2] = z * A[1][2] - y * A[2][2];
+  o[3] = -z * A[0][1] + x * A[2][1], o[4] = -z * A[0][2] + x * A[2][2];
+  o[5] = y * A[0][2] - x * A[1][2];
+}
+
+// residual e = b - T a, returns e^T M e; optionally adds J^T M J, J^T M e to acc[28] (upper triangle row-major, b, -)
 template <bool WITH_JACOBIAN>
 HGS_HD double gicp_point_terms(const Pose& T, const Sym3& M, float ax, float ay, float az, double bx, double by, double bz, double* acc) {
-  const double x = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];
-  const double y = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
-  const double z = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
-  const double ex = bx - x, ey = by - y, ez = bz - z;
-  const double mex = M.xx * ex + M.xy * ey + M.xz * ez;
-  const double mey = M.xy * ex + M.yy * ey + M.yz * ez;
-  const double mez = M.xz * ex + M.yz * ey + M.zz * ez;
-  const double err = ex * mex + ey * mey + ez * mez;
+  const GicpPointResidual r = gicp_point_residual(T, M, ax, ay, az, bx, by, bz);
   if (WITH_JACOBIAN) {
-    // A = M S, S = skew(ta): S[:,0]=(0,z,-y) S[:,1]=(-z,0,x) S[:,2]=(y,-x,0)
-    const double Mr[3][3] = {{M.xx, M.xy, M.xz}, {M.xy, M.yy, M.yz}, {M.xz, M.yz, M.zz}};
-    double A[3][3];
-    for (int r = 0; r < 3; r++) {
-      A[r][0] = Mr[r][1] * z - Mr[r][2] * y;
-      A[r][1] = -Mr[r][0] * z + Mr[r][2] * x;
-      A[r][2] = Mr[r][0] * y - Mr[r][1] * x;
-    }
-    // H_rr = S^T A ; (S^T X)[0][j] = z X[1][j] - y X[2][j]; [1][j] = -z X[0][j] + x X[2][j]; [2][j] = y X[0][j] - x X[1][j]
-    double Hrr[3][3], Hrt[3][3];
-    for (int j = 0; j < 3; j++) {
-      Hrr[0][j] = z * A[1][j] - y * A[2][j];
-      Hrr[1][j] = -z * A[0][j] + x * A[2][j];
-      Hrr[2][j] = y * A[0][j] - x * A[1][j];
-      Hrt[0][j] = -(z * Mr[1][j] - y * Mr[2][j]);
-      Hrt[1][j] = -(-z * Mr[0][j] + x * Mr[2][j]);
-      Hrt[2][j] = -(y * Mr[0][j] - x * Mr[1][j]);
-    }
-    // upper triangle, row-major: row0: (0,0..5) row1: (1,1..5) ...
-    acc[0] += Hrr[0][0], acc[1] += Hrr[0][1], acc[2] += Hrr[0][2], acc[3] += Hrt[0][0], acc[4] += Hrt[0][1], acc[5] += Hrt[0][2];
-    acc[6] += Hrr[1][1], acc[7] += Hrr[1][2], acc[8] += Hrt[1][0], acc[9] += Hrt[1][1], acc[10] += Hrt[1][2];
-    acc[11] += Hrr[2][2], acc[12] += Hrt[2][0], acc[13] += Hrt[2][1], acc[14] += Hrt[2][2];
-    acc[15] += M.xx, acc[16] += M.xy, acc[17] += M.xz;
-    acc[18] += M.yy, acc[19] += M.yz;
-    acc[20] += M.zz;
-    // b = J^T M e = [ S^T Me ; -Me ]
-    acc[21] += z * mey - y * mez;
-    acc[22] += -z * mex + x * mez;
-    acc[23] += y * mex - x * mey;
-    acc[24] -= mex, acc[25] -= mey, acc[26] -= mez;
+    double rr[6], rt[9], tt[6], bb[7];
+    gicp_terms_rr(r, M, rr), gicp_terms_rt(r, M, rt), gicp_terms_tt(M, tt), gicp_terms_b(r, bb);
+    acc[0] += rr[0], acc[1] += rr[1], acc[2] += rr[2], acc[3] += rt[0], acc[4] += rt[1], acc[5] += rt[2];
+    acc[6] += rr[3], acc[7] += rr[4], acc[8] += rt[3], acc[9] += rt[4], acc[10] += rt[5];
+    acc[11] += rr[5], acc[12] += rt[6], acc[13] += rt[7], acc[14] += rt[8];
+    for (int k = 0; k < 6; k++) acc[15 + k] += tt[k];
+    for (int k = 0; k < 6; k++) acc[21 + k] += bb[k];
   }
-  return err;
+  return r.err;
 }
 
 HGS_HD Sym3 sym3_from_floats(float xx, float xy, float xz, float yy, float yz, float zz) {

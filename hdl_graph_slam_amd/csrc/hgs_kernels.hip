@@ -25,6 +25,8 @@ namespace hgs {
 #ifndef HGS_OPAQUE_POINTER  // (the host emulation of tests/emul supplies its own spelling of these two)
 #define HGS_OPAQUE_POINTER(p) asm volatile("" : "+v"(p))
 #define HGS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// lane id recomputed where it is needed (2 VALU) instead of kept in a register across a long search: not CSE'd with an earlier one
+#define HGS_LANE_ID(dst) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(dst))
 #endif
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
@@ -63,6 +65,16 @@ __device__ __forceinline__ void progress_tick(Progress p, bool finished_now) {
 
 // Sum N per-thread doubles over a 256-thread block in a fixed order; thread k < N stores result k.
 template <int N>
+__device__ __forceinline__ void block_reduce_store(const double* acc, double* out, double* lds /* [4*N] */, int lane, int wave) {
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) lds[wave * N + k] = v;
+  }
+  __syncthreads();
+  if (wave == 0 && lane < N) out[lane] = (lds[lane] + lds[N + lane]) + (lds[2 * N + lane] + lds[3 * N + lane]);
+}
+template <int N>
 __device__ __forceinline__ void block_reduce_store(const double* acc, double* out, double* lds /* [4*N] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -72,6 +84,16 @@ __device__ __forceinline__ void block_reduce_store(const double* acc, double* ou
   }
   __syncthreads();
   if (threadIdx.x < N) out[threadIdx.x] = (lds[threadIdx.x] + lds[N + threadIdx.x]) + (lds[2 * N + threadIdx.x] + lds[3 * N + threadIdx.x]);
+}
+
+// N per-lane doubles summed over the wave; lane 0 stores sum k at row[slot[k]].
+template <int N>
+__device__ __forceinline__ void wave_sums_to(const double (&v)[N], const int (&slot)[N], double* row, int lane) {
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const double s = wave_sum(v[k]);
+    if (lane == 0) row[slot[k]] = s;
+  }
 }
 
 // Second reduction stage: out[k] = sum over tiles of p[tile*N + k], k < N, for a 256-thread block.
@@ -448,9 +470,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7))) voi
   const int tile = xcd_tile(blockIdx.x, ntiles);
   __shared__ double lds[4 * kAcc];
   __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][kNW * 32];
-  double acc[kAcc];
-#pragma unroll
-  for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+  // the wave's index lives in an SGPR and the lane id is recomputed after the search: nothing about the thread's identity is
+  // kept in (or spilled from) a VGPR across the walk — the kernel runs at 72 VGPRs for 7 waves per SIMD without scratch
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const Pose T = states[b].x0;
   float Tf[12];
   pose_to_float(T, Tf);
@@ -462,29 +484,62 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7))) voi
   float d2[kNW];
 #pragma unroll
   for (int w = 0; w < kNW; w++) {
-    idx[w] = tile * tile_pts + (int)(threadIdx.x >> 6) * (qpw * kNW) + w * qpw + (int)(threadIdx.x & 63);
+    idx[w] = tile * tile_pts + wave * (qpw * kNW) + w * qpw + (int)(threadIdx.x & 63);
     active[w] = (int)(threadIdx.x & 63) < qpw && idx[w] < n;
     a[w] = active[w] ? load_stream(d.pts + idx[w]) : make_float4(0.f, 0.f, 0.f, 0.f);
     q[w] = transform_point_f(Tf, a[w].x, a[w].y, a[w].z);
     // seed: the correspondence of the previous linearisation (or of an earlier align; -1 / stale values are harmless)
     seed[w] = active[w] ? __builtin_nontemporal_load(d.corr + idx[w]) : -1;
   }
-  wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, c.search_bound2, seed, d2, j, orig, qpw);
+  wave_nn1<kNW>(view_of(tgt), walk_slots[wave], q, active, c.search_bound2, seed, d2, j, orig, qpw);
   const double R[9] = {T.m[0], T.m[1], T.m[2], T.m[4], T.m[5], T.m[6], T.m[8], T.m[9], T.m[10]};
-#pragma unroll
-  for (int w = 0; w < kNW; w++) {
-    if (active[w]) {
-      int jj = j[w];
-      if (jj >= 0 && !((double)d2[w] < c.max_corr2)) jj = -1;
-      __builtin_nontemporal_store(jj, d.corr + idx[w]);
-      if (jj >= 0) {
-        const Sym3 M = gicp_mahalanobis(R, load_cov_stream(d.cov, idx[w]), load_cov(tgt.cov, jj));
-        const float4 bp = tgt.pts[jj];
-        acc[27] += gicp_point_terms<true>(T, M, a[w].x, a[w].y, a[w].z, bp.x, bp.y, bp.z, acc);
-      }
-    }
+  static_assert(kNW == 1, "the staged reduction below is written for one packet per wave");
+  int jj = active[0] ? j[0] : -1;
+  if (jj >= 0 && !((double)d2[0] < c.max_corr2)) jj = -1;
+  if (active[0]) __builtin_nontemporal_store(jj, d.corr + idx[0]);
+  // a lane without a correspondence carries M = 0, T a = 0: every term below is then an exact zero
+  Sym3 M = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  GicpPointResidual r = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (jj >= 0) {
+    M = gicp_mahalanobis(R, load_cov_stream(d.cov, idx[0]), load_cov(tgt.cov, jj));
+    const float4 bp = tgt.pts[jj];
+    r = gicp_point_residual(T, M, a[0].x, a[0].y, a[0].z, bp.x, bp.y, bp.z);
   }
-  block_reduce_store<kAcc>(acc, partials + ((size_t)b * max_blocks + tile) * kAcc, lds);
+  // The 28 sums of the wave, one block of the normal equations at a time: only that block's terms are live while it is
+  // reduced (all 28 at once need more registers than the 72 the search runs at, and spilled — 12 bytes of scratch per thread).
+  int lane;
+  HGS_LANE_ID(lane);
+  double* row = lds + wave * kAcc;
+  {
+    double v[7];
+    gicp_terms_b(r, v);
+    const int slot[7] = {21, 22, 23, 24, 25, 26, 27};
+    wave_sums_to<7>(v, slot, row, lane);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    double v[6];
+    gicp_terms_tt(M, v);
+    const int slot[6] = {15, 16, 17, 18, 19, 20};
+    wave_sums_to<6>(v, slot, row, lane);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    double v[9];
+    gicp_terms_rt(r, M, v);
+    const int slot[9] = {3, 4, 5, 8, 9, 10, 12, 13, 14};
+    wave_sums_to<9>(v, slot, row, lane);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    double v[6];
+    gicp_terms_rr(r, M, v);
+    const int slot[6] = {0, 1, 2, 6, 7, 11};
+    wave_sums_to<6>(v, slot, row, lane);
+  }
+  __syncthreads();
+  double* out = partials + ((size_t)b * max_blocks + tile) * kAcc;
+  if (wave == 0 && lane < kAcc) out[lane] = (lds[lane] + lds[kAcc + lane]) + (lds[2 * kAcc + lane] + lds[3 * kAcc + lane]);
 }
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
                            int max_blocks, int B, int qpw) {

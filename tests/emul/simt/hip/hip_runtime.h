@@ -14,6 +14,8 @@
 #define HGS_SIMT_EMULATION 1
 #define HGS_OPAQUE_POINTER(p) asm volatile("" : "+r"(p))
 #define HGS_WAIT_VMEM() ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define HGS_LANE_ID(dst) ((dst) = (int)(threadIdx.x & 63))
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 

@@ -296,8 +296,9 @@ def test_gpu_suite_odometry_stream(method):
     _gpu_test("test_odometry", "test_hip_stream_follows_the_oracle_stream")(method)
 
 
-def test_gpu_suite_odometry_device_downsample():
-    _gpu_test("test_odometry", "test_hip_stream_with_device_voxelgrid_downsample")()
+@pytest.mark.parametrize("filter_name,method_id", [("VOXELGRID", 1), ("APPROX_VOXELGRID", 2)])
+def test_gpu_suite_odometry_device_downsample(filter_name, method_id):
+    _gpu_test("test_odometry", "test_hip_stream_with_device_voxelgrid_downsample")(filter_name, method_id)
 
 
 def test_gpu_suite_information_matrix_fitness():
