@@ -76,7 +76,7 @@ EXPORTS = [
     "hgs_align", "hgs_transform_source", "hgs_fitness", "hgs_nn_target",
     "hgs_loop_match_batch", "hgs_select_best", "hgs_calc_fitness_score",
     "hgs_comm_get_unique_id", "hgs_comm_init", "hgs_comm_finalize", "hgs_loop_match_batch_sharded",
-    "hgs_prefilter_params_default", "hgs_prefilter", "hgs_cloud_download", "hgs_map_cloud_generate",
+    "hgs_prefilter_params_default", "hgs_prefilter", "hgs_prefilter_deskewed", "hgs_cloud_download", "hgs_map_cloud_generate",
     "hgs_profile_enable", "hgs_profile_read", "hgs_synchronize",
     "hgs_debug_target_covariances", "hgs_debug_gicp_linearize", "hgs_debug_ndt_cells", "hgs_debug_ndt_derivatives",
 ]
@@ -120,6 +120,7 @@ def lib():
     L.hgs_calc_fitness_score.argtypes = [vp, vp, vp, fp, C.c_double, C.POINTER(C.c_double)]
     L.hgs_prefilter_params_default.argtypes = [C.POINTER(HgsPrefilterParams)]
     L.hgs_prefilter.argtypes = [vp, vp, sz, sz, C.POINTER(HgsPrefilterParams), C.POINTER(vp)]
+    L.hgs_prefilter_deskewed.argtypes = [vp, vp, sz, sz, C.POINTER(HgsPrefilterParams), vp, C.c_double, C.POINTER(vp)]
     L.hgs_cloud_download.argtypes = [vp, vp, sz]
     L.hgs_map_cloud_generate.argtypes = [vp, C.POINTER(vp), vp, sz, C.c_double, C.POINTER(vp)]
     L.hgs_profile_enable.argtypes = [vp, C.c_int]

@@ -155,7 +155,7 @@ void launch_map_centers(hipStream_t s, const float4* pts, const unsigned long lo
                         const int* meta, float4* out, int* count_out);
 
 // prefilter (apps/prefiltering_nodelet.cpp)
-void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out);
+void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out, const float* deskew_w /* -(gyro rate), or null */, double scan_period);
 void launch_pf_distance_flags(hipStream_t s, const float4* pts, int n, int use_filter, double near_thresh, double far_thresh, unsigned* keep);
 void launch_pf_compact(hipStream_t s, const float4* in, int n, const unsigned* keep, const unsigned* slot, float4* out, int* count);
 void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta);

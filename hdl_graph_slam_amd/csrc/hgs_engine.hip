@@ -1475,7 +1475,8 @@ extern "C" int hgs_prefilter_params_default(hgs_prefilter_params* p) try {
   return status_of_current_exception(nullptr);
 }
 
-extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, hgs_cloud** out) try {
+static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, const float* deskew_w, double scan_period,
+                          hgs_cloud** out) {
   std::unique_lock<std::recursive_mutex> api_lock__;
   if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !p || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
@@ -1502,7 +1503,7 @@ extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t st
   double* d_stats = reinterpret_cast<double*>(h->pf_small.as<char>() + 192);
   if (n > 0) {
     HGS_HIP(h, hipMemcpyAsync(h->staging.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream));
-    launch_pf_load(h->stream, h->staging.p, stride_bytes, (int)n, cur);
+    launch_pf_load(h->stream, h->staging.p, stride_bytes, (int)n, cur, deskew_w, scan_period);
   }
   int host_n = (int)n;
   HGS_HIP(h, hipMemcpyAsync(d_count, &host_n, sizeof(int), hipMemcpyHostToDevice, h->stream));  // (pageable 4-byte copy: staged by the runtime)
@@ -1624,6 +1625,21 @@ extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t st
   }
   *out = c;
   return HGS_OK;
+}
+
+extern "C" int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, hgs_cloud** out) try {
+  return prefilter_impl(h, pts, n, stride_bytes, p, nullptr, 0.0, out);
+} catch (...) {
+  return status_of_current_exception(h);
+}
+
+extern "C" int hgs_prefilter_deskewed(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, const double* imu_angular_velocity,
+                                      double scan_period, hgs_cloud** out) try {
+  if (!imu_angular_velocity) return prefilter_impl(h, pts, n, stride_bytes, p, nullptr, 0.0, out);  // empty imu_queue: the cloud passes as it is (:184-186)
+  if (!std::isfinite(scan_period)) return HGS_ERR_INVALID_ARGUMENT;
+  // ang_v(x, y, z) as floats, times -1 (:219-220)
+  const float w[3] = {-(float)imu_angular_velocity[0], -(float)imu_angular_velocity[1], -(float)imu_angular_velocity[2]};
+  return prefilter_impl(h, pts, n, stride_bytes, p, w, scan_period, out);
 } catch (...) {
   return status_of_current_exception(h);
 }

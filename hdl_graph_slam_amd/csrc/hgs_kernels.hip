@@ -1344,14 +1344,21 @@ void launch_vgicp_error(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt
 // Working format: float4 {x, y, z, intensity}.  Every stage writes keep-flags; a rocPRIM exclusive scan turns them into
 // output slots (order preserving, hence deterministic); the voxel grid reuses the sort-by-cell + segment-head scheme
 // of the NDT / VGICP targets with FLOAT centroids accumulated in input order (CentroidPoint semantics).
-__global__ __launch_bounds__(kBlock) void k_pf_load(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ out) {
+// deskew != 0: the deskewing step of cloud_callback (:112, :182-243) on the way in — point i of the sweep rotated back by the
+// first-order rotation of delta_t = scan_period * i / n at the gyro rate w (pf_deskew_point, hgs_math.h).
+__global__ __launch_bounds__(kBlock) void k_pf_load(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ out, int deskew, float wx, float wy,
+                                                    float wz, double scan_period) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float* f = reinterpret_cast<const float*>(staging + (size_t)i * stride);
-  out[i] = make_float4(f[0], f[1], f[2], stride >= 20 ? f[4] : 0.f);
+  float x = f[0], y = f[1], z = f[2];
+  if (deskew) pf_deskew_point(wx, wy, wz, scan_period, i, n, &x, &y, &z);
+  out[i] = make_float4(x, y, z, stride >= 20 ? f[4] : 0.f);
 }
-void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out) {
-  if (n > 0) hipLaunchKernelGGL(k_pf_load, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const char*)staging, stride, n, out);
+void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out, const float* deskew_w, double scan_period) {
+  if (n > 0)
+    hipLaunchKernelGGL(k_pf_load, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const char*)staging, stride, n, out, deskew_w ? 1 : 0, deskew_w ? deskew_w[0] : 0.f,
+                       deskew_w ? deskew_w[1] : 0.f, deskew_w ? deskew_w[2] : 0.f, scan_period);
 }
 
 // keep[i] = near < |p| < far  (float norm against double thresholds, :170-173); use_filter == 0 keeps everything

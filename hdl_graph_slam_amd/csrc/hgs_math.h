@@ -307,6 +307,25 @@ HGS_HD void solve_svd6(const double* A, const double* b, double* x) {
   svd6_backsolve<const double*>(U, V, b, x);
 }
 
+// ---- deskewing of one sweep point (apps/prefiltering_nodelet.cpp:229-239) ---------------------------------------------
+// p' = delta_q.inverse() * p with delta_q = (1, delta_t/2 * w), delta_t = scan_period * i / n and w = -(gyro rate) as floats:
+// Eigen's float arithmetic restated (inverse = conjugate / squaredNorm, the (x^2 + z^2) + (y^2 + w^2) reduction;
+// q * v = v + w * uv + q.vec x uv with uv = 2 q.vec x v), unfused.
+HGS_HD void pf_deskew_point(float wx, float wy, float wz, double scan_period, int i, int n, float* x, float* y, float* z) {
+  HGS_FP_STRICT
+  const double delta_t = scan_period * (double)i / (double)n;
+  const float qw = 1.f, qx = (float)(delta_t / 2.0 * (double)wx), qy = (float)(delta_t / 2.0 * (double)wy), qz = (float)(delta_t / 2.0 * (double)wz);
+  const float n2 = (qx * qx + qz * qz) + (qy * qy + qw * qw);
+  float ix = 0.f, iy = 0.f, iz = 0.f, iw = 0.f;
+  if (n2 > 0.f) ix = -qx / n2, iy = -qy / n2, iz = -qz / n2, iw = qw / n2;
+  const float vx = *x, vy = *y, vz = *z;
+  float ux = iy * vz - iz * vy, uy = iz * vx - ix * vz, uz = ix * vy - iy * vx;
+  ux += ux, uy += uy, uz += uz;
+  *x = (vx + iw * ux) + (iy * uz - iz * uy);
+  *y = (vy + iw * uy) + (iz * ux - ix * uz);
+  *z = (vz + iw * uz) + (ix * uy - iy * ux);
+}
+
 // ---- symmetric 3x3 eigen decomposition (cyclic Jacobi), eigenvalues ascending, eigenvectors in columns of V ----
 HGS_HD void eig_sym3(const double* A_in, double* w, double* V) {
   HGS_FP_STRICT

@@ -162,15 +162,22 @@ class RegistrationHIP:
     def upload(self, cloud) -> DeviceCloud:
         return DeviceCloud(self, cloud)
 
-    def prefilter(self, cloud, params=None) -> DeviceCloud:
-        """PrefilteringNodelet::cloud_callback (apps/prefiltering_nodelet.cpp:131-133) on the device: distance filter ->
-        voxel grid -> outlier removal.  Returns a resident cloud usable as setInputSource / setInputTarget argument."""
+    def prefilter(self, cloud, params=None, imu_angular_velocity=None, scan_period: float = 0.1) -> DeviceCloud:
+        """PrefilteringNodelet::cloud_callback (apps/prefiltering_nodelet.cpp:106-136) on the device: [deskewing ->] distance
+        filter -> voxel grid -> outlier removal.  Returns a resident cloud usable as setInputSource / setInputTarget argument.
+        imu_angular_velocity: the angular_velocity of the sensor_msgs/Imu sample `select_imu_sample` picks (None = the
+        nodelet's empty imu_queue or deskewing off: no deskewing)."""
         if params is None:
             params = L.HgsPrefilterParams()
             self._check(L.lib().hgs_prefilter_params_default(C.byref(params)))
         arr, n, stride = L.cloud_args(cloud)
         h = C.c_void_p()
-        self._check(L.lib().hgs_prefilter(self._h, arr.ctypes.data_as(C.c_void_p), n, stride, C.byref(params), C.byref(h)))
+        if imu_angular_velocity is None:
+            self._check(L.lib().hgs_prefilter(self._h, arr.ctypes.data_as(C.c_void_p), n, stride, C.byref(params), C.byref(h)))
+        else:
+            w = np.ascontiguousarray(imu_angular_velocity, np.float64).reshape(3)
+            self._check(L.lib().hgs_prefilter_deskewed(self._h, arr.ctypes.data_as(C.c_void_p), n, stride, C.byref(params), w.ctypes.data_as(C.c_void_p),
+                                                       float(scan_period), C.byref(h)))
         return DeviceCloud._adopt(self, h)
 
     def map_cloud(self, keyframes, poses, resolution: float) -> DeviceCloud:
@@ -276,6 +283,24 @@ class RegistrationHIP:
 
     def synchronize(self):
         self._check(L.lib().hgs_synchronize(self._h))
+
+
+def select_imu_sample(imu_queue, cloud_stamp):
+    """The gyro sample PrefilteringNodelet::deskewing uses (apps/prefiltering_nodelet.cpp:206-216): imu_queue is a list of
+    (stamp, angular_velocity) in arrival order; the first sample stamped after the cloud, else the newest one; every sample in
+    front of the chosen one is dropped from the queue (the chosen one stays).  Returns the angular velocity, or None for an
+    empty queue (the cloud then passes undeskewed)."""
+    if not imu_queue:
+        return None
+    loc = 0
+    chosen = imu_queue[0]
+    while loc < len(imu_queue):
+        chosen = imu_queue[loc]
+        if imu_queue[loc][0] > cloud_stamp:
+            break
+        loc += 1
+    del imu_queue[:loc]
+    return chosen[1]
 
 
 def select_best(records: np.ndarray) -> int:

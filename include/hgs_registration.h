@@ -204,6 +204,13 @@ int hgs_prefilter_params_default(hgs_prefilter_params* p);
  * an hgs_cloud that can be handed to hgs_set_source_cloud / hgs_set_target_cloud directly (no second upload) and
  * fetched with hgs_cloud_download. */
 int hgs_prefilter(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, hgs_cloud** out);
+/* The same with the deskewing step of cloud_callback in front (apps/prefiltering_nodelet.cpp:112, :182-243, rosparam
+ * "deskewing"): point i of the n input points is rotated back by the first-order rotation the sensor made during
+ * scan_period * i / n at the gyro rate of ONE sensor_msgs/Imu sample — imu_angular_velocity[3] = that message's
+ * angular_velocity (the nodelet takes the first queued sample stamped after the cloud, else the newest; choosing it stays
+ * host logic).  NULL = the nodelet's empty imu_queue: no deskewing.  scan_period: rosparam "scan_period" (0.1). */
+int hgs_prefilter_deskewed(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const hgs_prefilter_params* p, const double* imu_angular_velocity,
+                           double scan_period, hgs_cloud** out);
 /* Copy a resident cloud back: out_pts[i] = {x, y, z, (1.0), intensity, ...} with the PointXYZI layout for stride >= 20,
  * packed xyz(+w) otherwise.  Needs room for hgs_cloud_size(c) records. */
 int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_bytes);

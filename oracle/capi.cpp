@@ -246,6 +246,20 @@ long hgso_prefilter(const void* pts, size_t n, size_t stride, const PrefilterPar
   return (long)out.size();
 }
 
+// The same with the deskewing step of cloud_callback (:112) in front: imu_angular_velocity as in the sensor_msgs/Imu message.
+long hgso_prefilter_deskewed(const void* pts, size_t n, size_t stride, const PrefilterParams* prm, const double* imu_angular_velocity, double scan_period,
+                             float* out4, size_t cap) {
+  std::vector<PfPoint> in(n), out;
+  for (size_t i = 0; i < n; i++) {
+    const float* f = (const float*)((const char*)pts + i * stride);
+    in[i] = {f[0], f[1], f[2], stride >= 20 ? f[4] : 0.f};
+  }
+  pf_deskew(in, imu_angular_velocity, scan_period);
+  if (!prefilter(in, *prm, out)) return -1;
+  for (size_t i = 0; i < out.size() && i < cap; i++) out4[4 * i] = out[i].x, out4[4 * i + 1] = out[i].y, out4[4 * i + 2] = out[i].z, out4[4 * i + 3] = out[i].intensity;
+  return (long)out.size();
+}
+
 // MapCloudGenerator::generate: n_kf clouds given as one concatenated record array + per-keyframe sizes; poses: 16
 // column-major floats each.  Returns the number of output points ({x,y,z,intensity} float4 records) or -1.
 long hgso_map_cloud(const void* pts, const size_t* sizes, size_t n_kf, size_t stride, const float* poses16, double resolution, float* out4, size_t cap) {

@@ -102,6 +102,8 @@ def lib():
         L.hgso_gicp_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hgso_prefilter.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.hgso_prefilter.restype = C.c_long
+        L.hgso_prefilter_deskewed.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]
+        L.hgso_prefilter_deskewed.restype = C.c_long
         L.hgso_map_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]
         L.hgso_map_cloud.restype = C.c_long
         L.hgso_ndt_cells.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -271,14 +273,18 @@ def default_prefilter_params() -> PrefilterParams:
     return PrefilterParams(1, 1, 1.0, 100.0, 0.1, 1, 20, 1.0, 0.8, 2, 0)
 
 
-def prefilter(cloud: np.ndarray, params) -> np.ndarray:
-    """distance_filter -> pcl::VoxelGrid -> outlier removal; returns [m, 4] float32 {x, y, z, intensity}."""
+def prefilter(cloud: np.ndarray, params, imu_angular_velocity=None, scan_period: float = 0.1) -> np.ndarray:
+    """[deskewing ->] distance_filter -> pcl::VoxelGrid -> outlier removal; returns [m, 4] float32 {x, y, z, intensity}."""
     arr, n, stride = _cloud_args(cloud)
     p = PrefilterParams()
     for name, _ in PrefilterParams._fields_:
         setattr(p, name, getattr(params, name))
     out = np.zeros((max(n, 1), 4), np.float32)
-    m = lib().hgso_prefilter(_ptr(arr), n, stride, C.byref(p), _ptr(out), max(n, 1))
+    if imu_angular_velocity is None:
+        m = lib().hgso_prefilter(_ptr(arr), n, stride, C.byref(p), _ptr(out), max(n, 1))
+    else:
+        w = np.ascontiguousarray(imu_angular_velocity, np.float64).reshape(3)
+        m = lib().hgso_prefilter_deskewed(_ptr(arr), n, stride, C.byref(p), _ptr(w), float(scan_period), _ptr(out), max(n, 1))
     if m < 0:
         raise ValueError("voxel grid index overflow")
     return out[:m].copy()

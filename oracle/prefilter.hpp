@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.hpp header). Parity unpinned by the reference.
 //
 // CPU restatement of the prefilter that feeds the scan-matching path, apps/prefiltering_nodelet.cpp:
+//   deskewing        (:182-243)  optional, before everything else: see pf_deskew below
 //   distance_filter  (:165-182)  keep p iff near < |p| < far, |p| the FLOAT norm compared against double thresholds
 //   downsample       (:138-149)  pcl::VoxelGrid with leaf = downsample_resolution (:52-58)
 //   outlier_removal  (:151-163)  pcl::RadiusOutlierRemoval (:85-93) or pcl::StatisticalOutlierRemoval (:73-84)
@@ -41,6 +42,30 @@ struct PrefilterParams {  // mirrors hgs_prefilter_params of include/hgs_registr
   int32_t radius_min_neighbors;
   int32_t reserved;
 };
+
+// deskewing (:182-243): every point i of the sweep is rotated back by the rotation the sensor made during
+// delta_t = scan_period * i / size, from ONE gyro sample: delta_q = (1, delta_t/2 * w) with w = -(imu angular velocity)
+// as floats — a first-order, NOT normalised quaternion —, p' = delta_q.inverse() * p.  Eigen is not under /root/reference;
+// [UPSTREAM-KNOWLEDGE] Eigen 3.3: inverse() = conjugate().coeffs() / squaredNorm() (float, the SSE2 reduction order
+// (x^2 + z^2) + (y^2 + w^2)), and q * v = v + w * uv + q.vec().cross(uv) with uv = 2 * q.vec().cross(v), all in float,
+// no fused multiply-add.  Non-finite points stay non-finite; intensity is kept.
+inline void pf_deskew(std::vector<PfPoint>& pts, const double imu_angular_velocity[3], double scan_period) {
+  const float w[3] = {-(float)imu_angular_velocity[0], -(float)imu_angular_velocity[1], -(float)imu_angular_velocity[2]};
+  const size_t n = pts.size();
+  for (size_t i = 0; i < n; i++) {
+    const double delta_t = scan_period * (double)i / (double)n;
+    const float qw = 1.f, qx = (float)(delta_t / 2.0 * (double)w[0]), qy = (float)(delta_t / 2.0 * (double)w[1]), qz = (float)(delta_t / 2.0 * (double)w[2]);
+    const float n2 = (qx * qx + qz * qz) + (qy * qy + qw * qw);
+    float ix = 0.f, iy = 0.f, iz = 0.f, iw = 0.f;
+    if (n2 > 0.f) ix = -qx / n2, iy = -qy / n2, iz = -qz / n2, iw = qw / n2;
+    const float vx = pts[i].x, vy = pts[i].y, vz = pts[i].z;
+    float ux = iy * vz - iz * vy, uy = iz * vx - ix * vz, uz = ix * vy - iy * vx;
+    ux += ux, uy += uy, uz += uz;
+    pts[i].x = (vx + iw * ux) + (iy * uz - iz * uy);
+    pts[i].y = (vy + iw * uy) + (iz * ux - ix * uz);
+    pts[i].z = (vz + iw * uz) + (ix * uy - iy * ux);
+  }
+}
 
 inline std::vector<PfPoint> pf_distance_filter(const std::vector<PfPoint>& in, double near, double far) {
   std::vector<PfPoint> out;

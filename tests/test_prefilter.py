@@ -218,3 +218,97 @@ def test_hip_approx_voxelgrid_matches_oracle_in_order():
     from hdl_graph_slam_amd import _lib as L
     from hdl_graph_slam_amd.registration import RegistrationHIP
     _check_approx_voxelgrid(lambda: RegistrationHIP(L.default_params(L.HGS_FAST_GICP)))
+
+
+# ---- deskewing (apps/prefiltering_nodelet.cpp:182-243) -----------------------------------------------------------------
+def _np_deskew(xyz, imu_w, scan_period):
+    """Independent numpy restatement: Eigen's float quaternion arithmetic, point by point."""
+    f = np.float32
+    w = [-f(imu_w[0]), -f(imu_w[1]), -f(imu_w[2])]
+    n = len(xyz)
+    out = np.empty_like(xyz)
+    with np.errstate(invalid="ignore", over="ignore"):
+        for i in range(n):
+            dt = np.float64(scan_period) * np.float64(i) / np.float64(n)
+            q = [f(dt / 2.0 * np.float64(w[0])), f(dt / 2.0 * np.float64(w[1])), f(dt / 2.0 * np.float64(w[2])), f(1.0)]      # x y z w
+            n2 = (q[0] * q[0] + q[2] * q[2]) + (q[1] * q[1] + q[3] * q[3])
+            iv = np.array([-q[0] / n2, -q[1] / n2, -q[2] / n2], f)
+            iw = q[3] / n2
+            v = xyz[i].astype(f)
+            uv = np.array([iv[1] * v[2] - iv[2] * v[1], iv[2] * v[0] - iv[0] * v[2], iv[0] * v[1] - iv[1] * v[0]], f)
+            uv = uv + uv
+            c = np.array([iv[1] * uv[2] - iv[2] * uv[1], iv[2] * uv[0] - iv[0] * uv[2], iv[0] * uv[1] - iv[1] * uv[0]], f)
+            out[i] = (v + iw * uv) + c
+    return out
+
+
+def test_oracle_deskew_matches_numpy_and_undoes_a_constant_rate_rotation():
+    cloud = _scan(4)[:3000]
+    p = O.default_prefilter_params()
+    p.use_distance_filter, p.downsample_method, p.outlier_removal_method = 0, 0, 0
+    imu_w, period = [0.3, -0.2, 1.1], 0.1
+    got = O.prefilter(cloud, p, imu_angular_velocity=imu_w, scan_period=period)
+    xyz = np.stack([cloud["x"], cloud["y"], cloud["z"]], axis=1)
+    ref = _np_deskew(xyz, imu_w, period)
+    assert np.array_equal(got[:, :3], ref, equal_nan=True) and np.array_equal(got[:, 3], cloud["intensity"])
+    # the meaning: a static point seen by a sensor turning at rate w appears, at time t, rotated by R(-w t) in the sensor frame;
+    # deskewing brings every point of the sweep back into the frame of the sweep's start, to first order in |w| t
+    rng = np.random.default_rng(0)
+    n = 2000
+    world = rng.uniform(-20, 20, (n, 3))
+    w = np.array(imu_w)
+    seen = np.empty((n, 3), np.float32)
+    for i in range(n):
+        th = w * (period * i / n)
+        a = np.linalg.norm(th)
+        k = th / a if a > 0 else th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+        seen[i] = R.T @ world[i]
+    rec = O.prefilter(synth.to_xyzi(seen), p, imu_angular_velocity=imu_w, scan_period=period)[:, :3]
+    assert np.abs(rec - world).max() < 0.02 and np.abs(seen - world).max() > 1.0      # |w| t = 0.12 rad: second-order residue only
+    # no gyro sample -> untouched
+    assert np.array_equal(O.prefilter(cloud, p)[:, :3], xyz, equal_nan=True)
+
+
+def test_select_imu_sample_follows_the_nodelet_queue_rule():
+    from hdl_graph_slam_amd.registration import select_imu_sample
+    assert select_imu_sample([], 5.0) is None
+    q = [(1.0, "a"), (2.0, "b"), (3.0, "c"), (4.0, "d")]
+    assert select_imu_sample(q, 2.0) == "c" and [s for s, _ in q] == [3.0, 4.0]      # first stamp AFTER the cloud; older ones dropped, it stays
+    assert select_imu_sample(q, 2.5) == "c" and len(q) == 2
+    assert select_imu_sample(q, 9.0) == "d" and q == []                                 # none newer: the newest, queue emptied
+    q = [(7.0, "x")]
+    assert select_imu_sample(q, 1.0) == "x" and q == [(7.0, "x")]
+
+
+def _check_deskewed_prefilter(make_engine):
+    from hdl_graph_slam_amd import _lib as L
+    reg = make_engine()
+    for seed, imu_w, period, full in ((5, [0.3, -0.2, 1.1], 0.1, True), (6, [0.0, 0.0, -2.5], 0.05, False), (7, [0.0, 0.0, 0.0], 0.1, False)):
+        cloud = _scan(seed)
+        p = L.HgsPrefilterParams()
+        L.lib().hgs_prefilter_params_default(C.byref(p))
+        if not full:
+            p.use_distance_filter, p.downsample_method, p.outlier_removal_method = 0, 0, 0
+        got = reg.prefilter(cloud, p, imu_angular_velocity=imu_w, scan_period=period).download()
+        ref = O.prefilter(cloud, p, imu_angular_velocity=imu_w, scan_period=period)
+        g4 = np.stack([got["x"], got["y"], got["z"], got["intensity"]], axis=1)
+        if not full:   # nothing filtered: the non-finite records are still there (hgs_cloud keeps n_input, downloads them as they are)
+            assert g4.shape == ref.shape and np.array_equal(g4, ref, equal_nan=True), seed
+        else:
+            assert g4.shape == ref.shape and np.array_equal(g4, ref), seed
+    # NULL gyro sample = the nodelet's empty queue
+    cloud = _scan(8)
+    a = reg.prefilter(cloud).download()
+    b = reg.prefilter(cloud, None, imu_angular_velocity=None).download()
+    assert np.array_equal(a["x"], b["x"])
+    reg.close()
+
+
+@pytest.mark.gpu
+def test_hip_deskewed_prefilter_matches_oracle():
+    """Row f2: the deskewing step in front of the prefilter, on the device, bit for bit the oracle's (same unfused float sequence)."""
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    _check_deskewed_prefilter(lambda: RegistrationHIP(L.default_params(L.HGS_FAST_GICP)))

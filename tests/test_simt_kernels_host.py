@@ -475,6 +475,12 @@ def test_sharded_batch_entry_point_world_one():
     _sharded_equals_unsharded(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
 
 
+def test_deskewed_prefilter():
+    """hgs_prefilter_deskewed (k_pf_load with the deskewing step) against the oracle, bit for bit."""
+    from test_prefilter import _check_deskewed_prefilter
+    _check_deskewed_prefilter(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
+
+
 def test_approx_voxelgrid_in_eviction_order():
     """pcl::ApproximateVoxelGrid through the emulated k_pf_approx_* kernels: the oracle's sequential output, in order."""
     from test_prefilter import _check_approx_voxelgrid
