@@ -148,11 +148,30 @@ struct MapSource {
   float T[16];             // keyframe pose, column-major float
 };
 void launch_map_transform(hipStream_t s, const MapSource* srcs, int nsrc, int max_n, float4* out);
-void launch_map_first_finite(hipStream_t s, const float4* pts, int n, int* meta);
-void launch_map_cell_bbox(hipStream_t s, const float4* pts, int n, double res, int* meta);
-void launch_map_keys(hipStream_t s, const float4* pts, int n, double res, int* meta, unsigned long long* keys, unsigned* vals);
-void launch_map_centers(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* head, const unsigned* slot, int n, double res,
-                        const int* meta, float4* out, int* count_out);
+// The growth of pcl::octree::OctreePointCloud's bounding box while the map's points are added in order (hgs_math.h "octree box"):
+// events[0] is the first finite point, every later event a point that lay outside the box of its moment and the state after the
+// doublings it forced.  A point's key is taken against the box of the last event at or before it and then gains what the later
+// doublings added — exactly what re-rooting the tree does to the leaves inserted earlier.
+constexpr int kMapMaxDepth = 21;                  // 3 * 21 interleaved key bits < 64
+constexpr int kMapMaxEvents = kMapMaxDepth + 3;
+struct MapOctreeEvent {
+  int index, depth;
+  double mn[3];
+  unsigned long long gained[3];
+};
+struct MapOctree {
+  int first;      // index of the first finite point (INT_MAX: none)
+  int next_viol;  // lowest index after the last event that lies outside the current box (INT_MAX: none found)
+  int n_events, overflow, done, pad;
+  double mx[3];   // the current box's max; min / depth / gained: events[n_events - 1]
+  MapOctreeEvent events[kMapMaxEvents];
+};
+void launch_map_first_finite(hipStream_t s, const float4* pts, int n, MapOctree* oct);
+void launch_map_octree_init(hipStream_t s, const float4* pts, int n, double res, MapOctree* oct);
+void launch_map_octree_step(hipStream_t s, const float4* pts, int n, double res, MapOctree* oct);
+void launch_map_keys(hipStream_t s, const float4* pts, int n, double res, const MapOctree* oct, unsigned long long* keys, unsigned* vals);
+void launch_map_centers(hipStream_t s, const unsigned long long* keys, const unsigned* head, const unsigned* slot, int n, double res, const MapOctree* oct, float4* out,
+                        int* count_out);
 
 // prefilter (apps/prefiltering_nodelet.cpp)
 void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out, const float* deskew_w /* -(gyro rate), or null */, double scan_period);
@@ -163,7 +182,7 @@ void launch_pf_grid(hipStream_t s, unsigned* meta, float inv_leaf);
 void launch_pf_voxel_keys(hipStream_t s, const float4* pts, const int* count, const unsigned* meta, float inv_leaf, int cap, unsigned long long* keys, unsigned* vals);
 void launch_pf_voxel_heads(hipStream_t s, const unsigned long long* keys, int cap, unsigned* head, unsigned long long invalid_key);
 constexpr unsigned long long kVoxelInvalidKey = 0xffffffffull;  // prefilter voxel grid: 31-bit linear indices like pcl::VoxelGrid
-constexpr unsigned long long kMapInvalidKey = ~0ull;            // map cloud: up to 2^62 lattice cells
+constexpr unsigned long long kMapInvalidKey = ~0ull;            // map cloud: interleaved keys use at most 63 bits
 void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* slot,
                                int cap, float4* out, int* count_out);
 void launch_pf_approx_keys(hipStream_t s, const float4* pts, const int* count, float inv_leaf, int cap, unsigned long long* keys, unsigned* vals);

@@ -1690,8 +1690,8 @@ extern "C" int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes
   HGS_HIP(h, h->pf_b.reserve(cap * sizeof(float4)));
   HGS_HIP(h, h->pf_keep.reserve(cap * sizeof(uint32_t)));
   HGS_HIP(h, h->pf_slot.reserve(cap * sizeof(uint32_t)));
-  HGS_HIP(h, h->pf_small.reserve(256));
-  HGS_HIP(h, h->h_small.reserve(64));
+  HGS_HIP(h, h->pf_small.reserve(256 + sizeof(MapOctree)));
+  HGS_HIP(h, h->h_small.reserve(std::max<size_t>(64, sizeof(MapOctree))));
   float4* all = h->pf_a.as<float4>();
   if (n_keyframes > 0 && total > 0) {
     std::vector<MapSource> srcs(n_keyframes);
@@ -1710,32 +1710,35 @@ extern "C" int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes
   size_t m = total;
   float4* result = all;
   if (resolution > 0.0 && total > 0) {
-    int* d_meta = h->pf_small.as<int>() + 16;
     int* d_count = h->pf_small.as<int>();
-    const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0};
-    HGS_HIP(h, hipMemcpyAsync(d_meta, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    MapOctree* d_oct = reinterpret_cast<MapOctree*>(h->pf_small.as<char>() + 256);
+    MapOctree* h_oct = reinterpret_cast<MapOctree*>(h->h_small.p);
     const int n = (int)total;
-    launch_map_first_finite(h->stream, all, n, d_meta);
-    launch_map_cell_bbox(h->stream, all, n, resolution, d_meta);
+    // replay the octree's bounding box: one round per point that forced the box to double (at most one per tree level), each a
+    // grid-wide "first point outside" search and a one-thread update; the host only watches the done flag (map clouds are
+    // generated every few seconds)
+    std::memset(h_oct, 0, sizeof(MapOctree));
+    h_oct->first = 0x7fffffff;
+    HGS_HIP(h, hipMemcpyAsync(d_oct, h_oct, sizeof(MapOctree), hipMemcpyHostToDevice, h->stream));
+    launch_map_first_finite(h->stream, all, n, d_oct);
+    launch_map_octree_init(h->stream, all, n, resolution, d_oct);
+    for (int round = 0; round <= kMapMaxEvents; round++) {
+      launch_map_octree_step(h->stream, all, n, resolution, d_oct);
+      HGS_HIP(h, hipMemcpyAsync(h_oct, d_oct, sizeof(MapOctree), hipMemcpyDeviceToHost, h->stream));
+      HGS_HIP(h, hipStreamSynchronize(h->stream));
+      if (h_oct->done) break;
+    }
+    if (h_oct->overflow || !h_oct->done) {
+      h->err = "map cloud: resolution too fine for the extent of the map (the octree would be deeper than 21 levels)";
+      return HGS_ERR_INVALID_ARGUMENT;
+    }
     for (int i = 0; i < 2; i++) {
       HGS_HIP(h, h->sort_keys[i].reserve(total * sizeof(uint64_t)));
       HGS_HIP(h, h->sort_vals[i].reserve(total * sizeof(uint32_t)));
     }
-    // the lattice box decides how many key bits the sort has to look at (the reference's map_cloud_resolution of 0.05 / 0.01 m
-    // over a few hundred metres is 10^10 .. 10^12 cells): one small read-back, map clouds are generated every few seconds
-    int* hs = h->h_small.as<int>();
-    HGS_HIP(h, hipMemcpyAsync(hs, d_meta, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HGS_HIP(h, hipStreamSynchronize(h->stream));
-    int key_bits = 1;
-    if (hs[0] < n) {  // some finite point exists
-      const double cells = ((double)hs[4] - hs[1] + 1.0) * ((double)hs[5] - hs[2] + 1.0) * ((double)hs[6] - hs[3] + 1.0);
-      if (!(cells < 4.6e18)) {  // 2^62
-        h->err = "map cloud: resolution too fine for the extent of the map (more than 2^62 lattice cells)";
-        return HGS_ERR_INVALID_ARGUMENT;
-      }
-      while (key_bits < 63 && (double)(1ull << key_bits) <= cells) key_bits++;  // 2^key_bits > cells: all-ones stays above every cell
-    }
-    launch_map_keys(h->stream, all, n, resolution, d_meta, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
+    // interleaved keys use 3 * depth bits; one more so that the all-ones key of a non-finite point sorts behind every voxel
+    const int key_bits = h_oct->n_events > 0 ? 3 * h_oct->events[h_oct->n_events - 1].depth + 1 : 1;
+    launch_map_keys(h->stream, all, n, resolution, d_oct, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
     size_t tmp_bytes = 0;
     int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
                                     h->sort_vals[1].as<uint32_t>(), total, 0, key_bits, h->stream);
@@ -1750,9 +1753,10 @@ extern "C" int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes
     }
     launch_pf_voxel_heads(h->stream, h->sort_keys[1].as<unsigned long long>(), n, h->pf_keep.as<unsigned>(), kMapInvalidKey);
     HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), total));
-    launch_map_centers(h->stream, all, h->sort_keys[1].as<unsigned long long>(), h->pf_keep.as<unsigned>(), h->pf_slot.as<unsigned>(), n, resolution, d_meta,
+    launch_map_centers(h->stream, h->sort_keys[1].as<unsigned long long>(), h->pf_keep.as<unsigned>(), h->pf_slot.as<unsigned>(), n, resolution, d_oct,
                        h->pf_b.as<float4>(), d_count);
     HGS_HIP(h, hipGetLastError());
+    int* hs = h->h_small.as<int>();
     HGS_HIP(h, hipMemcpyAsync(hs, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HGS_HIP(h, hipStreamSynchronize(h->stream));
     m = (size_t)std::max(0, hs[0]);

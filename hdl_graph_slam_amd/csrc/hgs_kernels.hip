@@ -1694,7 +1694,7 @@ void launch_pf_statistical(hipStream_t s, const double* dist, int n, double* sta
 // ------------------------------------------------------------------------------------------------ map cloud (next row f3)
 // MapCloudGenerator::generate, src/hdl_graph_slam/map_cloud_generator.cpp:13-51: every keyframe cloud transformed by
 // its (float) pose and concatenated; with a positive resolution, the centres of the occupied voxels of the
-// pcl::octree::OctreePointCloud lattice (anchored on the first finite point) instead of the points themselves.
+// pcl::octree::OctreePointCloud built from the points in order, in the tree's depth-first order, instead of the points themselves.
 __global__ __launch_bounds__(kBlock) void k_map_transform(const MapSource* __restrict__ srcs, float4* __restrict__ out) {
   HGS_FP_STRICT
   const MapSource m = srcs[blockIdx.y];
@@ -1712,77 +1712,111 @@ void launch_map_transform(hipStream_t s, const MapSource* srcs, int nsrc, int ma
   if (nsrc > 0 && max_n > 0) hipLaunchKernelGGL(k_map_transform, dim3((max_n + kBlock - 1) / kBlock, nsrc), dim3(kBlock), 0, s, srcs, out);
 }
 
-// meta (ints): [0] index of the first finite point, [1..3] min cell, [4..6] max cell, [7] overflow flag
-__global__ __launch_bounds__(kBlock) void k_map_first_finite(const float4* __restrict__ pts, int n, int* __restrict__ meta) {
+__global__ __launch_bounds__(kBlock) void k_map_first_finite(const float4* __restrict__ pts, int n, MapOctree* __restrict__ oct) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool ok = i < n && finite3(pts[i]);
   const unsigned long long m = __ballot(ok);
-  if (m != 0ull && (threadIdx.x & 63) == 0) atomicMin(&meta[0], (int)(blockIdx.x * kBlock + (threadIdx.x & ~63u)) + (__ffsll((long long)m) - 1));
+  if (m != 0ull && (threadIdx.x & 63) == 0) atomicMin(&oct->first, (int)(blockIdx.x * kBlock + (threadIdx.x & ~63u)) + (__ffsll((long long)m) - 1));
 }
-__device__ __forceinline__ bool map_cell_of(const float4& p, const float4& p0, double res, long long* c) {
-  HGS_FP_STRICT
-  const double h = res / 2;
-  const double mn[3] = {(double)p0.x - h, (double)p0.y - h, (double)p0.z - h};
-  c[0] = (long long)floor(((double)p.x - mn[0]) / res);
-  c[1] = (long long)floor(((double)p.y - mn[1]) / res);
-  c[2] = (long long)floor(((double)p.z - mn[2]) / res);
-  return c[0] > -(1ll << 30) && c[0] < (1ll << 30) && c[1] > -(1ll << 30) && c[1] < (1ll << 30) && c[2] > -(1ll << 30) && c[2] < (1ll << 30);
+// The octree's bounding box is replayed event by event (see MapOctree, hgs_device.h): the box after the first finite point, then
+// repeatedly { the first later point outside the current box (a grid-wide minimum), the doublings it forces (one thread) } until
+// no point is outside — at most one round per tree level.
+__global__ void k_map_octree_init(const float4* __restrict__ pts, int n, double res, MapOctree* __restrict__ oct) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  oct->next_viol = 0x7fffffff, oct->overflow = 0, oct->n_events = 0, oct->done = 1;
+  if (oct->first >= n) return;
+  const float4 p = pts[oct->first];
+  const float q[3] = {p.x, p.y, p.z};
+  MapOctreeEvent& e = oct->events[0];
+  e.index = oct->first, e.gained[0] = e.gained[1] = e.gained[2] = 0ull;
+  octree_box_first(q, res, e.mn, oct->mx, &e.depth);
+  oct->n_events = 1, oct->done = 0;
 }
-__global__ __launch_bounds__(kBlock) void k_map_cell_bbox(const float4* __restrict__ pts, int n, double res, int* __restrict__ meta) {
+__global__ __launch_bounds__(kBlock) void k_map_octree_scan(const float4* __restrict__ pts, int n, MapOctree* __restrict__ oct) {
+  if (oct->done) return;
+  const MapOctreeEvent& e = oct->events[oct->n_events - 1];
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n || meta[0] >= n) return;
-  const float4 p = pts[i];
-  if (!finite3(p)) return;
-  long long c[3];
-  if (!map_cell_of(p, pts[meta[0]], res, c)) {
-    meta[7] = 1;
+  bool out = false;
+  if (i < n && i > e.index) {
+    const float4 p = pts[i];
+    const float q[3] = {p.x, p.y, p.z};
+    out = finite3(p) && octree_box_violated(q, e.mn, oct->mx);
+  }
+  const unsigned long long m = __ballot(out);
+  if (m != 0ull && (threadIdx.x & 63) == 0) atomicMin(&oct->next_viol, (int)(blockIdx.x * kBlock + (threadIdx.x & ~63u)) + (__ffsll((long long)m) - 1));
+}
+__global__ void k_map_octree_apply(const float4* __restrict__ pts, double res, MapOctree* __restrict__ oct) {
+  if (blockIdx.x != 0 || threadIdx.x != 0 || oct->done) return;
+  if (oct->next_viol == 0x7fffffff) {
+    oct->done = 1;
     return;
   }
-  for (int a = 0; a < 3; a++) atomicMin(&meta[1 + a], (int)c[a]), atomicMax(&meta[4 + a], (int)c[a]);
+  const float4 p = pts[oct->next_viol];
+  const float q[3] = {p.x, p.y, p.z};
+  MapOctreeEvent e = oct->events[oct->n_events - 1];
+  e.index = oct->next_viol;
+  while (octree_box_violated(q, e.mn, oct->mx)) {
+    if (e.depth >= kMapMaxDepth) {
+      oct->overflow = 1, oct->done = 1;
+      return;
+    }
+    octree_box_double(q, res, e.mn, oct->mx, &e.depth, e.gained);
+  }
+  oct->events[oct->n_events++] = e;  // at least one doubling per event: n_events <= kMapMaxDepth + 1
+  oct->next_viol = 0x7fffffff;
 }
-__global__ __launch_bounds__(kBlock) void k_map_keys(const float4* __restrict__ pts, int n, double res, int* __restrict__ meta, unsigned long long* __restrict__ keys,
-                                                     unsigned* __restrict__ vals) {
+__global__ __launch_bounds__(kBlock) void k_map_keys(const float4* __restrict__ pts, int n, double res, const MapOctree* __restrict__ oct,
+                                                     unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+  HGS_FP_STRICT
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  unsigned long long key = kMapInvalidKey;  // the host has checked that the lattice box holds fewer than 2^62 cells
-  if (meta[0] < n) {
-    const long long dx = (long long)meta[4] - meta[1] + 1, dy = (long long)meta[5] - meta[2] + 1;
-    const float4 p = pts[i];
-    long long c[3];
-    if (finite3(p) && map_cell_of(p, pts[meta[0]], res, c)) key = (unsigned long long)((c[0] - meta[1]) + (c[1] - meta[2]) * dx + (c[2] - meta[3]) * dx * dy);
+  unsigned long long code = kMapInvalidKey;
+  const int ne = oct->n_events;
+  const float4 p = pts[i];
+  if (ne > 0 && finite3(p)) {
+    int ei = ne - 1;
+    while (ei > 0 && oct->events[ei].index > i) ei--;  // the box this point was inserted into
+    const MapOctreeEvent& e = oct->events[ei];
+    const MapOctreeEvent& last = oct->events[ne - 1];
+    const float q[3] = {p.x, p.y, p.z};
+    unsigned long long key[3];
+    for (int a = 0; a < 3; a++) key[a] = (unsigned long long)(unsigned)(((double)q[a] - e.mn[a]) / res) + (last.gained[a] - e.gained[a]);
+    code = octree_interleave(key, last.depth);
   }
-  keys[i] = key;
+  keys[i] = code;
   vals[i] = (unsigned)i;
 }
-// one thread per occupied voxel (head of a sorted key run): its centre
-__global__ __launch_bounds__(kBlock) void k_map_centers(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys, const unsigned* __restrict__ head,
-                                                        const unsigned* __restrict__ slot, int n, double res, const int* __restrict__ meta, float4* __restrict__ out,
-                                                        int* __restrict__ count_out) {
+// one thread per occupied voxel (head of a sorted key run): its centre, genLeafNodeCenterFromOctreeKey with the final box
+__global__ __launch_bounds__(kBlock) void k_map_centers(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ head, const unsigned* __restrict__ slot, int n,
+                                                        double res, const MapOctree* __restrict__ oct, float4* __restrict__ out, int* __restrict__ count_out) {
   HGS_FP_STRICT
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   if (i == n - 1) *count_out = (int)(slot[i] + head[i]);
   if (!head[i]) return;
-  const long long dx = (long long)meta[4] - meta[1] + 1, dy = (long long)meta[5] - meta[2] + 1;
-  const long long k = (long long)keys[i];
-  const long long cx = k % dx + meta[1], cy = (k / dx) % dy + meta[2], cz = k / (dx * dy) + meta[3];
-  const float4 p0 = pts[meta[0]];
-  const double h = res / 2;
-  out[slot[i]] = make_float4((float)(((double)cx + 0.5) * res + ((double)p0.x - h)), (float)(((double)cy + 0.5) * res + ((double)p0.y - h)),
-                             (float)(((double)cz + 0.5) * res + ((double)p0.z - h)), 0.f);
+  const MapOctreeEvent& last = oct->events[oct->n_events - 1];
+  unsigned long long key[3];
+  octree_deinterleave(keys[i], last.depth, key);
+  out[slot[i]] = make_float4((float)(((double)key[0] + 0.5) * res + last.mn[0]), (float)(((double)key[1] + 0.5) * res + last.mn[1]),
+                             (float)(((double)key[2] + 0.5) * res + last.mn[2]), 0.f);
 }
-void launch_map_first_finite(hipStream_t s, const float4* pts, int n, int* meta) {
-  if (n > 0) hipLaunchKernelGGL(k_map_first_finite, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, meta);
+void launch_map_first_finite(hipStream_t s, const float4* pts, int n, MapOctree* oct) {
+  if (n > 0) hipLaunchKernelGGL(k_map_first_finite, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, oct);
 }
-void launch_map_cell_bbox(hipStream_t s, const float4* pts, int n, double res, int* meta) {
-  if (n > 0) hipLaunchKernelGGL(k_map_cell_bbox, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, res, meta);
+void launch_map_octree_init(hipStream_t s, const float4* pts, int n, double res, MapOctree* oct) {
+  hipLaunchKernelGGL(k_map_octree_init, dim3(1), dim3(64), 0, s, pts, n, res, oct);
 }
-void launch_map_keys(hipStream_t s, const float4* pts, int n, double res, int* meta, unsigned long long* keys, unsigned* vals) {
-  if (n > 0) hipLaunchKernelGGL(k_map_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, res, meta, keys, vals);
+void launch_map_octree_step(hipStream_t s, const float4* pts, int n, double res, MapOctree* oct) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_map_octree_scan, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, oct);
+  hipLaunchKernelGGL(k_map_octree_apply, dim3(1), dim3(64), 0, s, pts, res, oct);
 }
-void launch_map_centers(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* head, const unsigned* slot, int n, double res,
-                        const int* meta, float4* out, int* count_out) {
-  if (n > 0) hipLaunchKernelGGL(k_map_centers, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, keys, head, slot, n, res, meta, out, count_out);
+void launch_map_keys(hipStream_t s, const float4* pts, int n, double res, const MapOctree* oct, unsigned long long* keys, unsigned* vals) {
+  if (n > 0) hipLaunchKernelGGL(k_map_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, res, oct, keys, vals);
+}
+void launch_map_centers(hipStream_t s, const unsigned long long* keys, const unsigned* head, const unsigned* slot, int n, double res, const MapOctree* oct, float4* out,
+                        int* count_out) {
+  if (n > 0) hipLaunchKernelGGL(k_map_centers, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, keys, head, slot, n, res, oct, out, count_out);
 }
 
 // pack a resident float4 {x,y,z,intensity} array into a cloud: raw = {x,y,z,index}, intensity kept beside it

@@ -307,6 +307,57 @@ HGS_HD void solve_svd6(const double* A, const double* b, double* x) {
   svd6_backsolve<const double*>(U, V, b, x);
 }
 
+// ---- octree box: the bounding box of pcl::octree::OctreePointCloud while points are added ---------------------------------
+// (MapCloudGenerator::generate, src/hdl_graph_slam/map_cloud_generator.cpp:39-44; PCL 1.10 octree_pointcloud.hpp
+// adoptBoundingBoxToPoint / getKeyBitSize / genOctreeKeyforPoint / genLeafNodeCenterFromOctreeKey.)  All in double, unfused.
+constexpr double kOctreeMinValue = 1.1920928955078125e-07;  // (double)std::numeric_limits<float>::epsilon()
+// first point: min = p - res/2, max = p + res/2, then getKeyBitSize() on the empty tree: >= 2 voxels per axis (depth 1) and the
+// box widened symmetrically to that side length — the point ends up on the corner shared by the root's eight voxels
+HGS_HD void octree_box_first(const float* p, double res, double* mn, double* mx, int* depth) {
+  HGS_FP_STRICT
+  unsigned max_voxels = 2u;
+  for (int a = 0; a < 3; a++) {
+    mn[a] = (double)p[a] - res / 2, mx[a] = (double)p[a] + res / 2;
+    const unsigned mk = (unsigned)ceil((mx[a] - mn[a] - kOctreeMinValue) / res);
+    max_voxels = mk > max_voxels ? mk : max_voxels;
+  }
+  const unsigned d = (unsigned)ceil(log2((double)max_voxels) - kOctreeMinValue);
+  *depth = (int)(d < 32u ? d : 32u);
+  const double side = (double)(1 << *depth) * res;
+  for (int a = 0; a < 3; a++) {
+    const double oversize = (side - (mx[a] - mn[a])) / 2.0;
+    if (oversize > kOctreeMinValue) mn[a] -= oversize, mx[a] += oversize;
+  }
+}
+HGS_HD bool octree_box_violated(const float* p, const double* mn, const double* mx) {
+  return (double)p[0] < mn[0] || (double)p[0] >= mx[0] || (double)p[1] < mn[1] || (double)p[1] >= mx[1] || (double)p[2] < mn[2] || (double)p[2] >= mx[2];
+}
+// one doubling towards p: per axis the box grows downwards unless p violates the upper bound there; gained[a] += 2^old_depth
+// where it grew downwards (the old root becomes the child with that bit set)
+HGS_HD void octree_box_double(const float* p, double res, double* mn, double* mx, int* depth, unsigned long long* gained) {
+  HGS_FP_STRICT
+  double side = (double)(1 << *depth) * res;
+  for (int a = 0; a < 3; a++) {
+    if (!((double)p[a] >= mx[a])) mn[a] -= side, gained[a] += 1ull << *depth;
+  }
+  *depth += 1;
+  side = (double)(1 << *depth) * res - kOctreeMinValue;
+  for (int a = 0; a < 3; a++) mx[a] = mn[a] + side;
+}
+// (x_bit << 2 | y_bit << 1 | z_bit) per level, most significant level first: ascending = the depth-first child order 0..7
+HGS_HD unsigned long long octree_interleave(const unsigned long long* key, int depth) {
+  unsigned long long m = 0;
+  for (int bit = depth - 1; bit >= 0; bit--) m = (m << 3) | (((key[0] >> bit) & 1ull) << 2) | (((key[1] >> bit) & 1ull) << 1) | ((key[2] >> bit) & 1ull);
+  return m;
+}
+HGS_HD void octree_deinterleave(unsigned long long m, int depth, unsigned long long* key) {
+  key[0] = key[1] = key[2] = 0ull;
+  for (int bit = 0; bit < depth; bit++) {
+    const unsigned long long t = (m >> (3 * bit)) & 7ull;
+    key[0] |= ((t >> 2) & 1ull) << bit, key[1] |= ((t >> 1) & 1ull) << bit, key[2] |= (t & 1ull) << bit;
+  }
+}
+
 // ---- deskewing of one sweep point (apps/prefiltering_nodelet.cpp:229-239) ---------------------------------------------
 // p' = delta_q.inverse() * p with delta_q = (1, delta_t/2 * w), delta_t = scan_period * i / n and w = -(gyro rate) as floats:
 // Eigen's float arithmetic restated (inverse = conjugate / squaredNorm, the (x^2 + z^2) + (y^2 + w^2) reduction;

@@ -217,10 +217,11 @@ int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_bytes);
 
 /* ---- "next" row f3: MapCloudGenerator::generate (src/hdl_graph_slam/map_cloud_generator.cpp:13-51) ------------------ */
 /* Every resident keyframe cloud transformed by its pose (float 4x4, column-major, 16 floats each) and concatenated; with
- * resolution > 0 the centres of the occupied voxels of pcl::octree::OctreePointCloud(resolution) (lattice anchored on the
- * first finite point, intensity 0) in ascending (z, y, x) cell order, else the transformed points with their intensity.
- * The map stays resident (*out); fetch it with hgs_cloud_download.  The bounding box of the map may hold up to 2^62
- * lattice cells (0.01 m over kilometres); HGS_ERR_INVALID_ARGUMENT beyond that. */
+ * resolution > 0 what pcl::octree::OctreePointCloud(resolution).addPointsFromInputCloud() + getOccupiedVoxelCenters() return
+ * (:39-44): the octree's bounding box is replayed in input order (the first finite point on the corner of a 2x2x2 root, every
+ * point outside doubling the box towards it), the voxel centres (intensity 0) come in the tree's depth-first order; else the
+ * transformed points with their intensity.  The map stays resident (*out); fetch it with hgs_cloud_download.  The octree
+ * may be up to 21 levels deep (2^21 voxels per axis: 0.01 m over 20 km); HGS_ERR_INVALID_ARGUMENT beyond that. */
 int hgs_map_cloud_generate(hgs_handle* h, hgs_cloud* const* keyframes, const float* poses, size_t n_keyframes, double resolution, hgs_cloud** out);
 
 /* ---- measurement ---------------------------------------------------------------------------------------- */

@@ -475,6 +475,11 @@ def test_sharded_batch_entry_point_world_one():
     _sharded_equals_unsharded(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
 
 
+def test_map_cloud_octree_growth():
+    from test_map_cloud import _check_map_growth
+    _check_map_growth(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
+
+
 def test_deskewed_prefilter():
     """hgs_prefilter_deskewed (k_pf_load with the deskewing step) against the oracle, bit for bit."""
     from test_prefilter import _check_deskewed_prefilter
