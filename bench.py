@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: measured float4-copy ceiling (SURVEY 8d asks for both)
 LIMITER = {"FAST_GICP": "instruction issue (VALU+SALU) of the exact tree search, not HBM: see DESIGN.md section 4",
            "FAST_VGICP": "VALU + dependent L2 round trips of the voxel hash probes, not HBM: see DESIGN.md section 4",
-           "NDT_OMP": "VALU issue of the per-cell derivative terms and of the exact integer reduction (~650 instructions per visited cell, ~1100 per 64-point "
+           "NDT_OMP": "VALU issue of the per-cell derivative terms and of the exact integer reduction (~380 VALU instructions per visited cell, ~1100 per 64-point "
                       "tile), not HBM: see DESIGN.md section 4"}
 
 
