@@ -1182,7 +1182,7 @@ __global__ void k_ndt_results(const CloudDesc* descs, const NdtState* states, De
   DevResult r;
   pose_to_colmajor_f(st.final_T, r.T);
   r.converged = st.converged, r.iterations = st.iterations, r.lm_tries = st.passes, r.pad = 0;
-  const int n = descs[b].meta->nvalid;
+  const int n = descs[b].n_input;  // trans_probability_ = score / input_->points.size(): non-finite points included
   r.error = n > 0 ? st.score / (double)n : 0.0;
   r.fit_sum = 0, r.fit_count = 0, r.pad2 = 0;
   out[b] = r;

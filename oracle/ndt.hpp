@@ -599,7 +599,8 @@ public:
     iso_to_colmajor_f(finalT, out->final_transformation);
     out->converged = converged ? 1 : 0;
     out->iterations = nr_iterations;
-    out->error = n > 0 ? score / (double)n : 0.0;
+    // trans_probability_ = score / input_->points.size(): the size of the cloud as handed in, non-finite points included
+    out->error = source->n_input > 0 ? score / (double)source->n_input : 0.0;
     out->fitness_score = std::numeric_limits<double>::quiet_NaN();
     out->num_inliers = 0;
     out->candidate_id = 0;
