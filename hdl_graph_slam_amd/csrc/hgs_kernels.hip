@@ -457,7 +457,7 @@ __device__ __forceinline__ Sym3 load_cov_stream(const float4* cov, int i) {
 // update_correspondences + linearize fused: per source point 1-NN in the target tree, Mahalanobis matrix,
 // 6x6 normal-equation terms; wave shuffle + LDS reduction to one 28-double partial per block.
 // Algorithmic bytes per source point: 16 (a_i) + 24 (C_A) + 4 (corr) + 16 (b_j) + 24 (C_B) = 84.
-// 7 waves per SIMD (72 VGPRs, 8 of the 28 fp64 accumulators spill around the search): measured best of 5 / 6 / 7 / 8.
+// 7 waves per SIMD (budget 72 VGPRs, 66 used, no scratch): measured best of 5 / 6 / 7 / 8.
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
                                                            double* __restrict__ partials, int max_blocks, int qpw) {
   const int b = blockIdx.y;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7))) voi
   __shared__ double lds[4 * kAcc];
   __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][kNW * 32];
   // the wave's index lives in an SGPR and the lane id is recomputed after the search: nothing about the thread's identity is
-  // kept in (or spilled from) a VGPR across the walk — the kernel runs at 72 VGPRs for 7 waves per SIMD without scratch
+  // kept in (or spilled from) a VGPR across the walk — the kernel fits the 72 VGPRs of 7 waves per SIMD without scratch
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const Pose T = states[b].x0;
   float Tf[12];
