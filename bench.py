@@ -237,6 +237,22 @@ def run_loop_batch(ctx):
     reg = ctx["select_registration_method"](pnh, device_id=ctx["local_rank"])
     shard = ctx["CandidateShard"](rank, world, device=ctx["coll_device"]) if ctx["sharded"] else None
     barrier = make_barrier(ctx, reg)
+    # The exchange step of a sharded detection: the library's own entry point (hgs_comm_init + hgs_loop_match_batch_sharded: RCCL
+    # all-gather of device-built records on the engine's stream) when every rank could join its communicator; otherwise the same
+    # all-gather through torch.distributed (gloo in the emulated CPU runs, or HGS_BENCH_EXCHANGE=torch).
+    exchange = {"kind": None if shard is None else "torch.distributed all_gather of the records"}
+    if shard is not None and not ctx["emulated"] and str(ctx["coll_device"]).startswith("cuda") and os.environ.get("HGS_BENCH_EXCHANGE", "hgs") != "torch":
+        ok = 1
+        try:
+            shard.comm_bootstrap(reg)
+        except Exception as e:  # noqa: BLE001 - any failure means "use the torch path", on every rank
+            ok = 0
+            if rank == 0:
+                print(f"[bench] hgs_comm_init failed ({e}); exchanging through torch.distributed", file=sys.stderr)
+        t = ctx["torch"].tensor([ok], device=ctx["coll_device"], dtype=ctx["torch"].int32)
+        ctx["dist"].all_reduce(t, op=ctx["dist"].ReduceOp.MIN)
+        if int(t.item()) == 1:
+            exchange["kind"] = "hgs_loop_match_batch_sharded (RCCL all-gather on the engine's stream, C-ABI)"
 
     def load(seed):
         # every rank holds the query keyframe (replicated target) and its own shard of the N*B candidates
@@ -255,9 +271,13 @@ def run_loop_batch(ctx):
                 for c in d_cands:           # reference behaviour: setInputSource rebuilds tree + covariances of every candidate
                     c.invalidate()
             reg.setInputTarget(d_target)
+            ids = np.arange(rank, world * B, world, dtype=np.int32)   # candidate c lives on rank c mod world
+            if shard is not None and exchange["kind"].startswith("hgs_"):
+                allrec, best = reg.loop_match_batch_sharded(d_cands, ids, wl.guesses, world * B, L.DBL_MAX)
+                return allrec[ids], best
             rec, best = reg.loop_match_batch(d_cands, wl.guesses, L.DBL_MAX)
             if shard is not None:
-                rec["candidate_id"] = np.arange(rank, world * B, world, dtype=np.int32)
+                rec["candidate_id"] = ids
                 allrec = shard.gather_records(rec, world * B)
                 best = ctx["select_best"](allrec)
             return rec, best
@@ -357,7 +377,7 @@ def run_loop_batch(ctx):
                     f"{' (covariance regularisation ' + a.regularization + ')' if a.regularization else ''}"
                     f" + getFitnessScore, cold (index + covariances rebuilt every step)",
                     {"candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": method,
-                     "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU"})
+                     "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU", "exchange": exchange["kind"]})
     out.update({"step_ms": percentiles(per_step), "timed_region_s": round(dt, 3),
                 "value_by_scene_seed": by_seed, "value_mean_std_over_seeds": [round(float(np.mean(by_seed)), 1), round(float(np.std(by_seed)), 1)],
                 "pose_rmse_vs_ground_truth": {"translation_m": round(rmse_t, 5), "rotation_rad": round(rmse_r, 6)},

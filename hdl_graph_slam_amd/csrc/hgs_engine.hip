@@ -152,7 +152,7 @@ struct hgs_handle {
   int ndt_chunk = 0;             // largest queue grab in items (0: the default, 8; 1 = one tile per grab); HGS_NDT_CHUNK (A/B runs)
   int ndt_sort = -1;       // NDT source order: -1 Hilbert order if the source has an index, 1 build the index first, 0 input order (HGS_NDT_SORT, A/B runs)
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
-  PinnedBuffer h_descs, h_results, h_small, h_flags;  // h_flags: host-mapped progress mirror (Progress)
+  PinnedBuffer h_descs, h_results, h_small, h_flags, h_comm;  // h_flags: host-mapped progress mirror (Progress)
 
   // freed cloud blocks kept for reuse: the odometry path creates and destroys one cloud per sweep, and hipMalloc /
   // hipFree (which synchronises the device) cost more than the upload itself
@@ -1006,6 +1006,7 @@ int hgs_destroy(hgs_handle* h) try {
   h->h_descs.release();
   h->h_results.release();
   h->h_small.release();
+  h->h_comm.release();
   h->h_flags.release();
   for (auto& ev : h->prof_events) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
@@ -1388,7 +1389,13 @@ int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, si
   HGS_HIP(h, h->comm_send.reserve(per * sizeof(hgs_result)));
   HGS_HIP(h, h->comm_recv.reserve((size_t)world * per * sizeof(hgs_result)));
   HGS_HIP(h, h->comm_ids.reserve(std::max<size_t>(n_mine, 1) * sizeof(int32_t)));
-  if (n_mine > 0) HGS_HIP(h, hipMemcpyAsync(h->comm_ids.p, candidate_ids, n_mine * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  // pinned staging on both sides of the exchange (ids in front, the gathered records behind): no pageable copies on the stream
+  const size_t ids_bytes = (std::max<size_t>(n_mine, 1) * sizeof(int32_t) + 15) & ~(size_t)15;
+  HGS_HIP(h, h->h_comm.reserve(ids_bytes + (size_t)world * per * sizeof(hgs_result)));
+  if (n_mine > 0) {
+    std::memcpy(h->h_comm.p, candidate_ids, n_mine * sizeof(int32_t));
+    HGS_HIP(h, hipMemcpyAsync(h->comm_ids.p, h->h_comm.p, n_mine * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  }
   launch_results_to_records(h->stream, h->results.as<DevResult>(), h->comm_ids.as<int>(), (int)n_mine, (int)per, h->comm_send.as<hgs_result>());
   HGS_HIP(h, hipGetLastError());
   char err[256] = "";
@@ -1396,16 +1403,18 @@ int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, si
     h->err = err;
     return HGS_ERR_COMM;
   }
-  std::vector<hgs_result> gathered((size_t)world * per);
-  HGS_HIP(h, hipMemcpyAsync(gathered.data(), h->comm_recv.p, gathered.size() * sizeof(hgs_result), hipMemcpyDeviceToHost, h->stream));
+  const hgs_result* gathered = reinterpret_cast<const hgs_result*>(static_cast<const char*>(h->h_comm.p) + ids_bytes);
+  HGS_HIP(h, hipMemcpyAsync(const_cast<hgs_result*>(gathered), h->comm_recv.p, (size_t)world * per * sizeof(hgs_result), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
   for (size_t i = 0; i < n_total; i++) {  // a candidate no rank reported stays "not converged"
     std::memset(&all_out[i], 0, sizeof(hgs_result));
     all_out[i].candidate_id = (int32_t)i;
     all_out[i].fitness_score = std::numeric_limits<double>::max();
   }
-  for (const hgs_result& r : gathered)
+  for (size_t k = 0; k < (size_t)world * per; k++) {
+    const hgs_result& r = gathered[k];
     if (r.candidate_id >= 0 && (size_t)r.candidate_id < n_total) all_out[r.candidate_id] = r;
+  }
   if (best) HGS_TRY(hgs_select_best(all_out, n_total, best));
   return HGS_OK;
 } catch (...) {
