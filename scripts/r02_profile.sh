@@ -16,7 +16,7 @@ for M in FAST_GICP NDT_OMP; do
   m=$(echo $M | tr A-Z a-z)
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_$m" -o bench -- python "$ROOT/bench.py" --method $M $ARGS > "$ROOT/gpurun_out/prof_$m.log" 2>&1); echo "trace $M exit $?"
   f=$(find gpurun_out/prof_$m -name "*kernel_stats.csv" | head -1)
-  { echo "rocprofv3 --kernel-trace --stats -- python bench.py --method $M $ARGS   (HGS_BATCH_LANES=1)"; echo; echo '```'; tail -1 gpurun_out/prof_$m.log | cut -c1-2500; echo '```'; echo;
+  { echo "rocprofv3 --kernel-trace --stats -- python bench.py --method $M $ARGS   (HGS_BATCH_LANES=1)"; echo; echo '```'; grep '^{' gpurun_out/prof_$m.log | tail -1; echo '```'; echo;
     [ -n "$f" ] && python scripts/prof_summary.py "$f"; } > gpurun_out/r02_${m}_kernel_stats.md
   head -12 gpurun_out/r02_${m}_kernel_stats.md | cut -c1-300
   OUT="$ROOT/gpurun_out/pmc_$m"; mkdir -p "$OUT"
