@@ -178,3 +178,52 @@ def test_hip_reproduces_the_long_ndt_run():
             setattr(p, name, getattr(params, name))
         return RegistrationHIP(p)
     _check_long_ndt_run(make)
+
+
+# ---- third fixture: deskewing, pcl::ApproximateVoxelGrid, the map cloud in octree order (tests/golden/make_golden_v3.py) -----------
+G3 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vlp16_next_rows_v3.npz"))
+
+
+def _v3():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_v3", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_v3.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _xyzi(a):
+    return synth.to_xyzi(a[:, :3], a[:, 3])
+
+
+def test_oracle_reproduces_golden_v3():
+    m = _v3()
+    raw = _xyzi(G3["raw_xyzi"])
+    for name, p, w in m.cases():
+        assert np.array_equal(O.prefilter(raw, p, imu_angular_velocity=w, scan_period=m.SCAN_PERIOD), G3[name]), name
+    kf = [_xyzi(G3[f"kf{k}_xyzi"]) for k in range(3)]
+    assert np.array_equal(O.map_cloud(kf, list(G3["poses"]), m.MAP_RES), G3["map_cloud"])
+
+
+def _check_golden_v3(e):
+    from hdl_graph_slam_amd import _lib as L
+    m = _v3()
+    raw = _xyzi(G3["raw_xyzi"])
+    for name, p, w in m.cases():
+        q = L.HgsPrefilterParams()
+        for f, _ in L.HgsPrefilterParams._fields_:
+            setattr(q, f, getattr(p, f))
+        got = e.prefilter(raw, q, imu_angular_velocity=w, scan_period=m.SCAN_PERIOD).download()
+        assert np.array_equal(np.stack([got["x"], got["y"], got["z"], got["intensity"]], axis=1), G3[name]), name
+    resident = [e.upload(_xyzi(G3[f"kf{k}_xyzi"])) for k in range(3)]
+    got = e.map_cloud(resident, list(G3["poses"]), m.MAP_RES).download()
+    assert np.array_equal(np.stack([got["x"], got["y"], got["z"], got["intensity"]], axis=1), G3["map_cloud"])   # same centres, same order
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_v3():
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    e = RegistrationHIP(L.default_params(L.HGS_FAST_GICP))
+    _check_golden_v3(e)
+    e.close()

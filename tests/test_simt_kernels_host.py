@@ -475,6 +475,14 @@ def test_sharded_batch_entry_point_world_one():
     _sharded_equals_unsharded(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
 
 
+def test_golden_v3_next_rows():
+    """deskewing, pcl::ApproximateVoxelGrid and the octree-ordered map cloud against the committed fixture."""
+    from test_golden import _check_golden_v3
+    e = _engine(O.default_params(O.HGS_FAST_GICP))
+    _check_golden_v3(e)
+    e.close()
+
+
 def test_map_cloud_octree_growth():
     from test_map_cloud import _check_map_growth
     _check_map_growth(lambda: _engine(O.default_params(O.HGS_FAST_GICP)))
