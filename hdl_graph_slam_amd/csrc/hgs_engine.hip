@@ -148,7 +148,7 @@ struct hgs_handle {
   hgs::Comm* comm = nullptr;            // hgs_comm_init: the ranks of a sharded loop-closure batch
   DeviceBuffer comm_send, comm_recv, comm_ids;
   DeviceBuffer ndt_plan;         // per lane: work queue head + tile prefix sums of the running NDT batch
-  int ndt_resident_blocks = 512; // blocks per k_ndt_pass launch (2 per CU); HGS_NDT_RESIDENT (A/B runs)
+  int ndt_resident_blocks = 768; // blocks per k_ndt_pass launch: 2 per CU are resident, the third is the tail filler (512 / 640 / 768 / 896 / 1024 measured on the 64-candidate batch: 1276 / 1281 / 1319 / 1319 / 1291 reg/s); HGS_NDT_RESIDENT (A/B runs)
   int ndt_chunk = 0;             // largest queue grab in items (0: the default, 8; 1 = one tile per grab); HGS_NDT_CHUNK (A/B runs)
   int ndt_sort = -1;       // NDT source order: -1 Hilbert order if the source has an index, 1 build the index first, 0 input order (HGS_NDT_SORT, A/B runs)
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
