@@ -335,7 +335,7 @@ def run_loop_batch(ctx):
         units["covariance"] = units["error"] = 0.0
     roofline = roofline_of(method, prof, units, prof_steps,
                            "whole-device launches (all candidates of the rank in one launch, HIP events on the engine's stream); the timed region "
-                           "runs the same kernels split over up to 4 concurrent lanes, whose launches overlap each other",
+                           "runs the same kernels split over 2 to 4 concurrent lanes (by batch size), whose launches overlap each other",
                            pmc_ok=(sensor == "HDL-64E" and B == 64 and not a.downsample))
 
     # ---- the other scene seeds (informational: spread of the metric over scenes)

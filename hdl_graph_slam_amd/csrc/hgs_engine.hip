@@ -134,8 +134,10 @@ struct hgs_handle {
   hipStream_t lane_stream[3] = {};
   hipEvent_t lane_event[4] = {};
   // measured on the 16 x 120 k-point loop batch: 1 -> 2 -> 4 lanes = 2850 -> 2935 -> 2975 GICP reg/s, 735 -> 772 -> 797 NDT;
-  // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default)
-  int batch_lanes = 4;
+  // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default).  Round 2, 64 x 119 k-point batch:
+  // 1 / 2 / 3 / 4 lanes = 3680 / 3999 / 3937 / 3913 GICP reg/s and 1064 / 1403 / 1384 / 1326 NDT — with 32 problems per lane a lane's
+  // launches fill the device on their own and two chains are enough to cover each other's solves and tails.
+  int batch_lanes = 0;  // 0: by batch size (4 up to 32 problems, 2 above); HGS_BATCH_LANES fixes it (A/B runs)
   std::string err;
   hgs_cloud* target = nullptr;
   hgs_cloud* source = nullptr;
@@ -600,7 +602,8 @@ struct BatchLane {
 // so far (indices, covariances, descriptors, guesses).  Profiling keeps one lane: the stage timers bracket launches on the
 // main stream and are meant to time kernels that have the device to themselves.
 int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t partial_err_bytes_per_problem, std::vector<BatchLane>& lanes) {
-  const int n = h->profiling ? 1 : std::max(1, std::min(std::min(h->batch_lanes, kMaxLanes), B));
+  const int wanted = h->batch_lanes > 0 ? h->batch_lanes : (B <= 32 ? 4 : 2);
+  const int n = h->profiling ? 1 : std::max(1, std::min(std::min(wanted, kMaxLanes), B));
   lanes.assign(n, BatchLane{});
   for (int i = 0, b0 = 0; i < n; i++) {
     BatchLane& L = lanes[i];
