@@ -908,6 +908,8 @@ __device__ __forceinline__ unsigned wave_rows4_u32(unsigned a, unsigned b, unsig
 //   3. the block whose flush completes a problem's tile count turns the totals into doubles, runs the Newton step
 //      (Jacobi-SVD solve on three lanes, step clamp, convergence test, next angle tables) and ticks the batch progress.
 // Algorithmic bytes per source point: 16 + 7*40 = 296 (DIRECT7), 56 (DIRECT1); the cell table of a LiDAR scan is L2-resident.
+__device__ __forceinline__ int ndt_cell_coord(float v) { return (int)floorf(fminf(fmaxf(v, -1.0e9f), 1.0e9f)); }  // NaN -> -1e9
+
 template <int NOFF>
 __device__ __forceinline__ int ndt_pop_cell(unsigned& mask, const int (&ci)[NOFF]) {
   if (!mask) return -1;
@@ -1070,7 +1072,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
         int ci[NOFF];
         unsigned vmask = 0;
         {
-          const int cx = (int)floorf(xt.x * tgt.inv_leaf), cy = (int)floorf(xt.y * tgt.inv_leaf), cz = (int)floorf(xt.z * tgt.inv_leaf);
+          // a transformed source point can be anything (non-finite, 1e30): clamp before the conversion — such a coordinate is
+          // outside every grid either way, and float -> int of a NaN or an out-of-range value is not defined in C++
+          const int cx = ndt_cell_coord(xt.x * tgt.inv_leaf), cy = ndt_cell_coord(xt.y * tgt.inv_leaf), cz = ndt_cell_coord(xt.z * tgt.inv_leaf);
           int key[NOFF];
           unsigned slot[NOFF];
           int2 kv[NOFF];
