@@ -86,6 +86,7 @@ struct Progress {
 };
 
 constexpr int kBlock = 256;
+constexpr int kKnnLeafLog = 128;           // leaves pass 1 of k_knn_cov remembers per wave for pass 2 (more: pass 2 walks the tree)
 constexpr int kNW = 1;                    // packets of 64 queries a wave walks in lock-step in the 1-NN kernels (hgs_wave_bvh.h)
 constexpr int kTileNN = kBlock * kNW;     // source points per block of k_gicp_linearize / k_fitness
 

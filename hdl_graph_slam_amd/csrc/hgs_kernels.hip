@@ -342,7 +342,10 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   const F3 q = {qp.x, qp.y, qp.z};
   const int live = k < KMAX ? k : KMAX;
   __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][32];
+  __shared__ unsigned leaf_log[kBlock / 64][kKnnLeafLog];
   float* slot = walk_slots[threadIdx.x >> 6];
+  LeafLog log = {leaf_log[threadIdx.x >> 6], kKnnLeafLog, 0};
+  const int i0 = i - lane;
   float r2;
   int ties;
   {
@@ -352,7 +355,6 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
     // The wave's own 64 points (8 whole leaves of the Hilbert order) are every lane's first candidates: all-pairs
     // through v_readlane, no memory traffic — the walk then starts with every list full and a bound within ~1.2x of
     // the final radius instead of +inf, which is what keeps it from wandering (3x fewer insertions and leaves).
-    const int i0 = i - lane;
     const int own = min(qpw, n - i0);
     for (int jj = 0; jj < own; jj++) {
       const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), jj)), py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), jj)),
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
       w[0].start(tv, q, height);
       w[0].order_lane = qpw >> 1;
       w[0].skip_lo = (unsigned)(tv.P + (i0 >> 3)), w[0].skip_n = (unsigned)(qpw >> 3);
-      wave_walk_multi<KnnRadiusLane<KMAX>, 1>(tv, w, slot);
+      wave_walk_multi<KnnRadiusLane<KMAX>, 1>(tv, w, slot, &log);
     }
     r2 = w[0].lane.worst();
     int n_lt = 0;
@@ -377,13 +379,39 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   Sym3 s2;
   int found;
   if (__ballot(active && ties > 1) == 0ull) {
-    PacketWalk<KnnGatherLane<1>> g[1];
-    g[0].lane.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
-    g[0].start(tv, q, height);
-    g[0].order_lane = qpw >> 1;
-    wave_walk_multi<KnnGatherLane<1>, 1>(tv, g, slot);
-    g[0].lane.finish(d.pts);
-    const KnnGatherLane<1>& L = g[0].lane;
+    KnnGatherLane<1> L;
+    L.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
+    if (n > qpw && log.count <= log.cap) {
+      // No second tree walk: every leaf with a point within r2 of some lane (box_d2 <= r2 <= the bound pass 1 had when it met the
+      // leaf) is either one of the wave's own 8 leaves or in pass 1's log.  The records are fetched by index, so the next one is
+      // in flight while the current one is summed — no dependent chain, no box tests.
+      const int n_own = qpw >> 3, total = n_own + log.count;
+      const hgs_f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+      const int l32 = lane & 31;
+      unsigned leaf = (unsigned)(i0 >> 3);  // leaf index (node id - P)
+      float v = reinterpret_cast<const float*>(tv.lpts + 8 * (size_t)leaf)[l32];
+      for (int j = 0; j < total; j++) {
+        __builtin_amdgcn_wave_barrier();  // the previous record's reads are issued before the slot is overwritten
+        slot[l32] = v;
+        __builtin_amdgcn_wave_barrier();
+        const hgs_f16v* r = reinterpret_cast<const hgs_f16v*>(slot);
+        const hgs_f16v lo = r[0], hi = r[1];
+        const unsigned this_leaf = leaf;
+        if (j + 1 < total) {
+          leaf = j + 1 < n_own ? (unsigned)(i0 >> 3) + (unsigned)(j + 1) : log.ids[j + 1 - n_own] - (unsigned)tv.P;
+          v = reinterpret_cast<const float*>(tv.lpts + 8 * (size_t)leaf)[l32];
+        }
+        L.visit_leaf(lo, hi, qx, qy, qz, (int)this_leaf * kLeaf);
+      }
+    } else {
+      PacketWalk<KnnGatherLane<1>> g[1];
+      g[0].lane = L;
+      g[0].start(tv, q, height);
+      g[0].order_lane = qpw >> 1;
+      wave_walk_multi<KnnGatherLane<1>, 1>(tv, g, slot);
+      L = g[0].lane;
+    }
+    L.finish(d.pts);
     s1[0] = L.s1[0], s1[1] = L.s1[1], s1[2] = L.s1[2], found = L.found;
     s2 = Sym3{L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
   } else {

@@ -172,16 +172,28 @@ __device__ __forceinline__ void fetch_record(const hgs_f16v* rec, float* slot /*
   lo = r[0], hi = r[1];
 }
 
+// The leaves a walk visited, in order (wave-uniform; ids in wave-private LDS).  count may run past cap: the list is then
+// incomplete and the caller must not use it.
+struct LeafLog {
+  unsigned* ids;
+  int cap, count;
+};
+
 // NW independent packet walks in lock-step (NW = 1 everywhere today: with VGPR-resident records occupancy provides the
 // overlap; the multi-walk form is kept because it costs nothing at NW = 1).
 template <class Lane, int NW>
-__device__ __forceinline__ void wave_walk_multi(const BvhView& t, PacketWalk<Lane> (&w)[NW], float* slots /* NW * 32 floats, wave-private LDS */) {
+__device__ __forceinline__ void wave_walk_multi(const BvhView& t, PacketWalk<Lane> (&w)[NW], float* slots /* NW * 32 floats, wave-private LDS */,
+                                                LeafLog* log = nullptr /* NW == 1 only */) {
   const int k = 31 - __clz(t.P);  // P = 2^k leaves
   for (;;) {
     bool alive = false;
 #pragma unroll
     for (int i = 0; i < NW; i++) alive = alive || w[i].kind != WALK_DONE;
     if (!alive) return;
+    if (NW == 1 && log && w[0].kind == WALK_LEAF) {
+      if (log->count < log->cap && (__lane_id() & 63u) == 0u) log->ids[log->count] = w[0].ldnode;
+      log->count++;
+    }
     hgs_f16v lo[NW], hi[NW];
 #pragma unroll
     for (int i = 0; i < NW; i++) fetch_record(w[i].record(t), slots + 32 * i, lo[i], hi[i]);
@@ -255,7 +267,11 @@ struct KnnRadiusLane {
     for (int i = 0; i < KMAX; i++) d[i] = (!active || i < KMAX - k) ? -1.f : FLT_MAX;
   }
   __device__ __forceinline__ float worst() const { return d[KMAX - 1]; }
-  __device__ __forceinline__ bool wants(float box_d2) const { return box_d2 < worst(); }
+  // <=, not <: a leaf whose box is exactly as far as the current k-th distance cannot shorten the list, but it may hold a point AT
+  // the final k-th distance — one of the equidistant candidates the gather pass chooses from by original index.  With <= the
+  // leaves this walk visits are a superset of the leaves the gather pass needs (box_d2 <= r2 <= worst at any time), which is what
+  // lets k_knn_cov replay the visited leaves instead of walking the tree a second time.
+  __device__ __forceinline__ bool wants(float box_d2) const { return box_d2 <= worst(); }
   __device__ __forceinline__ void insert(float x) {  // x < worst()
 #pragma unroll
     for (int i = KMAX - 1; i > 0; i--) d[i] = __builtin_amdgcn_fmed3f(d[i - 1], d[i], x);
