@@ -317,9 +317,13 @@ void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 //   1. the squared distance r2 of the k-th nearest neighbour — a sorted list of k DISTANCES only (one v_med3_f32 per
 //      slot and insertion; keeping the positions sorted alongside costs 4x as many instructions and this kernel is
 //      VALU bound, see profiles/),
-//   2. a second walk bounded by r2 that sums (p - q) and (p - q)(p - q)^T over exactly the k nearest points (those
-//      closer than r2 plus, of those at exactly r2, as many as the list held, lowest original index first like a
-//      kd-tree k-NN orders equal distances) — the covariance needs the set, not its order.
+//   2. a gather bounded by r2 that sums (p - q) and (p - q)(p - q)^T over exactly the k nearest points (those closer than r2
+//      plus, of those at exactly r2, as many as the list held, lowest original index first like a kd-tree k-NN orders equal
+//      distances) — the covariance needs the set, not its order.  The gather does not walk the tree again: pass 1 logs the
+//      leaves it visits, and because it prunes with box_d2 <= bound (never tighter than the final r2) that log plus the wave's own
+//      8 leaves holds every leaf with a point within r2 of some lane; their records are fetched by index, the next one in flight
+//      while the current one is summed.  The tree is walked a second time only when the log overflows (kKnnLeafLog leaves) or a
+//      lane needs several points at exactly its k-th distance.
 // Algorithmic bytes per point: 16 (query) + k*16 (neighbours) + 24 (cov).
 // qpw = queries per wave (64, or fewer — a multiple of 8 — when the whole launch is too small to fill the chip: shorter
 // packets walk fewer nodes, so the dependent-load chain that bounds a small launch gets shorter; lanes >= qpw idle).
