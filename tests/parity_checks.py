@@ -57,6 +57,28 @@ def check_covariances(engine, tgt, k=20, method=O.HGS_REG_FROBENIUS):
     assert rel.max() < 5e-6, f"covariance mismatch: max rel {rel.max():.3e}"
 
 
+def outlier_cloud(seed=5, n_dense=3000, n_far=40):
+    """A dense blob plus a few scattered far points: the k nearest neighbours of a far point are spread over the whole blob, so
+    the wave that holds it visits hundreds of leaves in the radius pass — more than k_knn_cov's leaf log holds (the gather pass
+    then walks the tree instead of replaying the log), next to waves that stay well inside it."""
+    rng = np.random.default_rng(seed)
+    blob = rng.normal(0, 0.4, (n_dense, 3))
+    far = rng.uniform(-60, 60, (n_far, 3)) * [1, 1, 0.1]
+    pts = np.concatenate([blob, far]).astype(np.float32)
+    return synth.to_xyzi(pts[rng.permutation(len(pts))])
+
+
+def check_covariances_with_outliers(make_engine):
+    for k in (20, 48):
+        p = O.default_params(O.HGS_FAST_GICP)
+        p.correspondence_randomness = k
+        e = make_engine(p)
+        cloud = outlier_cloud()
+        e.setInputTarget(cloud)
+        check_covariances(e, cloud, k)
+        e.close()
+
+
 def check_gicp_linearize(engine, oracle, T, err_rel=1e-6):
     He, be, ee, ce = engine.gicp_linearize(T)
     Ho, bo, eo, co = oracle.gicp_linearize(T)

@@ -69,6 +69,11 @@ def test_covariances_with_equidistant_neighbours():
         e.close()
 
 
+def test_covariances_when_the_leaf_log_overflows():
+    """k_knn_cov with lanes whose k-NN ball covers hundreds of leaves: the gather pass falls back from the logged leaves to the tree."""
+    PC.check_covariances_with_outliers(_hip)
+
+
 @pytest.mark.parametrize("method", [O.HGS_REG_PLANE, O.HGS_REG_NORMALIZED_MIN_EIG, O.HGS_REG_NONE])
 def test_covariance_regularization_methods(method):
     """fast_gicp::RegularizationMethod other than the FROBENIUS default: covariances, one linearisation and a full

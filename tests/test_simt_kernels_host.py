@@ -84,6 +84,10 @@ def test_covariances_with_equidistant_neighbours(k):
     e.close()
 
 
+def test_covariances_when_the_leaf_log_overflows():
+    PC.check_covariances_with_outliers(_engine)
+
+
 def test_gicp_linearize_align_fitness(gicp_case):
     e, o, tgt, src, T = gicp_case
     PC.check_gicp_linearize(e, o, T.astype(np.float32).astype(np.float64))
