@@ -97,7 +97,7 @@ void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals);
 void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int max_slots, const unsigned* sorted_vals);
 void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int max_P);
-void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method);
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, bool replay);
 
 void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog);
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B,

@@ -137,6 +137,7 @@ struct hgs_handle {
   // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default).  Round 2, 64 x 119 k-point batch:
   // 1 / 2 / 3 / 4 lanes = 3680 / 3999 / 3937 / 3913 GICP reg/s and 1064 / 1403 / 1384 / 1326 NDT — with 32 problems per lane a lane's
   // launches fill the device on their own and two chains are enough to cover each other's solves and tails.
+  int knn_replay = -1;  // k_knn_cov gather: -1 by launch shape, 0 tree walk, 1 leaf-log replay; HGS_KNN_REPLAY (A/B runs, tests)
   int batch_lanes = 0;  // 0: by batch size (4 up to 32 problems, 2 above); HGS_BATCH_LANES fixes it (A/B runs)
   std::string err;
   hgs_cloud* target = nullptr;
@@ -397,8 +398,10 @@ int ensure_cov(hgs_handle* h, const std::vector<hgs_cloud*>& all, int k) {
   for (hgs_cloud* c : todo) max_n = std::max(max_n, (int)c->n_input);
   size_t total_q = 0;
   for (hgs_cloud* c : todo) total_q += c->n_input;
-  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, queries_per_wave(total_q, 32),  // >= k points in the pre-fill window
-                 h->prm.regularization_method);
+  const int qpw = queries_per_wave(total_q, 32);  // >= k points in the pre-fill window
+  // the leaf-log gather pays for batches of LiDAR keyframes, not for one or two (dense) clouds: see launch_knn_cov
+  const bool replay = h->knn_replay >= 0 ? h->knn_replay != 0 : (todo.size() >= 8 && qpw == 64);
+  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, qpw, h->prm.regularization_method, replay);
   HGS_HIP(h, hipGetLastError());
   HGS_HIP(h, hipStreamSynchronize(h->stream));
   for (hgs_cloud* c : todo) c->has_cov = true, c->cov_k = key;
@@ -963,6 +966,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
   for (int i = 0; i < HGS_STAGE_COUNT; i++) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
   if (const char* e = std::getenv("HGS_BATCH_LANES")) h->batch_lanes = std::max(1, std::min(kMaxLanes, std::atoi(e)));  // A/B measurements
   if (const char* e = std::getenv("HGS_NDT_SORT")) h->ndt_sort = std::max(-1, std::min(1, std::atoi(e)));
+  if (const char* e = std::getenv("HGS_KNN_REPLAY")) h->knn_replay = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("HGS_NDT_RESIDENT")) h->ndt_resident_blocks = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("HGS_NDT_CHUNK")) h->ndt_chunk = std::max(0, std::atoi(e));
   if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -319,17 +319,18 @@ void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 //      VALU bound, see profiles/),
 //   2. a gather bounded by r2 that sums (p - q) and (p - q)(p - q)^T over exactly the k nearest points (those closer than r2
 //      plus, of those at exactly r2, as many as the list held, lowest original index first like a kd-tree k-NN orders equal
-//      distances) — the covariance needs the set, not its order.  The gather does not walk the tree again: pass 1 logs the
+//      distances) — the covariance needs the set, not its order.  With REPLAY the gather does not walk the tree again: pass 1 logs the
 //      leaves it visits, and because it prunes with box_d2 <= bound (never tighter than the final r2) that log plus the wave's own
 //      8 leaves holds every leaf with a point within r2 of some lane; their records are fetched by index, the next one in flight
 //      while the current one is summed.  The tree is walked a second time only when the log overflows (kKnnLeafLog leaves) or a
-//      lane needs several points at exactly its k-th distance.
+//      lane needs several points at exactly its k-th distance.  Without REPLAY (one or two clouds, dense clouds: launch_knn_cov)
+//      pass 2 is a second walk bounded by r2.
 // Algorithmic bytes per point: 16 (query) + k*16 (neighbours) + 24 (cov).
 // qpw = queries per wave (64, or fewer — a multiple of 8 — when the whole launch is too small to fill the chip: shorter
 // packets walk fewer nodes, so the dependent-load chain that bounds a small launch gets shorter; lanes >= qpw idle).
 // REG_GENERAL = false: FROBENIUS (the mode hdl_graph_slam runs); true: any hgs_regularization (3x3 eigen-decomposition per
 // point), a separate instantiation so that the default kernel carries none of it.
-template <int KMAX, bool REG_GENERAL>
+template <int KMAX, bool REG_GENERAL, bool REPLAY>
 __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int k, int qpw, int reg_method) {
   const CloudDesc d = descs[blockIdx.y];
   const int n = d.meta->nvalid;
@@ -346,15 +347,15 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   const F3 q = {qp.x, qp.y, qp.z};
   const int live = k < KMAX ? k : KMAX;
   __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][32];
-  __shared__ unsigned leaf_log[kBlock / 64][kKnnLeafLog];
+  __shared__ unsigned leaf_log[REPLAY ? kBlock / 64 : 1][REPLAY ? kKnnLeafLog : 1];
   float* slot = walk_slots[threadIdx.x >> 6];
-  LeafLog log = {leaf_log[threadIdx.x >> 6], kKnnLeafLog, 0};
+  LeafLog log = {leaf_log[REPLAY ? threadIdx.x >> 6 : 0], REPLAY ? kKnnLeafLog : 0, 0};
   const int i0 = i - lane;
   float r2;
   int ties;
   {
-    PacketWalk<KnnRadiusLane<KMAX>> w[1];
-    KnnRadiusLane<KMAX>& L = w[0].lane;
+    PacketWalk<KnnRadiusLane<KMAX, REPLAY>> w[1];
+    KnnRadiusLane<KMAX, REPLAY>& L = w[0].lane;
     L.init(live, active);
     // The wave's own 64 points (8 whole leaves of the Hilbert order) are every lane's first candidates: all-pairs
     // through v_readlane, no memory traffic — the walk then starts with every list full and a bound within ~1.2x of
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
       w[0].start(tv, q, height);
       w[0].order_lane = qpw >> 1;
       w[0].skip_lo = (unsigned)(tv.P + (i0 >> 3)), w[0].skip_n = (unsigned)(qpw >> 3);
-      wave_walk_multi<KnnRadiusLane<KMAX>, 1>(tv, w, slot, &log);
+      wave_walk_multi<KnnRadiusLane<KMAX, REPLAY>, 1>(tv, w, slot, REPLAY ? &log : nullptr);
     }
     r2 = w[0].lane.worst();
     int n_lt = 0;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   if (__ballot(active && ties > 1) == 0ull) {
     KnnGatherLane<1> L;
     L.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
-    if (n > qpw && log.count <= log.cap) {
+    if (REPLAY && n > qpw && log.count <= log.cap) {
       // No second tree walk: every leaf with a point within r2 of some lane (box_d2 <= r2 <= the bound pass 1 had when it met the
       // leaf) is either one of the wave's own 8 leaves or in pass 1's log.  The records are fetched by index, so the next one is
       // in flight while the current one is summed — no dependent chain, no box tests.
@@ -442,20 +443,28 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   d.cov[2 * i] = make_float4((float)c.xx, (float)c.xy, (float)c.xz, (float)c.yy);
   d.cov[2 * i + 1] = make_float4((float)c.yz, (float)c.zz, 0.f, 0.f);
 }
-template <bool REG_GENERAL>
+template <bool REG_GENERAL, bool REPLAY>
 static void launch_knn_cov_t(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method) {
   const int tile_pts = (kBlock / 64) * qpw;
   const dim3 grid((max_n + tile_pts - 1) / tile_pts, ncloud), block(kBlock);
-  if (k <= 8) hipLaunchKernelGGL((k_knn_cov<8, REG_GENERAL>), grid, block, 0, s, descs, k, qpw, reg_method);
-  else if (k <= 16) hipLaunchKernelGGL((k_knn_cov<16, REG_GENERAL>), grid, block, 0, s, descs, k, qpw, reg_method);
-  else if (k <= 20) hipLaunchKernelGGL((k_knn_cov<20, REG_GENERAL>), grid, block, 0, s, descs, k, qpw, reg_method);
-  else if (k <= 32) hipLaunchKernelGGL((k_knn_cov<32, REG_GENERAL>), grid, block, 0, s, descs, k, qpw, reg_method);
-  else hipLaunchKernelGGL((k_knn_cov<64, REG_GENERAL>), grid, block, 0, s, descs, k < 64 ? k : 64, qpw, reg_method);
+  if (k <= 8) hipLaunchKernelGGL((k_knn_cov<8, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
+  else if (k <= 16) hipLaunchKernelGGL((k_knn_cov<16, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
+  else if (k <= 20) hipLaunchKernelGGL((k_knn_cov<20, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
+  else if (k <= 32) hipLaunchKernelGGL((k_knn_cov<32, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
+  else hipLaunchKernelGGL((k_knn_cov<64, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k < 64 ? k : 64, qpw, reg_method);
 }
-void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method) {
+// replay: the gather pass replays pass 1's leaf log instead of walking the tree again.  Measured (same-box A/B): 64 LiDAR clouds in one
+// launch 6.28 -> 6.14 ms; a single HDL-32E pair 0.33 -> 0.41 ms and a dense 1 M-point pair 1.91 -> 2.15 ms (a dense cloud's first walk
+// visits far more leaves than the gather needs) — hence two instantiations and a choice per launch (hgs_engine.hip).
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, bool replay) {
   if (max_n <= 0) return;
-  if (reg_method == 0) launch_knn_cov_t<false>(s, descs, ncloud, max_n, k, qpw, reg_method);
-  else launch_knn_cov_t<true>(s, descs, ncloud, max_n, k, qpw, reg_method);
+  if (reg_method == 0) {
+    if (replay) launch_knn_cov_t<false, true>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    else launch_knn_cov_t<false, false>(s, descs, ncloud, max_n, k, qpw, reg_method);
+  } else {
+    if (replay) launch_knn_cov_t<true, true>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    else launch_knn_cov_t<true, false>(s, descs, ncloud, max_n, k, qpw, reg_method);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ GICP iteration

@@ -259,7 +259,8 @@ __device__ __forceinline__ void wave_nn1(const BvhView& t, float* slots, const F
 
 // ---- k-NN radius: sorted list of the k smallest squared distances only (no positions) -----------------------------
 // With d ascending, inserting x makes the new d[i] the median of (d[i-1], d[i], x): one v_med3_f32 per slot.
-template <int KMAX>
+// INCLUSIVE: prune with box_d2 <= bound instead of <, see wants().
+template <int KMAX, bool INCLUSIVE = false>
 struct KnnRadiusLane {
   float d[KMAX];  // slots [KMAX-k, KMAX) are live, the others hold -1 and never move
   __device__ __forceinline__ void init(int k, bool active) {
@@ -267,11 +268,11 @@ struct KnnRadiusLane {
     for (int i = 0; i < KMAX; i++) d[i] = (!active || i < KMAX - k) ? -1.f : FLT_MAX;
   }
   __device__ __forceinline__ float worst() const { return d[KMAX - 1]; }
-  // <=, not <: a leaf whose box is exactly as far as the current k-th distance cannot shorten the list, but it may hold a point AT
-  // the final k-th distance — one of the equidistant candidates the gather pass chooses from by original index.  With <= the
-  // leaves this walk visits are a superset of the leaves the gather pass needs (box_d2 <= r2 <= worst at any time), which is what
-  // lets k_knn_cov replay the visited leaves instead of walking the tree a second time.
-  __device__ __forceinline__ bool wants(float box_d2) const { return box_d2 <= worst(); }
+  // INCLUSIVE (<= instead of <): a leaf whose box is exactly as far as the current k-th distance cannot shorten the list, but it may
+  // hold a point AT the final k-th distance — one of the equidistant candidates the gather pass chooses from by original index.
+  // With <= the leaves this walk visits are a superset of the leaves the gather pass needs (box_d2 <= r2 <= worst at any time),
+  // which is what lets k_knn_cov<.., REPLAY> replay the visited leaves instead of walking the tree a second time.
+  __device__ __forceinline__ bool wants(float box_d2) const { return INCLUSIVE ? box_d2 <= worst() : box_d2 < worst(); }
   __device__ __forceinline__ void insert(float x) {  // x < worst()
 #pragma unroll
     for (int i = KMAX - 1; i > 0; i--) d[i] = __builtin_amdgcn_fmed3f(d[i - 1], d[i], x);

@@ -68,6 +68,28 @@ def outlier_cloud(seed=5, n_dense=3000, n_far=40):
     return synth.to_xyzi(pts[rng.permutation(len(pts))])
 
 
+def check_covariances_both_gathers(make_engine):
+    """k_knn_cov's two gather passes — the tree walk and the replay of pass 1's leaf log (HGS_KNN_REPLAY forces either, the engine
+    otherwise chooses by launch shape) — on a LiDAR scan, a tie-heavy cloud and the outlier cloud whose log overflows."""
+    import os
+    scene = synth.make_scene(3)
+    clouds = [synth.scan(scene, "VLP-16", synth.pose_matrix([0, 0, 0], [0, 0, 0]), 31), tie_heavy_cloud(), outlier_cloud()]
+    old = os.environ.get("HGS_KNN_REPLAY")
+    try:
+        for replay in ("0", "1"):
+            os.environ["HGS_KNN_REPLAY"] = replay          # read in hgs_create
+            for cloud in clouds:
+                e = make_engine(O.default_params(O.HGS_FAST_GICP))
+                e.setInputTarget(cloud)
+                check_covariances(e, cloud, 20)
+                e.close()
+    finally:
+        if old is None:
+            os.environ.pop("HGS_KNN_REPLAY", None)
+        else:
+            os.environ["HGS_KNN_REPLAY"] = old
+
+
 def check_covariances_with_outliers(make_engine):
     for k in (20, 48):
         p = O.default_params(O.HGS_FAST_GICP)

@@ -69,6 +69,10 @@ def test_covariances_with_equidistant_neighbours():
         e.close()
 
 
+def test_covariances_with_both_gather_passes():
+    PC.check_covariances_both_gathers(_hip)
+
+
 def test_covariances_when_the_leaf_log_overflows():
     """k_knn_cov with lanes whose k-NN ball covers hundreds of leaves: the gather pass falls back from the logged leaves to the tree."""
     PC.check_covariances_with_outliers(_hip)

@@ -84,6 +84,10 @@ def test_covariances_with_equidistant_neighbours(k):
     e.close()
 
 
+def test_covariances_with_both_gather_passes():
+    PC.check_covariances_both_gathers(_engine)
+
+
 def test_covariances_when_the_leaf_log_overflows():
     PC.check_covariances_with_outliers(_engine)
 
