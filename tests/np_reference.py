@@ -274,3 +274,72 @@ def vgicp_linearize(src, tgt, cov_s, cov_t, T, resolution, offsets=((0, 0, 0),))
             b += J.T @ M @ e
             err += e @ M @ e
     return H, b, err, hits
+
+
+# ---- LsqRegistration::computeTransformation / step_lm / is_converged, the GICP control path -----------
+def gicp_error_frozen(src, tgt, T, corr, maha):
+    """compute_error: the correspondences and Mahalanobis matrices of the last linearisation, residuals at T."""
+    q = np.asarray(src, np.float64) @ T[:3, :3].T + T[:3, 3]
+    v = corr >= 0
+    e = np.asarray(tgt, np.float64)[corr[v]] - q[v]
+    return float(np.einsum("ni,nij,nj->", e, maha[v], e))
+
+
+def gicp_align(src, tgt, cov_s, cov_t, guess, max_corr=2.5, max_iterations=64, rot_eps=2e-3, trans_eps=0.01, lm_max_iterations=10,
+               lm_init_lambda_factor=1e-9):
+    """The whole LM run written from the text of Appendix A.2 (not from oracle/gicp.hpp): returns (final T, outer iterations,
+    converged, total LM tries).  The correspondence search follows update_correspondences: the query is T a_i in FLOAT."""
+    src, tgt = np.asarray(src, np.float64), np.asarray(tgt, np.float64)
+    tree = cKDTree(tgt)
+
+    def is_converged(delta):
+        return max(np.abs(delta[:3, :3] - np.eye(3)).max() / rot_eps, np.abs(delta[:3, 3]).max() / trans_eps) < 1.0
+
+    def linearize(T):
+        R, t = T[:3, :3], T[:3, 3]
+        Tf = T.astype(np.float32)
+        q32 = (src.astype(np.float32) @ Tf[:3, :3].T + Tf[:3, 3]).astype(np.float64)   # the search point is a float cloud
+        d, j = tree.query(q32)
+        corr = np.where(d * d < max_corr**2, j, -1)
+        v = corr >= 0
+        maha = np.zeros((len(src), 3, 3))
+        maha[v] = np.linalg.inv(cov_t[corr[v]] + R @ cov_s[v] @ R.T)
+        q = src @ R.T + t
+        H, b, err = np.zeros((6, 6)), np.zeros(6), 0.0
+        for i in np.flatnonzero(v):
+            e = tgt[corr[i]] - q[i]
+            J = np.hstack([skew(q[i]), -np.eye(3)])
+            H += J.T @ maha[i] @ J
+            b += J.T @ maha[i] @ e
+            err += e @ maha[i] @ e
+        return err, H, b, corr, maha
+
+    x0 = np.array(guess, np.float64)
+    lam, converged, iterations, tries_total = -1.0, False, 0, 0
+    while iterations < max_iterations and not converged:
+        iterations += 1
+        y0, H, b, corr, maha = linearize(x0)
+        if lam < 0:
+            lam = lm_init_lambda_factor * np.abs(np.diag(H)).max()
+        nu, stepped, delta = 2.0, False, np.eye(4)
+        for _ in range(lm_max_iterations):
+            tries_total += 1
+            d = np.linalg.solve(H + lam * np.eye(6), -b)
+            delta = se3_exp(d)
+            xi = delta @ x0
+            yi = gicp_error_frozen(src, tgt, xi, corr, maha)
+            rho = (y0 - yi) / (d @ (lam * d - b))
+            if rho < 0:
+                if is_converged(delta):
+                    stepped = True
+                    break
+                lam, nu = nu * lam, 2 * nu
+                continue
+            x0 = xi
+            lam = lam * max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+            stepped = True
+            break
+        if not stepped:          # "lm not converged!!": the outer loop breaks
+            break
+        converged = is_converged(delta)
+    return x0, iterations, converged, tries_total

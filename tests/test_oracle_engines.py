@@ -36,6 +36,24 @@ def test_gicp_linearize_matches_numpy(small_pair):
     assert np.allclose(H, H.T, atol=1e-9 * scale)
 
 
+def test_gicp_lm_run_matches_the_independent_numpy_restatement(small_pair):
+    """LsqRegistration's control path (lambda initialisation and updates, the gain ratio, acceptance, is_converged, the outer loop)
+    exists once in C++ (oracle/gicp.hpp) and once here in numpy, written from SURVEY Appendix A.2: same final pose, the same
+    number of outer iterations and LM tries, from two different starting errors."""
+    tgt, src, T = small_pair
+    src = src[:1200]
+    xs, xt = synth.xyz_of(src), synth.xyz_of(tgt)
+    cs, ct = NP.gicp_covariances(xs), NP.gicp_covariances(xt)
+    for twist in ([0.01, -0.02, 0.015, 0.1, -0.05, 0.02], [-0.03, 0.02, 0.04, -0.25, 0.2, 0.05]):
+        guess = (T @ NP.se3_exp(twist)).astype(np.float32).astype(np.float64)
+        r = _gicp(tgt, src)
+        res = r.align(guess)
+        Tn, it, conv, tries = NP.gicp_align(xs, xt, cs, ct, guess)
+        dt, dr = synth.pose_error(res.matrix(), Tn)
+        assert bool(res.converged) == conv and res.iterations == it and res.lm_tries == tries, (res.iterations, it, res.lm_tries, tries)
+        assert dt < 2e-5 and dr < 2e-5, (dt, dr)       # float final_transformation_ + float-vs-double covariances
+
+
 def test_gicp_gradient_finite_difference(small_pair):
     """b = J^T M e with the correspondences and M frozen: d/d(delta) sum e^T M e = 2 b at delta = 0."""
     tgt, src, T = small_pair
