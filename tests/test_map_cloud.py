@@ -171,6 +171,13 @@ def _check_map_growth(make_engine):
         ref = O.map_cloud(halves, poses, res)
         got = np.stack([m["x"], m["y"], m["z"], m["intensity"]], axis=1)
         assert got.shape == ref.shape and np.array_equal(got, ref), trial      # same voxels in the same (octree traversal) order
+    # nothing finite: an empty map, not an error; one finite point: the single voxel whose corner it sits on
+    nan = synth.to_xyzi(np.full((5, 3), np.nan, np.float32))
+    assert reg.map_cloud([reg.upload(nan)], [np.eye(4)], 0.5).size == 0 and len(O.map_cloud([nan], [np.eye(4)], 0.5)) == 0
+    one = synth.to_xyzi(np.array([[np.nan, 0, 0], [1.0, 2.0, 3.0]], np.float32))
+    m = reg.map_cloud([reg.upload(one)], [np.eye(4)], 0.5).download()
+    ref = O.map_cloud([one], [np.eye(4)], 0.5)
+    assert len(m) == 1 and np.array_equal(np.stack([m["x"], m["y"], m["z"], m["intensity"]], axis=1), ref)
     # deeper than 21 levels: refused, not wrong
     from hdl_graph_slam_amd.registration import HgsError
     far = synth.to_xyzi(np.array([[0, 0, 0], [3.0e5, 0, 0]], np.float32))
