@@ -13,6 +13,7 @@ import os
 import sys
 import time
 import traceback
+import zlib
 
 import numpy as np
 
@@ -65,10 +66,11 @@ def make_engine(params):
 
 
 BACKEND = "emul"
+GUESS_SALT = 0
 
 
 def run_case(name, tgt, src, T, quick):
-    rng = np.random.default_rng(abs(hash(name)) % (1 << 31))
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + GUESS_SALT)   # (str hash() is salted per process: not reproducible)
     near = T @ synth.pose_matrix(rng.normal(0, 0.1, 3), rng.normal(0, 0.01, 3))
     done = []
     # ---- exact search + covariances + GICP
@@ -120,9 +122,10 @@ def main():
     ap.add_argument("--seed-base", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--backend", default="emul", choices=["emul", "simt"])
+    ap.add_argument("--guess-salt", type=int, default=0, help="added to the per-case seed of the random guesses (another draw of guesses)")
     args = ap.parse_args()
-    global BACKEND
-    BACKEND = args.backend
+    global BACKEND, GUESS_SALT
+    BACKEND, GUESS_SALT = args.backend, args.guess_salt
     if BACKEND == "simt":
         from emul import simt
         from hdl_graph_slam_amd import _lib as L
