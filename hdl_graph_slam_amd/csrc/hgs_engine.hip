@@ -239,7 +239,7 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   const size_t o_lpts = off;
   off = align_up(off + slots * sizeof(float4), 256);
   const size_t o_nodes = off;
-  off = align_up(off + ((size_t)4 * c->P + 8) * sizeof(float4), 256);  // + one 128-byte group: the 4-ary walk reads whole groups
+  off = align_up(off + ((size_t)4 * c->P + 32) * sizeof(float4), 256);  // + four 128-byte groups: the 4-ary walks read whole groups, the quad walk four at a time
   const size_t o_cov = off;
   off = align_up(off + 2 * slots * sizeof(float4), 256);
   const size_t o_corr = off;

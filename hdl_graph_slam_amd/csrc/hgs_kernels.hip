@@ -28,6 +28,12 @@ namespace hgs {
 // lane id recomputed where it is needed (2 VALU) instead of kept in a register across a long search: not CSE'd with an earlier one
 #define HGS_LANE_ID(dst) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(dst))
 #endif
+#ifndef HGS_LINEARIZE_WAVES
+#define HGS_LINEARIZE_WAVES 7  // waves per SIMD k_gicp_linearize is compiled for (A/B knob)
+#endif
+#ifndef HGS_FITNESS_WAVES
+#define HGS_FITNESS_WAVES 8
+#endif
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -495,11 +501,44 @@ __device__ __forceinline__ Sym3 load_cov_stream(const float4* cov, int i) {
   return sym3_from_floats(a.x, a.y, a.z, a.w, b.x, b.y);
 }
 
+// The waves of a block leave without waiting for each other (their walks end 30-40 k cycles apart: the closing __syncthreads of
+// round 2 cost ~20 % of a wave's lifetime): each wave has put its N sums into its LDS row, lane 0 takes a ticket, and the wave
+// that takes the last one adds the four rows in wave order — the same fixed order as before, so the tile partial is bitwise
+// what the block-wide reduction produced.  `arrivals` is zeroed by thread 0 before the block's opening barrier.
+template <int N>
+__device__ __forceinline__ void last_wave_stores(const double* lds /* [4 * N] */, unsigned* arrivals, double* out, int lane) {
+  unsigned ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  ticket = (unsigned)__builtin_amdgcn_readlane((int)ticket, 0);
+  if (ticket == kBlock / 64 - 1 && lane < N) out[lane] = (lds[lane] + lds[N + lane]) + (lds[2 * N + lane] + lds[3 * N + lane]);
+}
+
+// Exact 1-NN of one packet of queries for the kernels below: the quad walk (hgs_wave_bvh.h), nearest-first only when some lane
+// has no seed; position and original index resolved from the lane's best leaf, or — when some lane reached its minimum in two
+// leaves — by the exact keyed walk.  pos < 0: no target point within bound2.
+__device__ __forceinline__ void packet_nn1(const BvhView& tv, float* park, const F3& q, bool active, float bound2, int seed, int qpw, float& d2, int& pos, int& orig) {
+  const bool seeded = seed >= 0 && seed < tv.n;
+  int leaf;
+  bool tie, found;
+  if (__ballot(active && !seeded) != 0ull) wave_nn1_quad<true, true>(tv, park, q, active, bound2, seed, qpw >> 1, d2, leaf, tie, found);
+  else wave_nn1_quad<false, true>(tv, park, q, active, bound2, seed, qpw >> 1, d2, leaf, tie, found);
+  if (__ballot(tie) != 0ull) {
+    const F3 qa[1] = {q};
+    const bool aa[1] = {active};
+    const int sa[1] = {seed};
+    float da[1];
+    int pa[1], oa[1];
+    wave_nn1<1>(tv, park, qa, aa, bound2, sa, da, pa, oa, qpw);
+    d2 = da[0], pos = pa[0], orig = oa[0];
+  } else {
+    nn1_resolve_leaf(tv, q, found ? leaf : -1, d2, pos, orig);
+  }
+}
+
 // update_correspondences + linearize fused: per source point 1-NN in the target tree, Mahalanobis matrix,
-// 6x6 normal-equation terms; wave shuffle + LDS reduction to one 28-double partial per block.
+// 6x6 normal-equation terms; wave shuffle reduction, one LDS row per wave, the last wave of the block adds the rows.
 // Algorithmic bytes per source point: 16 (a_i) + 24 (C_A) + 4 (corr) + 16 (b_j) + 24 (C_B) = 84.
-// 7 waves per SIMD (budget 72 VGPRs, 66 used, no scratch): measured best of 5 / 6 / 7 / 8.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINEARIZE_WAVES))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
                                                            double* __restrict__ partials, int max_blocks, int qpw) {
   const int b = blockIdx.y;
   if (states[b].phase != GICP_LINEARIZE) return;
@@ -510,44 +549,40 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7))) voi
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = xcd_tile(blockIdx.x, ntiles);
   __shared__ double lds[4 * kAcc];
-  __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][kNW * 32];
+  __shared__ unsigned arrivals;
+  __shared__ __attribute__((aligned(512))) float park[kBlock / 64][kParkFloats];
+  if (threadIdx.x == 0) arrivals = 0u;
+  __syncthreads();
   // the wave's index lives in an SGPR and the lane id is recomputed after the search: nothing about the thread's identity is
-  // kept in (or spilled from) a VGPR across the walk — the kernel fits the 72 VGPRs of 7 waves per SIMD without scratch
+  // kept in (or spilled from) a VGPR across the walk
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const Pose T = states[b].x0;
   float Tf[12];
   pose_to_float(T, Tf);
-  // every wave walks kNW packets of 64 consecutive source points in lock-step (hgs_wave_bvh.h)
-  int idx[kNW], seed[kNW], j[kNW], orig[kNW];
-  bool active[kNW];
-  float4 a[kNW];
-  F3 q[kNW];
-  float d2[kNW];
-#pragma unroll
-  for (int w = 0; w < kNW; w++) {
-    idx[w] = tile * tile_pts + wave * (qpw * kNW) + w * qpw + (int)(threadIdx.x & 63);
-    active[w] = (int)(threadIdx.x & 63) < qpw && idx[w] < n;
-    a[w] = active[w] ? load_stream(d.pts + idx[w]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    q[w] = transform_point_f(Tf, a[w].x, a[w].y, a[w].z);
-    // seed: the correspondence of the previous linearisation (or of an earlier align; -1 / stale values are harmless)
-    seed[w] = active[w] ? __builtin_nontemporal_load(d.corr + idx[w]) : -1;
-  }
-  wave_nn1<kNW>(view_of(tgt), walk_slots[wave], q, active, c.search_bound2, seed, d2, j, orig, qpw);
+  static_assert(kNW == 1, "one packet of 64 consecutive source points per wave");
+  const int idx = tile * tile_pts + wave * qpw + (int)(threadIdx.x & 63);
+  const bool active = (int)(threadIdx.x & 63) < qpw && idx < n;
+  const float4 a = active ? load_stream(d.pts + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
+  // seed: the correspondence of the previous linearisation (or of an earlier align; -1 / stale values are harmless)
+  const int seed = active ? __builtin_nontemporal_load(d.corr + idx) : -1;
+  float d2;
+  int j, orig;
+  packet_nn1(view_of(tgt), park[wave], q, active, c.search_bound2, seed, qpw, d2, j, orig);
   const double R[9] = {T.m[0], T.m[1], T.m[2], T.m[4], T.m[5], T.m[6], T.m[8], T.m[9], T.m[10]};
-  static_assert(kNW == 1, "the staged reduction below is written for one packet per wave");
-  int jj = active[0] ? j[0] : -1;
-  if (jj >= 0 && !((double)d2[0] < c.max_corr2)) jj = -1;
-  if (active[0]) __builtin_nontemporal_store(jj, d.corr + idx[0]);
+  int jj = active ? j : -1;
+  if (jj >= 0 && !((double)d2 < c.max_corr2)) jj = -1;
+  if (active) __builtin_nontemporal_store(jj, d.corr + idx);
   // a lane without a correspondence carries M = 0, T a = 0: every term below is then an exact zero
   Sym3 M = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   GicpPointResidual r = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (jj >= 0) {
-    M = gicp_mahalanobis(R, load_cov_stream(d.cov, idx[0]), load_cov(tgt.cov, jj));
+    M = gicp_mahalanobis(R, load_cov_stream(d.cov, idx), load_cov(tgt.cov, jj));
     const float4 bp = tgt.pts[jj];
-    r = gicp_point_residual(T, M, a[0].x, a[0].y, a[0].z, bp.x, bp.y, bp.z);
+    r = gicp_point_residual(T, M, a.x, a.y, a.z, bp.x, bp.y, bp.z);
   }
   // The 28 sums of the wave, one block of the normal equations at a time: only that block's terms are live while it is
-  // reduced (all 28 at once need more registers than the 72 the search runs at, and spilled — 12 bytes of scratch per thread).
+  // reduced (all 28 at once need more registers than the search runs at, and spilled — 12 bytes of scratch per thread).
   int lane;
   HGS_LANE_ID(lane);
   double* row = lds + wave * kAcc;
@@ -578,9 +613,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7))) voi
     const int slot[6] = {0, 1, 2, 6, 7, 11};
     wave_sums_to<6>(v, slot, row, lane);
   }
-  __syncthreads();
-  double* out = partials + ((size_t)b * max_blocks + tile) * kAcc;
-  if (wave == 0 && lane < kAcc) out[lane] = (lds[lane] + lds[kAcc + lane]) + (lds[2 * kAcc + lane] + lds[3 * kAcc + lane]);
+  last_wave_stores<kAcc>(lds, &arrivals, partials + ((size_t)b * max_blocks + tile) * kAcc, lane);
 }
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
                            int max_blocks, int B, int qpw) {
@@ -672,8 +705,8 @@ void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out,
 
 // ------------------------------------------------------------------------------------------------ fitness / NN queries
 // getFitnessScore: per source point exact (unbounded) 1-NN in the target; sum d2 over d2 <= max_range.
-// Algorithmic bytes per source point: 16 + 16 = 32.
-__global__ __launch_bounds__(kBlock) void k_fitness(const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range,
+// Algorithmic bytes per source point: 16 + 16 = 32.  Only the distance is needed: the quad walk runs without leaf / tie tracking.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_FITNESS_WAVES))) void k_fitness(const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range,
                                                     double* __restrict__ partials, int max_blocks, int use_seed, int qpw) {
   const int b = blockIdx.y;
   const CloudDesc d = descs[b];
@@ -683,32 +716,39 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const CloudDesc* descs, Targ
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = xcd_tile(blockIdx.x, ntiles);
   __shared__ double lds[4 * 2];
-  __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][kNW * 32];
-  double acc[2] = {0.0, 0.0};
+  __shared__ unsigned arrivals;
+  __shared__ __attribute__((aligned(512))) float park[kBlock / 64][kParkFloats];
+  if (threadIdx.x == 0) arrivals = 0u;
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float Tf[12];
   const float* Tc = poses[b].T;
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
     for (int cc = 0; cc < 4; cc++) Tf[r * 4 + cc] = Tc[cc * 4 + r];
-  int idx[kNW], seed[kNW], j[kNW], orig[kNW];
-  bool active[kNW];
-  F3 q[kNW];
-  float d2[kNW];
-#pragma unroll
-  for (int w = 0; w < kNW; w++) {
-    idx[w] = tile * tile_pts + (int)(threadIdx.x >> 6) * (qpw * kNW) + w * qpw + (int)(threadIdx.x & 63);
-    active[w] = (int)(threadIdx.x & 63) < qpw && idx[w] < n;
-    const float4 a = active[w] ? load_stream(d.pts + idx[w]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    q[w] = transform_point_f(Tf, a.x, a.y, a.z);
-    // use_seed: corr[] holds this cloud's last GICP correspondences against this target — a tight starting bound
-    seed[w] = (active[w] && use_seed) ? __builtin_nontemporal_load(d.corr + idx[w]) : -1;
+  const int idx = tile * tile_pts + wave * qpw + (int)(threadIdx.x & 63);
+  const bool active = (int)(threadIdx.x & 63) < qpw && idx < n;
+  const float4 a = active ? load_stream(d.pts + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
+  // use_seed: corr[] holds this cloud's last GICP correspondences against this target — a tight starting bound
+  const int seed = (active && use_seed) ? __builtin_nontemporal_load(d.corr + idx) : -1;
+  const BvhView tv = view_of(tgt);
+  const bool seeded = seed >= 0 && seed < tv.n;
+  float d2;
+  int leaf;
+  bool tie, found;
+  if (__ballot(active && !seeded) != 0ull) wave_nn1_quad<true, false>(tv, park[wave], q, active, FLT_MAX, seed, qpw >> 1, d2, leaf, tie, found);
+  else wave_nn1_quad<false, false>(tv, park[wave], q, active, FLT_MAX, seed, qpw >> 1, d2, leaf, tie, found);
+  double acc[2] = {0.0, 0.0};
+  if (active && found && (double)d2 <= max_range) acc[0] = (double)d2, acc[1] = 1.0;
+  int lane;
+  HGS_LANE_ID(lane);
+  {
+    const int slot[2] = {0, 1};
+    wave_sums_to<2>(acc, slot, lds + wave * 2, lane);
   }
-  wave_nn1<kNW>(view_of(tgt), walk_slots[threadIdx.x >> 6], q, active, FLT_MAX, seed, d2, j, orig, qpw);
-#pragma unroll
-  for (int w = 0; w < kNW; w++)
-    if (active[w] && j[w] >= 0 && (double)d2[w] <= max_range) acc[0] += (double)d2[w], acc[1] += 1.0;
-  block_reduce_store<2>(acc, partials + ((size_t)b * max_blocks + tile) * 2, lds);
+  last_wave_stores<2>(lds, &arrivals, partials + ((size_t)b * max_blocks + tile) * 2, lane);
 }
 void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks,
                     int B, int use_seed, int qpw) {

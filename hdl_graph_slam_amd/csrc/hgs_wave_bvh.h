@@ -257,6 +257,179 @@ __device__ __forceinline__ void wave_nn1(const BvhView& t, float* slots, const F
   for (int i = 0; i < NW; i++) best[i] = w[i].lane.best(), best_pos[i] = w[i].lane.pos, best_orig[i] = w[i].lane.orig();
 }
 
+// ---- 1-NN, "quad" walk (round 3): what k_gicp_linearize and k_fitness run ------------------------------------------
+// The generic walk above fetches one 128-byte record per step, waits for it, and keeps a 64-bit {d2 : original index} key
+// per lane up to date at every tested point.  Measured (profiles/r02_fast_gicp_pmc_summary.md): the 1-NN kernels are bound by
+// VALU issue (a leaf visit cost ~80 vector instructions, 32 of them the per-point key compare/select chain, a group step
+// ~50) plus one dependent L2 round trip per step.  This walk removes both:
+//   * QUAD FETCH.  The records of the four children 4n..4n+3 of a node are adjacent in memory (group records are indexed by
+//     node id, leaf records by leaf id), so when a group has a wanted child the wave fetches all four child records with ONE
+//     512-byte load (lane l: bytes 8l..8l+7) and parks them in a wave-private LDS slot of the level.  The child descended
+//     into AND every sibling popped later are then read from LDS: a packet waits for memory once per group that has wanted
+//     children (~25 times per 64 queries) instead of once per step (~53), and the leaves of a leaf-parent group are all
+//     there after one wait.  A level's slot stays valid until the walk evaluates another node of the parent level, which
+//     cannot happen before every pending child of the current one has been popped (pops are deepest-first).  Slots exist
+//     for the leaf quad and the three group levels above it; all higher levels share one slot and re-fetch on a pop (rare).
+//   * MIN-ONLY LEAVES.  A leaf visit keeps, per lane, the minimum squared distance (v_min3 tree), the leaf that produced it
+//     and how many visited leaves reached exactly that minimum: 24 + 4 + 6 vector instructions.  Position and original index
+//     of the winner are resolved once per packet (nn1_resolve_leaf: the lane re-reads its best leaf and takes the lowest
+//     original index among the points at exactly the minimum — bit-identical distances, same fma chain).  A lane whose minimum
+//     was reached in two different leaves (equidistant points in different leaves: duplicated clouds, regular grids) cannot
+//     be resolved from one leaf: the caller then runs the exact keyed walk (wave_nn1) for that wave.  getFitnessScore needs
+//     the distance only — no leaf, no count, no resolve.
+//   * CHILD ORDER only where it pays: an unseeded walk (first linearisation, NDT's fitness pass) descends nearest-first as seen
+//     by the middle lane (93 vs 150 steps per packet); a seeded walk takes the lowest wanted child (the seed's bound is
+//     already tight: 53.4 vs 53.5 steps, and 14 vector instructions less per group).
+// Results are those of wave_nn1 (exact; ties -> lowest original index) except that a point at a squared distance of exactly
+// FLT_MAX is not found by an unbounded search (the exclusive bound is clamped to FLT_MAX so that empty boxes, whose distance
+// is +inf, are never wanted).
+typedef float hgs_f8v __attribute__((ext_vector_type(8)));
+constexpr int kParkLevels = 4;                     // leaf quad + three group levels with a slot of their own
+constexpr int kParkSlots = kParkLevels + 1;        // + the slot all higher levels share
+constexpr int kParkFloats = kParkSlots * 128;      // wave-private LDS floats (2560 bytes)
+
+// the four records (512 contiguous bytes) starting at `quad` -> LDS slot
+__device__ __forceinline__ void fetch_quad(const Float4* quad, float* slot) {
+  const int l = (int)(__lane_id() & 63u);
+  const hgs_f2 v = reinterpret_cast<const hgs_f2*>(quad)[l];
+  __builtin_amdgcn_wave_barrier();  // earlier reads of this slot are issued before it is overwritten
+  reinterpret_cast<hgs_f2*>(slot)[l] = v;
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float nn1_exclusive_bound(float d2_inclusive) {
+  const unsigned u = __float_as_uint(d2_inclusive) + 1u;  // next float up: "m < bound" == "m <= d2_inclusive"
+  return __uint_as_float(u < 0x7f7fffffu ? u : 0x7f7fffffu);
+}
+
+// TRACK: also keep the best leaf and the number of leaves that reached the minimum (what nn1_resolve_leaf needs)
+template <bool ORDERED, bool TRACK>
+__device__ __forceinline__ void wave_nn1_quad(const BvhView& t, float* park /* kParkFloats, wave-private, 512-byte aligned */, const F3& q0, bool active,
+                                              float bound2, int seed, int order_lane, float& best_out, int& leaf_out, bool& tie_out, bool& found_out) {
+  const int k = 31 - __clz(t.P);
+  const F3 q = active ? q0 : F3{FLT_MAX, FLT_MAX, FLT_MAX};  // a lane without a query is infinitely far from everything
+  const hgs_f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+  float best = active ? nn1_exclusive_bound(bound2) : 0.f;
+  if (active && seed >= 0 && seed < t.n) {
+    const Float4 p = t.pts[seed];
+    const float d = dist2f(q, p.x, p.y, p.z);
+    if (d <= bound2) best = nn1_exclusive_bound(d);  // the seed's own leaf will be visited (box_d2 <= d) and set the leaf
+  }
+  const float best_init = best;
+  int leaf = -1, cnt = 0;
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+  auto wanted = [&]() -> unsigned {
+    return (__ballot(d0 <= best) != 0ull ? 1u : 0u) | (__ballot(d1 <= best) != 0ull ? 2u : 0u) | (__ballot(d2 <= best) != 0ull ? 4u : 0u) |
+           (__ballot(d3 <= best) != 0ull ? 8u : 0u);
+  };
+  auto visit_leaf = [&](const float* rec, int ldnode) {
+    const hgs_f16v xy = *reinterpret_cast<const hgs_f16v*>(rec);
+    const hgs_f8v z = *reinterpret_cast<const hgs_f8v*>(rec + 16);
+    const hgs_f2 a = pk_dist2(qx, qy, qz, hgs_f2{xy[0], xy[1]}, hgs_f2{xy[8], xy[9]}, hgs_f2{z[0], z[1]});
+    const hgs_f2 b = pk_dist2(qx, qy, qz, hgs_f2{xy[2], xy[3]}, hgs_f2{xy[10], xy[11]}, hgs_f2{z[2], z[3]});
+    const hgs_f2 c = pk_dist2(qx, qy, qz, hgs_f2{xy[4], xy[5]}, hgs_f2{xy[12], xy[13]}, hgs_f2{z[4], z[5]});
+    const hgs_f2 e = pk_dist2(qx, qy, qz, hgs_f2{xy[6], xy[7]}, hgs_f2{xy[14], xy[15]}, hgs_f2{z[6], z[7]});
+    const float m = fminf(fminf(fminf(a.x, a.y), fminf(b.x, b.y)), fminf(fminf(c.x, c.y), fminf(e.x, e.y)));
+    if (TRACK) {
+      const bool better = m < best;
+      cnt = better ? 1 : cnt + (m == best ? 1 : 0);
+      leaf = better ? ldnode : leaf;
+    }
+    best = fminf(best, m);
+  };
+  if (t.n > 0 && k <= 1) {  // one or two leaves (at most 16 points): no boxes worth testing
+    const int l = (int)(__lane_id() & 31u);
+    for (int lf = 0; lf < t.P; lf++) {
+      const float v = reinterpret_cast<const float*>(t.lpts + 8 * lf)[l];
+      __builtin_amdgcn_wave_barrier();
+      park[l] = v;
+      __builtin_amdgcn_wave_barrier();
+      visit_leaf(park, t.P + lf);
+    }
+  } else if (t.n > 0) {
+    unsigned node = (k & 1) ? 0u : 1u;
+    int bd = (k & 1) ? -1 : 0;
+    unsigned long long pend = 0;
+    const auto slot_of = [&](int depth) { const int s = (k - depth) >> 1; return park + 128 * (s < kParkLevels ? s : kParkLevels); };
+    fetch_quad(t.nodes, slot_of(bd));
+    for (;;) {
+      {  // the group of `node`: boxes of its four grandchildren  {mnx[4], mny[4], mnz[4], mxx[4]} {mxy[4], mxz[4]}
+        const float* rec = slot_of(bd) + 32 * (node & 3u);
+        const hgs_f16v lo = *reinterpret_cast<const hgs_f16v*>(rec);
+        const hgs_f8v hi = *reinterpret_cast<const hgs_f8v*>(rec + 16);
+        const hgs_f2 d01 = pk_box_dist2(qx, qy, qz, hgs_f2{lo[0], lo[1]}, hgs_f2{lo[4], lo[5]}, hgs_f2{lo[8], lo[9]}, hgs_f2{lo[12], lo[13]}, hgs_f2{hi[0], hi[1]},
+                                        hgs_f2{hi[4], hi[5]});
+        const hgs_f2 d23 = pk_box_dist2(qx, qy, qz, hgs_f2{lo[2], lo[3]}, hgs_f2{lo[6], lo[7]}, hgs_f2{lo[10], lo[11]}, hgs_f2{lo[14], lo[15]}, hgs_f2{hi[2], hi[3]},
+                                        hgs_f2{hi[6], hi[7]});
+        d0 = d01.x, d1 = d01.y, d2 = d23.x, d3 = d23.y;
+      }
+      const unsigned any = wanted();
+      if (any) {
+        int cstar = __builtin_ctz(any);
+        if (ORDERED) {  // the nearest child the middle lane of the packet wants (else the lowest wanted slot)
+          const float w0 = d0 <= best ? d0 : INFINITY, w1 = d1 <= best ? d1 : INFINITY, w2 = d2 <= best ? d2 : INFINITY, w3 = d3 <= best ? d3 : INFINITY;
+          const float dmin = fminf(fminf(w0, w1), fminf(w2, w3));
+          const int pref = dmin == INFINITY ? -1 : (w0 == dmin ? 0 : (w1 == dmin ? 1 : (w2 == dmin ? 2 : 3)));
+          const int p = __builtin_amdgcn_readlane(pref, order_lane);
+          if (p >= 0) cstar = p;
+        }
+        const int cd = bd + 2;
+        const unsigned base = node << 2;
+        if (cd == k) {  // the children are leaves: all four records with one fetch, visited in place
+          fetch_quad(t.lpts + 8 * (size_t)(base - (unsigned)t.P), park);
+          unsigned todo = any;
+          int c = cstar;
+          while (todo) {
+            todo &= ~(1u << c);
+            visit_leaf(park + 32 * c, (int)(base + (unsigned)c));
+            todo &= wanted();  // the visit tightened the bounds: drop the leaves nobody wants any more
+            c = todo ? __builtin_ctz(todo) : 0;
+          }
+        } else {
+          pend |= (unsigned long long)(any & ~(1u << cstar)) << (4 * (cd >> 1));
+          fetch_quad(t.nodes + 8 * (size_t)base, slot_of(cd));
+          node = base + (unsigned)cstar;
+          bd = cd;
+          continue;
+        }
+      }
+      if (!pend) break;
+      // backtrack: the lowest pending child of the deepest pending group; its record is parked unless its level shares the top slot
+      const int idx = (63 - __clzll((long long)pend)) >> 2;
+      const unsigned nib = (unsigned)(pend >> (4 * idx)) & 0xfu;
+      const int c = __builtin_ctz(nib);
+      pend &= ~(1ull << (4 * idx + c));
+      const int pcd = 2 * idx + (k & 1);
+      node = ((node >> (bd - pcd)) & ~3u) + (unsigned)c;
+      bd = pcd;
+      if (((k - bd) >> 1) >= kParkLevels) fetch_quad(t.nodes + 8 * (size_t)(node & ~3u), slot_of(bd));
+    }
+  }
+  best_out = best;
+  leaf_out = leaf;
+  tie_out = TRACK && leaf >= 0 && cnt > 1;
+  found_out = best < best_init;
+}
+
+// Position (sorted) and original index of the point of leaf node `leaf` at squared distance exactly d2 from q with the lowest
+// original index.  Per-lane gather of the lane's own best leaf (128 contiguous bytes of the AoS point array).
+__device__ __forceinline__ void nn1_resolve_leaf(const BvhView& t, const F3& q, int leaf, float d2, int& pos_out, int& orig_out) {
+  int pos = -1, orig = 0x7fffffff;
+  if (leaf >= 0) {
+    const int base = (leaf - t.P) * kLeaf;
+#pragma unroll
+    for (int l = 0; l < kLeaf; l++) {
+      const Float4 p = t.pts[base + l];
+      const float d = dist2f(q, p.x, p.y, p.z);
+      const int oi = __float_as_int(p.w);
+      const bool take = d == d2 && oi < orig;
+      orig = take ? oi : orig;
+      pos = take ? base + l : pos;
+    }
+  }
+  pos_out = pos, orig_out = pos >= 0 ? orig : -1;
+}
+
 // ---- k-NN radius: sorted list of the k smallest squared distances only (no positions) -----------------------------
 // With d ascending, inserting x makes the new d[i] the median of (d[i-1], d[i], x): one v_med3_f32 per slot.
 // INCLUSIVE: prune with box_d2 <= bound instead of <, see wants().

@@ -18,6 +18,8 @@
 #define HGS_LANE_ID(dst) ((dst) = (int)(threadIdx.x & 63))
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))  /* one OS thread runs every fiber (atomicAdd below) */
 
 #include <math.h>
 #include <stdint.h>
