@@ -123,9 +123,15 @@ protected:
   }
 
 private:
+  // Never throws into the nodelet: when the engine cannot be created (no usable HIP device, out of memory) this logs and returns
+  // nullptr; every C-ABI entry point rejects a null handle, so setInputSource / setInputTarget log a second line and align()
+  // ends with hasConverged() == false and the guess as the final transformation — the failure signal the callers test
+  // (apps/scan_matching_odometry_nodelet.cpp:214, include/hdl_graph_slam/loop_detector.hpp:147).  Creation is retried on the
+  // next call.
   hgs_handle* handle() {
-    if (!handle_) {
-      if (hgs_create(&params_, &handle_) != HGS_OK) throw std::runtime_error(std::string("hgs_create: ") + hgs_last_error(nullptr));
+    if (!handle_ && hgs_create(&params_, &handle_) != HGS_OK) {
+      PCL_ERROR("[%s] hgs_create failed: %s\n", this->reg_name_.c_str(), hgs_last_error(nullptr));
+      handle_ = nullptr;
     }
     return handle_;
   }

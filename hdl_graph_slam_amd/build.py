@@ -44,7 +44,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    # no -lrccl: hgs_comm.hip loads RCCL with dlopen at the first hgs_comm_* call, the registration path does not depend on it
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -133,6 +133,7 @@ struct hgs_handle {
   // block-per-problem solve / decide kernels of one lane run under the point kernels of the others
   hipStream_t lane_stream[3] = {};
   hipEvent_t lane_event[4] = {};
+  hipEvent_t comm_event = nullptr;  // hgs_loop_match_batch_sharded: the gathered headers have reached the host
   // measured on the 16 x 120 k-point loop batch: 1 -> 2 -> 4 lanes = 2850 -> 2935 -> 2975 GICP reg/s, 735 -> 772 -> 797 NDT;
   // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default).  Round 2, 64 x 119 k-point batch:
   // 1 / 2 / 3 / 4 lanes = 3680 / 3999 / 3937 / 3913 GICP reg/s and 1064 / 1403 / 1384 / 1326 NDT — with 32 problems per lane a lane's
@@ -1006,6 +1007,7 @@ int hgs_destroy(hgs_handle* h) try {
   for (int i = 0; i < 3; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
   for (hipEvent_t ev : h->lane_event)
     if (ev) (void)hipEventDestroy(ev);
+  if (h->comm_event) (void)hipEventDestroy(h->comm_event);
   for (hipStream_t ls : h->lane_stream)
     if (ls) (void)hipStreamDestroy(ls);
   for (auto& blk : h->block_pool) (void)hipFree(blk.first);
@@ -1361,68 +1363,160 @@ int hgs_comm_finalize(hgs_handle* h) try {
   return status_of_current_exception(h);
 }
 
-int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, size_t n_mine, const int32_t* candidate_ids, const float* guesses,
-                                 size_t n_total, double max_range, hgs_result* all_out, int32_t* best) try {
-  std::unique_lock<std::recursive_mutex> api_lock__;
-  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
-  if (!h || !all_out || n_total == 0 || n_total > (size_t)1 << 24 || (n_mine > 0 && (!candidates || !candidate_ids || !guesses))) return HGS_ERR_INVALID_ARGUMENT;
-  if (!h->comm) {
-    h->err = "hgs_loop_match_batch_sharded: hgs_comm_init has not been called on this engine";
-    return HGS_ERR_COMM;
-  }
-  if (!h->target) return HGS_ERR_NO_TARGET;
-  if (best) *best = -1;
-  HGS_TRY(set_device(h));
-  const int world = hgs::comm_world(h->comm);
-  // Records every rank sends: its own, then padding.  n_total slots, so that ANY partition works without a second collective
-  // to agree on the largest shard — keyframes are cached on the GPU of keyframe_id mod world, and the candidates of one
-  // detection need not spread evenly.  512 candidates x 8 ranks x 112 B = 458 KB per batch: still a latency-bound exchange.
-  const size_t per = n_total;
-  if (n_mine > per) return HGS_ERR_INVALID_ARGUMENT;
-  std::vector<hgs_cloud*> src(candidates, candidates + n_mine);
-  for (size_t i = 0; i < n_mine; i++)
-    if (!src[i] || src[i]->owner != h || candidate_ids[i] < 0 || (size_t)candidate_ids[i] >= n_total) return HGS_ERR_INVALID_ARGUMENT;
-  {
-    std::vector<hgs_cloud*> sorted(src);
-    std::sort(sorted.begin(), sorted.end());
-    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) {
-      h->err = "hgs_loop_match_batch_sharded: candidate clouds must be distinct";
-      return HGS_ERR_INVALID_ARGUMENT;
-    }
-  }
-  if (n_mine > 0) HGS_TRY(run_batch(h, src, guesses, &max_range));
-  // records of this rank, built on the device from the batch's results and gathered from there: no host copy in between
-  HGS_HIP(h, h->results.reserve(sizeof(DevResult)));
-  HGS_HIP(h, h->comm_send.reserve(per * sizeof(hgs_result)));
-  HGS_HIP(h, h->comm_recv.reserve((size_t)world * per * sizeof(hgs_result)));
-  HGS_HIP(h, h->comm_ids.reserve(std::max<size_t>(n_mine, 1) * sizeof(int32_t)));
-  // pinned staging on both sides of the exchange (ids in front, the gathered records behind): no pageable copies on the stream
-  const size_t ids_bytes = (std::max<size_t>(n_mine, 1) * sizeof(int32_t) + 15) & ~(size_t)15;
-  HGS_HIP(h, h->h_comm.reserve(ids_bytes + (size_t)world * per * sizeof(hgs_result)));
-  if (n_mine > 0) {
-    std::memcpy(h->h_comm.p, candidate_ids, n_mine * sizeof(int32_t));
-    HGS_HIP(h, hipMemcpyAsync(h->comm_ids.p, h->h_comm.p, n_mine * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-  }
-  launch_results_to_records(h->stream, h->results.as<DevResult>(), h->comm_ids.as<int>(), (int)n_mine, (int)per, h->comm_send.as<hgs_result>());
-  HGS_HIP(h, hipGetLastError());
-  char err[256] = "";
-  if (hgs::comm_all_gather(h->comm, h->comm_send.p, h->comm_recv.p, per * sizeof(hgs_result), h->stream, err, sizeof(err)) != 0) {
-    h->err = err;
-    return HGS_ERR_COMM;
-  }
-  const hgs_result* gathered = reinterpret_cast<const hgs_result*>(static_cast<const char*>(h->h_comm.p) + ids_bytes);
-  HGS_HIP(h, hipMemcpyAsync(const_cast<hgs_result*>(gathered), h->comm_recv.p, (size_t)world * per * sizeof(hgs_result), hipMemcpyDeviceToHost, h->stream));
-  HGS_HIP(h, hipStreamSynchronize(h->stream));
-  for (size_t i = 0; i < n_total; i++) {  // a candidate no rank reported stays "not converged"
+// Pure host code of the sharded batch: the gathered slots -> the n_total records of the detection.  `gathered` holds `world`
+// blocks of `per` slots; of rank r's block the first counts[r] slots carry records, the rest is padding.  A candidate nobody
+// reported stays "not converged" (fitness DBL_MAX); a candidate reported twice (two ranks, or twice by one) is an error of the
+// caller's partition: *duplicate_id receives the id (else -1) and the first report is kept.
+int hgs_debug_merge_shard_records(const hgs_result* gathered, const int32_t* counts, int32_t world, size_t per, size_t n_total, hgs_result* all_out,
+                                  int32_t* duplicate_id) try {
+  if (!all_out || n_total == 0 || world < 1 || (per > 0 && !gathered) || !counts) return HGS_ERR_INVALID_ARGUMENT;
+  for (size_t i = 0; i < n_total; i++) {
     std::memset(&all_out[i], 0, sizeof(hgs_result));
     all_out[i].candidate_id = (int32_t)i;
     all_out[i].fitness_score = std::numeric_limits<double>::max();
   }
-  for (size_t k = 0; k < (size_t)world * per; k++) {
-    const hgs_result& r = gathered[k];
-    if (r.candidate_id >= 0 && (size_t)r.candidate_id < n_total) all_out[r.candidate_id] = r;
+  std::vector<char> seen(n_total, 0);
+  int32_t dup = -1;
+  for (int32_t r = 0; r < world; r++) {
+    const size_t n = counts[r] < 0 ? 0 : std::min<size_t>((size_t)counts[r], per);
+    for (size_t k = 0; k < n; k++) {
+      const hgs_result& rec = gathered[(size_t)r * per + k];
+      if (rec.candidate_id < 0 || (size_t)rec.candidate_id >= n_total) continue;  // padding (a rank that failed after announcing its shard)
+      if (seen[rec.candidate_id]) {
+        if (dup < 0) dup = rec.candidate_id;
+        continue;
+      }
+      seen[rec.candidate_id] = 1;
+      all_out[rec.candidate_id] = rec;
+    }
   }
+  if (duplicate_id) *duplicate_id = dup;
+  return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(nullptr);
+}
+
+// Collective.  Once the arguments that are the same on every rank have been checked, EVERY path of a rank reaches both
+// collectives — a rank whose own share is unusable (no target, an invalid or duplicated candidate cloud, a failed launch)
+// announces an empty shard / sends padding and reports its error AFTER the exchange, so that a bad keyframe on one rank costs
+// that rank's candidates ("not converged" records everywhere) and never blocks the other SLAM processes.  The one thing a rank
+// cannot do is take part without device memory for the exchange buffers: it then aborts the communicator (ncclCommAbort), which
+// makes the peers' collectives fail with HGS_ERR_COMM instead of hanging.
+//   1. all-gather of a 16-byte header per rank {shard size, status}, enqueued in front of the batch's kernels;
+//   2. the batch (run_batch), while the headers travel;
+//   3. all-gather of max(shard size) record slots per rank — not n_total: an even partition of 512 candidates over 8 ranks moves
+//      8 x 64 x 112 B = 57 KB instead of 458 KB — built on the device behind the kernels that produced the results;
+//   4. one D2H of world x max(shard) slots, merge (hgs_debug_merge_shard_records), sequential selection rule.
+int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, size_t n_mine, const int32_t* candidate_ids, const float* guesses,
+                                 size_t n_total, double max_range, hgs_result* all_out, int32_t* best) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
+  // ---- errors that keep the rank out of the collective: only what a correct caller gets wrong on every rank alike
+  if (!h || !all_out || n_total == 0 || n_total > (size_t)1 << 24) return HGS_ERR_INVALID_ARGUMENT;
+  if (!h->comm) {
+    h->err = "hgs_loop_match_batch_sharded: hgs_comm_init has not been called on this engine";
+    return HGS_ERR_COMM;
+  }
+  if (best) *best = -1;
+  const int world = hgs::comm_world(h->comm), rank = hgs::comm_rank(h->comm);
+  // ---- this rank's own share: problems found here are reported after the exchange
+  int local = HGS_OK;
+  std::string local_err;
+  auto fail_local = [&](int rc, const std::string& why) {
+    if (local == HGS_OK) local = rc, local_err = why;
+  };
+  if (n_mine > n_total || (n_mine > 0 && (!candidates || !candidate_ids || !guesses))) fail_local(HGS_ERR_INVALID_ARGUMENT, "hgs_loop_match_batch_sharded: bad candidate arrays");
+  if (!h->target) fail_local(HGS_ERR_NO_TARGET, "hgs_loop_match_batch_sharded: no target set on this rank");
+  std::vector<hgs_cloud*> src;
+  if (local == HGS_OK) {
+    src.assign(candidates, candidates + n_mine);
+    for (size_t i = 0; i < n_mine; i++)
+      if (!src[i] || src[i]->owner != h || candidate_ids[i] < 0 || (size_t)candidate_ids[i] >= n_total)
+        fail_local(HGS_ERR_INVALID_ARGUMENT, "hgs_loop_match_batch_sharded: candidate " + std::to_string(i) + " is not a cloud of this engine or its id is out of range");
+    std::vector<hgs_cloud*> sorted(src);
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) fail_local(HGS_ERR_INVALID_ARGUMENT, "hgs_loop_match_batch_sharded: candidate clouds must be distinct");
+  }
+  const size_t n_send = local == HGS_OK ? n_mine : 0;
+  // ---- exchange buffers (persistent, worst case: one rank holds every candidate)
+  const size_t hdr_bytes = 16;
+  const size_t ids_off = align_up((size_t)world * hdr_bytes + hdr_bytes, 16), rec_off = align_up(ids_off + n_total * sizeof(int32_t), 16);
+  bool mem_ok = set_device(h) == HGS_OK;
+  mem_ok = mem_ok && h->results.reserve(std::max<size_t>(n_total, 1) * sizeof(DevResult)) == hipSuccess;
+  mem_ok = mem_ok && h->comm_send.reserve(n_total * sizeof(hgs_result) + hdr_bytes) == hipSuccess;
+  mem_ok = mem_ok && h->comm_recv.reserve((size_t)world * (n_total * sizeof(hgs_result) + hdr_bytes)) == hipSuccess;
+  mem_ok = mem_ok && h->comm_ids.reserve(n_total * sizeof(int32_t)) == hipSuccess;
+  mem_ok = mem_ok && h->h_comm.reserve(rec_off + (size_t)world * n_total * sizeof(hgs_result)) == hipSuccess;
+  if (!mem_ok) {
+    hgs::comm_abort(h->comm);
+    h->err = "hgs_loop_match_batch_sharded: no memory for the exchange buffers; the communicator has been aborted (the peers' collective fails instead of waiting)";
+    return HGS_ERR_OUT_OF_MEMORY;
+  }
+  char err[256] = "";
+  auto comm_failed = [&](const char* what) {
+    h->err = std::string(what) + ": " + err;
+    hgs::comm_abort(h->comm);  // whatever state the peers are in, they must not wait for this rank
+    return HGS_ERR_COMM;
+  };
+  // ---- 1. headers: device layout comm_send = [header | records], comm_recv = [world headers | world x per records]
+  int32_t* h_hdr = static_cast<int32_t*>(h->h_comm.p);  // pinned: [my header][world gathered headers]
+  h_hdr[0] = (int32_t)n_send, h_hdr[1] = local, h_hdr[2] = 0, h_hdr[3] = 0;
+  char* d_send = static_cast<char*>(h->comm_send.p);
+  char* d_recv = static_cast<char*>(h->comm_recv.p);
+  bool hip_ok = hipMemcpyAsync(d_send, h_hdr, hdr_bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+  if (hgs::comm_all_gather(h->comm, d_send, d_recv, hdr_bytes, h->stream, err, sizeof(err)) != 0) return comm_failed("header all-gather");
+  hip_ok = hip_ok && hipMemcpyAsync(h_hdr + 4, d_recv, (size_t)world * hdr_bytes, hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+  if (!h->comm_event) hip_ok = hip_ok && hipEventCreateWithFlags(&h->comm_event, hipEventDisableTiming) == hipSuccess;
+  hip_ok = hip_ok && hipEventRecord(h->comm_event, h->stream) == hipSuccess;
+  // ---- 2. the batch
+  size_t n_valid = 0;  // records this rank really has
+  if (n_send > 0 && hip_ok) {
+    const int rc = run_batch(h, src, guesses, &max_range);
+    if (rc == HGS_OK) n_valid = n_send;
+    else fail_local(rc, h->err);
+  }
+  // ---- 3. records: everybody knows everybody's shard size now
+  hip_ok = hip_ok && hipEventSynchronize(h->comm_event) == hipSuccess;
+  size_t per = 1;
+  std::vector<int32_t> counts(world, 0), statuses(world, 0);
+  if (hip_ok)
+    for (int r = 0; r < world; r++) {
+      counts[r] = std::max(0, std::min<int32_t>(h_hdr[4 + 4 * r], (int32_t)n_total));
+      statuses[r] = h_hdr[4 + 4 * r + 1];
+      per = std::max(per, (size_t)counts[r]);
+    }
+  else per = n_total;  // the header never arrived here: this rank cannot know `per`; it aborts below
+  if (!hip_ok) {
+    h->err = std::string("hgs_loop_match_batch_sharded: HIP error around the header exchange: ") + hipGetErrorString(hipGetLastError());
+    hgs::comm_abort(h->comm);
+    return HGS_ERR_HIP;
+  }
+  hgs_result* d_records = reinterpret_cast<hgs_result*>(d_send + hdr_bytes);
+  if (n_valid > 0) {
+    std::memcpy(static_cast<char*>(h->h_comm.p) + ids_off, candidate_ids, n_valid * sizeof(int32_t));
+    if (hipMemcpyAsync(h->comm_ids.p, static_cast<char*>(h->h_comm.p) + ids_off, n_valid * sizeof(int32_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) n_valid = 0;
+  }
+  launch_results_to_records(h->stream, h->results.as<DevResult>(), h->comm_ids.as<int>(), (int)n_valid, (int)per, d_records);  // padding beyond n_valid
+  hgs_result* d_gathered = reinterpret_cast<hgs_result*>(d_recv + (size_t)world * hdr_bytes);
+  if (hgs::comm_all_gather(h->comm, d_records, d_gathered, per * sizeof(hgs_result), h->stream, err, sizeof(err)) != 0) return comm_failed("record all-gather");
+  // ---- 4. merge
+  hgs_result* gathered = reinterpret_cast<hgs_result*>(static_cast<char*>(h->h_comm.p) + rec_off);
+  HGS_HIP(h, hipMemcpyAsync(gathered, d_gathered, (size_t)world * per * sizeof(hgs_result), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  int32_t dup = -1;
+  HGS_TRY(hgs_debug_merge_shard_records(gathered, counts.data(), world, per, n_total, all_out, &dup));
   if (best) HGS_TRY(hgs_select_best(all_out, n_total, best));
+  if (local != HGS_OK) {
+    h->err = local_err;
+    return local;
+  }
+  if (dup >= 0) {  // every rank sees the same gathered slots, so every rank returns this
+    h->err = "hgs_loop_match_batch_sharded: candidate id " + std::to_string(dup) + " was reported more than once (the first report was kept)";
+    return HGS_ERR_INVALID_ARGUMENT;
+  }
+  h->err.clear();
+  for (int r = 0; r < world; r++)
+    if (statuses[r] != HGS_OK && r != rank) h->err += "rank " + std::to_string(r) + " reported status " + std::to_string(statuses[r]) + " (its candidates are not converged); ";
   return HGS_OK;
 } catch (...) {
   return status_of_current_exception(h);

@@ -217,17 +217,22 @@ class RegistrationHIP:
     def comm_finalize(self):
         self._check(L.lib().hgs_comm_finalize(self._h))
 
-    def loop_match_batch_sharded(self, candidates, candidate_ids, guesses, n_total: int, max_range: float = L.DBL_MAX):
+    def loop_match_batch_sharded(self, candidates, candidate_ids, guesses, n_total: int, max_range: float = L.DBL_MAX, return_status: bool = False):
         """This rank's candidates (DeviceClouds, their positions in the detection's candidate list, their guesses) -> the records of
-        ALL n_total candidates in candidate order and the index the sequential rule selects.  Collective over the communicator."""
+        ALL n_total candidates in candidate order and the index the sequential rule selects.  Collective over the communicator.
+        return_status: do not raise on an error status but return (records, best, status) — a rank whose own share failed has
+        still taken part in the exchange and holds the other ranks' records (include/hgs_registration.h)."""
         n = len(candidates)
         ptrs = (C.c_void_p * max(n, 1))(*[c._h for c in candidates])
         ids = np.ascontiguousarray(np.asarray(candidate_ids, np.int32).reshape(-1))
         g = np.ascontiguousarray(np.stack([L.colmajor16(T) for T in guesses]) if n else np.zeros((0, 16), np.float32))
         out = np.zeros(int(n_total), dtype=L.RESULT_DTYPE)
         best = C.c_int32(-1)
-        self._check(L.lib().hgs_loop_match_batch_sharded(self._h, ptrs, n, ids.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), int(n_total),
-                                                         float(max_range), out.ctypes.data_as(C.c_void_p), C.byref(best)))
+        rc = L.lib().hgs_loop_match_batch_sharded(self._h, ptrs, n, ids.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), int(n_total),
+                                                  float(max_range), out.ctypes.data_as(C.c_void_p), C.byref(best))
+        if return_status:
+            return out, best.value, rc
+        self._check(rc)
         return out, best.value
 
     def calc_fitness_score(self, cloud1: DeviceCloud, cloud2: DeviceCloud, relpose, max_range: float = L.DBL_MAX) -> float:

@@ -174,7 +174,15 @@ int hgs_comm_init(hgs_handle* h, int32_t rank, int32_t world, const void* unique
 int hgs_comm_finalize(hgs_handle* h); /* also done by hgs_destroy */
 /* candidates / candidate_ids / guesses describe THIS rank's n_mine candidates (candidate_ids[i] in [0, n_total) is the position
  * of candidates[i] in the detection's candidate list); all_out receives n_total records, all_out[c].candidate_id == c;
- * *best as hgs_loop_match_batch.  Collective: every rank of the communicator must call it, with the same n_total. */
+ * *best as hgs_loop_match_batch.  Collective: every rank of the communicator must call it, with the same n_total.
+ * Failure behaviour (a collective must not hang the other SLAM processes): only argument errors a correct caller makes on
+ * every rank alike (null all_out, n_total == 0, no hgs_comm_init) return before the exchange.  A rank whose OWN share is
+ * unusable (no target, a candidate that is not a cloud of this engine, duplicated clouds, a failed launch) still takes part:
+ * it contributes no records, the peers see its candidates as "not converged" (fitness DBL_MAX), and it returns its error
+ * AFTER the exchange.  A candidate id reported more than once makes every rank return HGS_ERR_INVALID_ARGUMENT (first report
+ * kept).  A rank that cannot allocate the exchange buffers, or whose collective fails, aborts the communicator
+ * (ncclCommAbort): the peers then get HGS_ERR_COMM instead of blocking; hgs_comm_init creates a new one.
+ * Traffic: one 16-byte header per rank (shard size, status) and max(shard size) record slots per rank. */
 int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, size_t n_mine, const int32_t* candidate_ids,
                                  const float* guesses /* 16*n_mine */, size_t n_total, double max_range, hgs_result* all_out,
                                  int32_t* best);
@@ -254,6 +262,11 @@ int hgs_debug_gicp_linearize(hgs_handle* h, const double T12[12], double* H36, d
 int hgs_debug_ndt_cells(hgs_handle* h, int32_t cap, int32_t* ijk3, double* mean3, float* icov6, int32_t* npts, int32_t* n_cells);
 /* One NDT derivative pass at p = (tx,ty,tz,rx,ry,rz): score, gradient[6], Hessian[36]. */
 int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, double* g6, double* H36);
+/* the pure-host merge step of hgs_loop_match_batch_sharded: `gathered` = world blocks of `per` slots, of rank r's block the first
+ * counts[r] carry records; fills all_out[0 .. n_total) (a candidate nobody reported: not converged, fitness DBL_MAX);
+ * *duplicate_id = an id reported more than once (first report kept) or -1.  Needs no device: callable on a CPU-only box. */
+int hgs_debug_merge_shard_records(const hgs_result* gathered, const int32_t* counts, int32_t world, size_t per, size_t n_total,
+                                  hgs_result* all_out, int32_t* duplicate_id);
 
 #ifdef __cplusplus
 }

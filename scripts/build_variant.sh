@@ -11,6 +11,6 @@ for src in hgs_sort hgs_kernels hgs_engine hgs_comm; do
   hipcc $FLAGS "$@" -c hdl_graph_slam_amd/csrc/$src.hip -o ab_libs/obj_$name/$src.o &
 done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/$name.so ab_libs/obj_$name/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/$name.so ab_libs/obj_$name/*.o -ldl
 rm -rf ab_libs/obj_$name
 ls -la ab_libs/$name.so

@@ -55,6 +55,19 @@ int main(int argc, char** argv) {
     auto* hip = dynamic_cast<hgs_hip::RegistrationHIP<PointT, PointT>*>(registration.get());
     std::printf("fitness %.12g\n", hip->fitnessScoreHIP());
     std::printf("aligned0 %.6f %.6f %.6f n %zu\n", aligned.points[0].x, aligned.points[0].y, aligned.points[0].z, aligned.size());
+    {
+      // an engine that cannot be created (device 4096 does not exist) must not throw into the caller: the nodelets test
+      // hasConverged() (apps/scan_matching_odometry_nodelet.cpp:214) and expect the guess back
+      pcl::Registration<PointT, PointT>::Ptr broken = std::make_shared<hgs_hip::RegistrationHIP<PointT, PointT>>(std::atoi(argv[1]), 4096);
+      broken->setInputTarget(keyframe);
+      broken->setInputSource(filtered);
+      pcl::PointCloud<PointT> out;
+      auto guess = pcl::MockMatrix4f::Identity();
+      guess.data()[12] = 0.25f;
+      broken->align(out, guess);
+      const auto Tb = broken->getFinalTransformation();
+      std::printf("no_device converged %d guess_kept %d\n", (int)broken->hasConverged(), (int)(Tb.data()[12] == 0.25f && Tb.data()[0] == 1.0f));
+    }
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 3;

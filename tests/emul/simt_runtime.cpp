@@ -293,27 +293,87 @@ extern "C" void simt_read_counters(unsigned long long* out2) {
 // ------------------------------------------------------------------------------------------------ hgs_comm.h on the host
 // single-rank stand-in for the RCCL exchange step: the "all-gather" of one rank is a copy
 #include "../../hdl_graph_slam_amd/csrc/hgs_comm.h"
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+// In-process stand-in for RCCL: the ranks of a communicator are engines driven from different host threads of ONE process (the
+// emulated "devices" share the address space), meeting in a mutex / condition-variable rendezvous keyed by the unique id.  What it
+// lets the CPU tests execute is the N > 1 path of hgs_loop_match_batch_sharded itself: headers, padding, merge, the failure paths.
 namespace hgs {
+namespace {
+struct Group {
+  std::mutex m;
+  std::condition_variable cv;
+  int world = 1, arrived = 0, departed = 0;
+  long generation = 0;
+  bool aborted = false;
+  std::vector<const void*> send;
+};
+std::mutex g_groups_mutex;
+std::map<std::string, std::shared_ptr<Group>> g_groups;
+unsigned g_next_id = 1;
+}  // namespace
 struct Comm {
   int rank, world;
+  std::shared_ptr<Group> group;
 };
 int comm_unique_id(void* id_out, char*, size_t) {
+  std::lock_guard<std::mutex> lock(g_groups_mutex);
   memset(id_out, 0x5a, kCommUniqueIdBytes);
+  const unsigned id = g_next_id++;
+  memcpy(id_out, &id, sizeof(id));
   return 0;
 }
-int comm_create(Comm** out, int rank, int world, const void*, int, char* err, size_t cap) {
-  if (world != 1) {
-    if (err && cap) snprintf(err, cap, "the host emulation has one rank");
+int comm_create(Comm** out, int rank, int world, const void* id, int, char* err, size_t cap) {
+  std::lock_guard<std::mutex> lock(g_groups_mutex);
+  const std::string key((const char*)id, kCommUniqueIdBytes);
+  std::shared_ptr<Group>& g = g_groups[key];
+  if (!g) {
+    g = std::make_shared<Group>();
+    g->world = world;
+    g->send.assign(world, nullptr);
+  }
+  if (g->world != world) {
+    if (err && cap) snprintf(err, cap, "ranks disagree on the world size");
     return 1;
   }
-  *out = new Comm{rank, world};
+  *out = new Comm{rank, world, g};
   return 0;
 }
 void comm_destroy(Comm* c) { delete c; }
+void comm_abort(Comm* c) {
+  if (!c || !c->group) return;
+  std::lock_guard<std::mutex> lock(c->group->m);
+  c->group->aborted = true;
+  c->group->cv.notify_all();
+}
 int comm_rank(const Comm* c) { return c->rank; }
 int comm_world(const Comm* c) { return c->world; }
-int comm_all_gather(Comm*, const void* send, void* recv, size_t bytes_per_rank, hipStream_t, char*, size_t) {
-  memmove(recv, send, bytes_per_rank);
+int comm_all_gather(Comm* c, const void* send, void* recv, size_t bytes_per_rank, hipStream_t, char* err, size_t cap) {
+  Group& g = *c->group;
+  std::unique_lock<std::mutex> lock(g.m);
+  auto aborted = [&]() {
+    if (err && cap) snprintf(err, cap, "the communicator has been aborted");
+    return 1;
+  };
+  if (g.aborted) return aborted();
+  // the previous collective's send buffers are released once everybody has left it
+  g.cv.wait(lock, [&] { return g.departed == 0 || g.aborted; });
+  if (g.aborted) return aborted();
+  g.send[c->rank] = send;
+  const long gen = g.generation;
+  if (++g.arrived == g.world) {
+    g.arrived = 0, g.departed = g.world, g.generation++;
+    g.cv.notify_all();
+  } else {
+    g.cv.wait(lock, [&] { return g.generation != gen || g.aborted; });
+    if (g.generation == gen) return aborted();
+  }
+  for (int r = 0; r < g.world; r++) memmove((char*)recv + (size_t)r * bytes_per_rank, g.send[r], bytes_per_rank);
+  if (--g.departed == 0) g.cv.notify_all();
   return 0;
 }
 }  // namespace hgs

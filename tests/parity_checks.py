@@ -261,3 +261,36 @@ def check_ndt_edge_cases(make_engine):
         if not np.isnan(b).any():
             assert bytes(re.final_transformation) == bytes(ro.final_transformation), (name, synth.pose_error(a, b))
     e.close()
+
+
+NDT_DEVIATION_MODES = (("DIRECT7 @ 1.0 m (every launch file)", 1.0, O.HGS_DIRECT7), ("DIRECT1 @ 0.5 m", 0.5, O.HGS_DIRECT1), ("KDTREE @ 1.0 m", 1.0, O.HGS_KDTREE))
+
+
+def ndt_serial_sum_deviation(make_exact, tgt, src, T, n_guesses=100, seed=0, modes=NDT_DEVIATION_MODES):
+    """How far the order-independent exact sum of the per-point NDT contributions (what the device computes; the oracle's sum
+    mode 1) ends from the upstream-faithful SERIAL double sum (ndt_omp adds the per-point results in index order: sum mode 0),
+    run for run, to convergence.  make_exact(params) -> an engine with setInputTarget / setInputSource / align (the HIP engine, or
+    the oracle in sum mode 1).  Returns one record per neighbourhood mode: the number of guesses that end more than the north-star
+    tolerance (1e-3 m / 1e-3 rad) apart or with another iteration count, and the largest differences."""
+    out = []
+    guesses = ndt_guesses(T, n=n_guesses, seed=seed)
+    for label, res, search in modes:
+        p = O.default_params(O.HGS_NDT_OMP)
+        p.resolution, p.neighbor_search = res, search
+        exact, serial = make_exact(p), make_oracle(p)
+        for r in (exact, serial):
+            r.setInputTarget(tgt)
+            r.setInputSource(src)
+        beyond, other_iters, dts, drs = 0, 0, [], []
+        for g in guesses:
+            re, rs = exact.align(g), serial.align(g)
+            dt, dr = synth.pose_error(re.matrix(), rs.matrix())
+            dts.append(float(dt)), drs.append(float(dr))
+            beyond += 0 if (dt <= POSE_TOL_M and dr <= POSE_TOL_RAD) else 1
+            other_iters += 0 if re.iterations == rs.iterations else 1
+        out.append({"mode": label, "resolution": res, "neighbor_search": int(search), "guesses": len(guesses), "beyond_1e-3": beyond,
+                    "other_iteration_count": other_iters, "max_dt_m": max(dts), "max_dr_rad": max(drs),
+                    "p99_dt_m": float(np.percentile(dts, 99)), "median_dt_m": float(np.median(dts))})
+        if hasattr(exact, "close"):
+            exact.close()
+    return out

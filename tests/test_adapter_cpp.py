@@ -51,6 +51,7 @@ def test_adapter_matches_python_mirror(tmp_path, method):
     r = reg.align(np.eye(4))
     assert np.array_equal(Tc, r.matrix())                       # same library, same inputs: identical bits
     assert abs(float(out[2].split()[1]) - reg.getFitnessScore()) < 1e-9      # printed with 12 significant digits
+    assert out[4] == "no_device converged 0 guess_kept 1"              # hgs_create failure: no exception, hasConverged() false, guess kept
     reg.close()
 
 

@@ -246,3 +246,45 @@ def test_sharded_batch_two_ranks_on_one_gpu():
     for rank, _, blob, b in res:
         assert blob == rec.tobytes() and b == best
     one.close()
+
+
+def test_merge_of_gathered_shard_records_is_plain_host_code():
+    """hgs_debug_merge_shard_records — the merge step of hgs_loop_match_batch_sharded (hgs_engine.hip), replacing the loop of
+    loop_detector.hpp:135-154 on a multi-GPU node — called in the REAL library on this CPU-only box: three ranks with uneven
+    shards, padding slots, a rank that announced records but sent padding (it failed after the header), an out-of-range id and a
+    candidate two ranks report."""
+    import ctypes as C
+    from hdl_graph_slam_amd import _lib as L
+    lib = L.lib()
+    world, per, n_total = 3, 3, 7
+    g = np.zeros(world * per, dtype=L.RESULT_DTYPE)
+    g["candidate_id"] = -1
+    g["fitness_score"] = L.DBL_MAX
+
+    def put(rank, slot, cid, fit, conv=1):
+        r = g[rank * per + slot]
+        r["candidate_id"], r["fitness_score"], r["converged"], r["iterations"] = cid, fit, conv, 3 + cid
+    put(0, 0, 0, 0.5), put(0, 1, 3, 0.2), put(0, 2, 6, 0.9)      # rank 0: three records
+    put(1, 0, 1, 0.3), put(1, 1, 4, 0.2, conv=0)                 # rank 1: two records + one padding slot
+    put(2, 1, 5, 0.1)                                            # rank 2 announced 2 records: slot 0 is padding (it failed), slot 1 is real
+    counts = np.array([3, 2, 2], np.int32)
+    out = np.zeros(n_total, dtype=L.RESULT_DTYPE)
+    dup = C.c_int32(123)
+    vp = C.c_void_p
+    assert lib.hgs_debug_merge_shard_records(g.ctypes.data_as(vp), counts.ctypes.data_as(vp), world, per, n_total, out.ctypes.data_as(vp), C.byref(dup)) == L.HGS_OK
+    assert dup.value == -1 and list(out["candidate_id"]) == list(range(n_total))
+    assert list(out["converged"]) == [1, 1, 0, 1, 0, 1, 1]                      # 2: nobody reported it; 4: reported, not converged
+    assert out["fitness_score"][2] == L.DBL_MAX and out["iterations"][2] == 0
+    assert list(out["fitness_score"][[0, 1, 3, 5, 6]]) == [0.5, 0.3, 0.2, 0.1, 0.9]
+    best = C.c_int32(-1)
+    assert lib.hgs_select_best(out.ctypes.data_as(vp), n_total, C.byref(best)) == L.HGS_OK and best.value == 5
+    # slots beyond a rank's count are ignored even when they carry an id; ids outside [0, n_total) are dropped
+    put(1, 2, 2, 0.01)
+    put(2, 0, 99, 0.0)
+    assert lib.hgs_debug_merge_shard_records(g.ctypes.data_as(vp), counts.ctypes.data_as(vp), world, per, n_total, out.ctypes.data_as(vp), C.byref(dup)) == L.HGS_OK
+    assert dup.value == -1 and not out["converged"][2]
+    # two ranks report candidate 3: flagged, first report kept
+    put(2, 0, 3, 0.7)
+    assert lib.hgs_debug_merge_shard_records(g.ctypes.data_as(vp), counts.ctypes.data_as(vp), world, per, n_total, out.ctypes.data_as(vp), C.byref(dup)) == L.HGS_OK
+    assert dup.value == 3 and out["fitness_score"][3] == 0.2
+    assert lib.hgs_debug_merge_shard_records(None, counts.ctypes.data_as(vp), world, per, n_total, out.ctypes.data_as(vp), C.byref(dup)) == L.HGS_ERR_INVALID_ARGUMENT

@@ -286,6 +286,7 @@ def test_cpp_adapter_end_to_end(simt_library, tmp_path, method):
     r = e.align(np.eye(4))
     assert np.array_equal(Tc, r.matrix())
     assert abs(float(out[2].split()[1]) - e.getFitnessScore()) < 1e-9
+    assert out[4] == "no_device converged 0 guess_kept 1"   # an engine that cannot be created does not throw into the caller
     if method == 0:
         dt, dr = synth.pose_error(Tc.astype(np.float64), o.align(np.eye(4)).matrix())
         assert dt < 1e-5 and dr < 1e-5
@@ -510,3 +511,96 @@ def test_approx_voxelgrid_in_eviction_order():
 
 def test_ndt_edge_cases():
     PC.check_ndt_edge_cases(_engine)
+
+
+# ---- hgs_loop_match_batch_sharded with TWO ranks: two engines driven from two host threads of this process, the emulated
+# communicator (tests/emul/simt_runtime.cpp) standing in for RCCL.  What runs is the C entry point itself: header gather, shard
+# sizing, device-built records, padding, merge, and the rule that a rank whose own share is unusable still takes part.
+def _two_ranks(world, body):
+    import threading
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    uid = RegistrationHIP.comm_unique_id()
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            out[rank] = body(rank, uid)
+        except Exception as exc:  # noqa: BLE001
+            errs.append((rank, repr(exc)))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in th), "a rank is still blocked in the collective"
+    assert not errs, errs
+    return out
+
+
+def test_sharded_batch_two_ranks_in_process(simt_library):
+    from hdl_graph_slam_amd import _lib as L, workloads
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    n_total, world = 5, 2
+    wl = workloads.make_loop_closure_set("VLP-16", scene_seed=3, n_candidates=n_total, n_distinct=3, downsample=0.5)
+    shards = [[0, 3, 4], [1, 2]]   # uneven on purpose: max(shard) slots travel, the smaller shard pads
+
+    def body(rank, uid):
+        reg = select_registration_method({"registration_method": "FAST_GICP"}, device_id=0)
+        reg.setInputTarget(wl.target)
+        reg.comm_init(rank, world, uid)
+        mine = shards[rank]
+        rec, best = reg.loop_match_batch_sharded([reg.upload(wl.candidates[i]) for i in mine], mine, [wl.guesses[i] for i in mine], n_total, 4.0)
+        reg.close()
+        return rec.tobytes(), best
+    res = _two_ranks(world, body)
+    one = select_registration_method({"registration_method": "FAST_GICP"}, device_id=0)
+    one.setInputTarget(wl.target)
+    rec, best = one.loop_match_batch([one.upload(c) for c in wl.candidates], wl.guesses, 4.0)
+    rec["candidate_id"] = np.arange(n_total)
+    one.close()
+    for blob, b in res:
+        assert blob == rec.tobytes() and b == best   # every rank: all records, candidate order, bits of the unsharded batch
+
+
+def test_sharded_batch_rank_without_a_usable_share_does_not_block_the_others(simt_library):
+    from hdl_graph_slam_amd import _lib as L, workloads
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    n_total, world = 4, 2
+    wl = workloads.make_loop_closure_set("VLP-16", scene_seed=4, n_candidates=n_total, n_distinct=2, downsample=0.5)
+
+    def body(rank, uid):
+        reg = select_registration_method({"registration_method": "FAST_GICP"}, device_id=0)
+        if rank == 0:
+            reg.setInputTarget(wl.target)   # rank 1 never got the query keyframe: HGS_ERR_NO_TARGET, after the exchange
+        reg.comm_init(rank, world, uid)
+        mine = [i for i in range(n_total) if i % world == rank]
+        rec, best, rc = reg.loop_match_batch_sharded([reg.upload(wl.candidates[i]) for i in mine], mine, [wl.guesses[i] for i in mine], n_total, 4.0,
+                                                     return_status=True)
+        reg.close()
+        return rec.copy(), best, rc
+    (rec0, best0, rc0), (rec1, best1, rc1) = _two_ranks(world, body)
+    assert rc0 == L.HGS_OK and rc1 == L.HGS_ERR_NO_TARGET
+    assert rec0.tobytes() == rec1.tobytes() and best0 == best1          # both hold the same merged list
+    assert rec0["converged"][0::2].all() and not rec0["converged"][1::2].any()
+    assert (rec0["fitness_score"][1::2] == L.DBL_MAX).all() and list(rec0["candidate_id"]) == list(range(n_total))
+    assert best0 in (0, 2)
+
+
+def test_sharded_batch_flags_a_candidate_two_ranks_report(simt_library):
+    from hdl_graph_slam_amd import _lib as L, workloads
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    n_total, world = 3, 2
+    wl = workloads.make_loop_closure_set("VLP-16", scene_seed=4, n_candidates=n_total, n_distinct=2, downsample=0.5)
+    shards = [[0, 1], [1, 2]]   # candidate 1 on both ranks: a broken partition
+
+    def body(rank, uid):
+        reg = select_registration_method({"registration_method": "FAST_GICP"}, device_id=0)
+        reg.setInputTarget(wl.target)
+        reg.comm_init(rank, world, uid)
+        mine = shards[rank]
+        rec, best, rc = reg.loop_match_batch_sharded([reg.upload(wl.candidates[i]) for i in mine], mine, [wl.guesses[i] for i in mine], n_total, 4.0,
+                                                     return_status=True)
+        reg.close()
+        return rc, bool(rec["converged"].all())
+    res = _two_ranks(world, body)
+    assert [r[0] for r in res] == [L.HGS_ERR_INVALID_ARGUMENT] * 2 and all(r[1] for r in res)
