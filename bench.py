@@ -96,7 +96,7 @@ def oracle_params(reg):
     return O, p
 
 
-def best_cpu(run_sample, unit, sample_text):
+def best_cpu(run_sample, unit, sample_text, single_thread=None):
     """The oracle (a port of fast_gicp / ndt_omp, OpenMP over points) on a bounded sample, at the best of a few thread counts:
     reg_num_threads = 0 means "all cores" upstream, which oversubscribes badly on a 2 x 128-thread host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -111,6 +111,10 @@ def best_cpu(run_sample, unit, sample_text):
     out = {"value": round(best[0], 4), "unit": unit, "cores": best[1], "kind": "port", "host_threads_available": ncpu,
            "sample": sample_text + "; best of OMP thread counts 8/16/32/64"}
     out.update(best[2])
+    if single_thread is not None:   # OMP_NUM_THREADS in {1, nproc} — the one-thread column on a smaller sample
+        O.set_num_threads(1)
+        rate1, _ = single_thread(O)
+        out["single_thread"] = {"value": round(rate1, 4), "unit": unit, "cores": 1, "sample": "the first unit of the sample above"}
     return out
 
 
@@ -122,7 +126,15 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="0: the metric's configuration (default); 2..5: BASELINE.json configs")
     ap.add_argument("--candidates", type=int, default=0, help="candidate keyframes per GPU per step (default 64; config 4: 512 / ranks)")
     ap.add_argument("--sensor", default="")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct ray-cast scans behind the candidates")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct ray-cast scans behind the candidates (default 16; 8 with --mild-set)")
+    ap.add_argument("--mild-set", action="store_true", help="the candidate set rounds 1 and 2 benchmarked (8 distinct scans within 4 m of the query, guess noise "
+                    "0.3 m / 1 deg) instead of SURVEY 8d's (within 20 m, 0.5 m / 2 deg): for continuity with the earlier lines")
+    ap.add_argument("--no-ndt-record", action="store_true", help="default command only: skip the NDT_OMP (factory default engine) sub-record")
+    ap.add_argument("--ndt-steps", type=int, default=8, help="timed steps of the NDT_OMP sub-record")
+    ap.add_argument("--fitness-max-range-variant", action="store_true", help="config 4: also time the batch with fitness_score_max_range = 4.0")
+    ap.add_argument("--cpu-single-thread", action="store_true", help="cpu_baseline also carries the one-thread rate (one unit of the sample)")
+    ap.add_argument("--oracle-sweeps", type=int, default=12, help="config 3: sweeps the CPU oracle runs through the same caller for the trajectory agreement (0: none)")
+    ap.add_argument("--speed", type=float, default=0.0, help="config 3: vehicle speed in m/s (default: 8.0 as SURVEY 8d, plus a 3.0 m/s sub-record)")
     ap.add_argument("--method", default="", choices=["", "FAST_GICP", "FAST_VGICP", "NDT_OMP"])
     ap.add_argument("--downsample", type=float, default=0.0, help="voxel size applied to every cloud (0 = raw scans, the metric's configuration)")
     ap.add_argument("--seeds", type=int, default=-1, help="scene seeds: the timed region runs on seed 0, the others are reported next to it "
@@ -221,12 +233,34 @@ def base_line(ctx, value, unit, steps, dt, dtype, workload, extra_config):
 
 # ============================================================================================== loop-closure batch (default, config 4)
 def run_loop_batch(ctx):
-    a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
+    """The metric's configuration (default) and config 4.  One engine per method; the primary method's line is the JSON line, and on
+    the default command (FAST_GICP, N = 1) the factory-default engine NDT_OMP (src/hdl_graph_slam/registrations.cpp:26,101-120) is
+    measured on the same candidate set right after it and reported as the `ndt_omp` sub-record."""
+    a, rank, world = ctx["args"], ctx["rank"], ctx["world"]
     cfg4 = a.config == 4
     method = a.method or "FAST_GICP"
-    sensor = a.sensor or ("HDL-32E" if cfg4 else "HDL-64E")
     B = a.candidates or ((512 + world - 1) // world if cfg4 else 64)
     steps = a.steps or (16 if cfg4 else 64)   # >= 1 s of timed region at the measured 62 / 16 ms per step
+    out = measure_loop_batch(ctx, method, B, steps, ctx["n_seeds"], with_cpu=not a.no_cpu_baseline, with_resident=True, max_range=None)
+    if cfg4 and a.fitness_max_range_variant and world == 1:
+        v = measure_loop_batch(ctx, method, B, max(2, steps // 4), 1, with_cpu=False, with_resident=False, max_range=4.0)
+        out["fitness_score_max_range_4"] = {k: v[k] for k in ("value", "ms_per_step", "steps", "converged", "best_candidate", "num_inliers_mean")}
+    if a.config == 0 and method == "FAST_GICP" and not a.no_ndt_record and world == 1:
+        nd = measure_loop_batch(ctx, "NDT_OMP", B, a.ndt_steps, 1, with_cpu=not a.no_cpu_baseline, with_resident=False, max_range=None)
+        out["ndt_omp"] = {k: nd[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
+                                             "mean_linearizations", "pose_rmse_vs_ground_truth", "best_candidate", "roofline", "cpu_baseline")}
+        out["ndt_omp"]["workload"] = nd["config"]["workload"]
+    return out
+
+
+def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, max_range):
+    a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
+    cfg4 = a.config == 4
+    sensor = a.sensor or ("HDL-32E" if cfg4 else "HDL-64E")
+    fit_range = L.DBL_MAX if max_range is None else float(max_range)
+    set_kwargs = dict(ctx["workloads"].MILD_LOOP_SET) if a.mild_set else {}
+    if a.distinct:
+        set_kwargs["n_distinct"] = a.distinct
     pnh = {"registration_method": method}
     if method in ("NDT_OMP", "FAST_VGICP"):
         pnh["reg_resolution"] = 1.0   # launch files use 1.0 (NDT factory default 0.5)
@@ -256,7 +290,8 @@ def run_loop_batch(ctx):
 
     def load(seed):
         # every rank holds the query keyframe (replicated target) and its own shard of the N*B candidates
-        wl = ctx["workloads"].make_loop_closure_set(sensor, scene_seed=seed, n_candidates=B, n_distinct=min(a.distinct, B), downsample=a.downsample or None)
+        wl = ctx["workloads"].make_loop_closure_set(sensor, scene_seed=seed, n_candidates=B, downsample=a.downsample or None,
+                                                    **dict(set_kwargs, n_distinct=min(set_kwargs.get("n_distinct", 16), B)))
         rng = np.random.default_rng(100 + rank)
         if rank > 0:  # different guesses per rank so that the shards are not identical problems
             for g in wl.guesses:
@@ -273,9 +308,9 @@ def run_loop_batch(ctx):
             reg.setInputTarget(d_target)
             ids = np.arange(rank, world * B, world, dtype=np.int32)   # candidate c lives on rank c mod world
             if shard is not None and exchange["kind"].startswith("hgs_"):
-                allrec, best = reg.loop_match_batch_sharded(d_cands, ids, wl.guesses, world * B, L.DBL_MAX)
+                allrec, best = reg.loop_match_batch_sharded(d_cands, ids, wl.guesses, world * B, fit_range)
                 return allrec[ids], best
-            rec, best = reg.loop_match_batch(d_cands, wl.guesses, L.DBL_MAX)
+            rec, best = reg.loop_match_batch(d_cands, wl.guesses, fit_range)
             if shard is not None:
                 rec["candidate_id"] = ids
                 allrec = shard.gather_records(rec, world * B)
@@ -304,18 +339,21 @@ def run_loop_batch(ctx):
 
     # ---- informational: the same batch with the candidate keyframes' index + covariances kept resident between detections
     # (what a keyframe device cache gives; never `value`)
-    step(cold=False)
-    barrier()
-    tw = time.perf_counter()
-    for _ in range(steps):
+    dt_warm = None
+    if with_resident:
         step(cold=False)
-    barrier()
-    dt_warm = time.perf_counter() - tw
+        barrier()
+        tw = time.perf_counter()
+        for _ in range(steps):
+            step(cold=False)
+        barrier()
+        dt_warm = time.perf_counter() - tw
 
     # ---- accuracy of the timed results (rank-local): vs ground truth
     et = [synth.pose_error(np.array(r["final_transformation"]).reshape(4, 4).T, Tg) for r, Tg in zip(rec, wl.T_gt)]
     rmse_t = float(np.sqrt(np.mean([e[0] ** 2 for e in et])))
     rmse_r = float(np.sqrt(np.mean([e[1] ** 2 for e in et])))
+    within = int(np.sum([e[0] < 0.3 and e[1] < 0.02 for e in et]))   # candidates that ended near their ground truth (GICP on raw rings: decimetres)
 
     # ---- roofline of the dominant kernel: HIP events on the handle's stream around every launch of each stage
     reg.profile_enable(True)
@@ -336,55 +374,67 @@ def run_loop_batch(ctx):
     roofline = roofline_of(method, prof, units, prof_steps,
                            "whole-device launches (all candidates of the rank in one launch, HIP events on the engine's stream); the timed region "
                            "runs the same kernels split over 2 to 4 concurrent lanes (by batch size), whose launches overlap each other",
-                           pmc_ok=(sensor == "HDL-64E" and B == 64 and not a.downsample))
+                           pmc_ok=(sensor == "HDL-64E" and B == 64 and not a.downsample and not a.mild_set))
 
     # ---- the other scene seeds (informational: spread of the metric over scenes)
     by_seed = [round(world * B * steps / dt, 1)]
-    for seed in range(1, ctx["n_seeds"]):
+    its_by_seed = [round(float(np.mean(rec["iterations"])), 2)]
+    for seed in range(1, n_seeds):
         for c in d_cands:
             c.close()
         d_target.close()
         wl_s, d_target, d_cands = load(seed)
         step_s = make_step(wl_s, d_target, d_cands)
         step_s()
-        dts, _, _, _ = timed(step_s, steps)
-        by_seed.append(round(world * B * steps / max_over_ranks(ctx, dts), 1))
+        steps_s = max(4, steps // 4)
+        dts, _, rec_s, _ = timed(step_s, steps_s)
+        by_seed.append(round(world * B * steps_s / max_over_ranks(ctx, dts), 1))
+        its_by_seed.append(round(float(np.mean(rec_s["iterations"])), 2))
 
     # ---- CPU baseline: rank 0, N == 1
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and with_cpu:
         O, p = oracle_params(reg)
         k = min(a.cpu_sample, B)
 
-        def sample(O):
+        def sample(O, kk=k):
             o = O.OracleRegistration(p)
             o.setInputTarget(wl.target)   # target structures are built once per batch in the reference too
             o.setInputSource(wl.candidates[0])
             o.align(wl.guesses[0])        # warm-up (first-touch, thread pool, target covariances)
             tc = time.perf_counter()
             dpose = []
-            for i in range(k):
+            for i in range(kk):
                 o.setInputSource(wl.candidates[i])
                 ro = o.align(wl.guesses[i])
                 o.getFitnessScore()
                 dpose.append(synth.pose_error(np.array(rec[i]["final_transformation"]).reshape(4, 4).T, ro.matrix()))
-            return k / (time.perf_counter() - tc), {"max_pose_diff_vs_gpu_m": float(max(d[0] for d in dpose)), "max_pose_diff_vs_gpu_rad": float(max(d[1] for d in dpose))}
-        cpu = best_cpu(sample, "registrations/sec", f"{k} of the {B} candidate registrations (setInputSource + align + getFitnessScore), target structures prebuilt")
+            return kk / (time.perf_counter() - tc), {"max_pose_diff_vs_gpu_m": float(max(d[0] for d in dpose)), "max_pose_diff_vs_gpu_rad": float(max(d[1] for d in dpose))}
+        cpu = best_cpu(sample, "registrations/sec", f"{k} of the {B} candidate registrations (setInputSource + align + getFitnessScore), target structures prebuilt",
+                       single_thread=(lambda O: sample(O, 1)) if a.cpu_single_thread else None)
 
     out = base_line(ctx, world * B * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
                     f"loop-closure batch: {B} candidate keyframes/GPU x {sensor} (~{int(np.mean(n_pts))} pts) vs 1 query keyframe, "
                     f"{method}{' with the opt-in More-Thuente line search (not the reference behaviour)' if pnh.get('reg_ndt_line_search') else ''}"
                     f"{' (covariance regularisation ' + a.regularization + ')' if a.regularization else ''}"
-                    f" + getFitnessScore, cold (index + covariances rebuilt every step)",
+                    f" + getFitnessScore{'' if max_range is None else f' (max_range {max_range})'}, cold (index + covariances rebuilt every step); candidate set: "
+                    + ("rounds 1-2 'mild' set (8 distinct scans within 4 m, guess noise 0.3 m / 1 deg)" if a.mild_set else
+                       "SURVEY 8d (distinct ray-casts at poses within 20 m of the query, guess = ground truth + 0.5 m / 2 deg noise, z forced to 0)"),
                     {"candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": method,
+                     "distinct_scans": min(set_kwargs.get("n_distinct", 16), B),
                      "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU", "exchange": exchange["kind"]})
     out.update({"step_ms": percentiles(per_step), "timed_region_s": round(dt, 3),
                 "value_by_scene_seed": by_seed, "value_mean_std_over_seeds": [round(float(np.mean(by_seed)), 1), round(float(np.std(by_seed)), 1)],
-                "pose_rmse_vs_ground_truth": {"translation_m": round(rmse_t, 5), "rotation_rad": round(rmse_r, 6)},
-                "resident_keyframes_value": round(world * B * steps / dt_warm, 3) if world == 1 else None,
+                "mean_iterations_by_scene_seed": its_by_seed,
+                "pose_rmse_vs_ground_truth": {"translation_m": round(rmse_t, 5), "rotation_rad": round(rmse_r, 6), "within_0.3m_0.02rad": within, "of": len(et)},
+                "resident_keyframes_value": round(world * B * steps / dt_warm, 3) if (world == 1 and dt_warm) else None,
                 "converged": int(np.sum(rec["converged"])), "mean_iterations": float(np.mean(rec["iterations"])),
                 "mean_linearizations": float(np.mean(rec["lm_tries"])), "best_candidate": int(best),
+                "num_inliers_mean": float(np.mean(rec["num_inliers"])),
                 "roofline": roofline, "cpu_baseline": cpu})
+    for c in d_cands:
+        c.close()
+    d_target.close()
     reg.close()
     return out
 
@@ -490,7 +540,8 @@ def run_single_align(ctx):
             el = time.perf_counter() - tc
             d = synth.pose_error(r.matrix(), ro.matrix())
             return k / el, {"max_pose_diff_vs_gpu_m": float(d[0]), "max_pose_diff_vs_gpu_rad": float(d[1])}
-        cpu = best_cpu(sample, "registrations/sec", f"{k} cold align(s) of the same pair (setInputTarget + setInputSource + align)")
+        cpu = best_cpu(sample, "registrations/sec", f"{k} cold align(s) of the same pair (setInputTarget + setInputSource + align)",
+                       single_thread=sample if a.cpu_single_thread else None)
 
     out = base_line(ctx, world * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
                     (f"config 5: dense 1 M-point pair, {method}, max_correspondence_distance 1.0, single cold align" if dense else
@@ -511,13 +562,26 @@ def run_odometry(ctx):
     """Config 3: ScanMatchingOdometryNodelet::matching (apps/scan_matching_odometry_nodelet.cpp:165-262) on a 64-beam stream with
     the keyframe rule of launch/hdl_graph_slam_kitti.launch:41-43; a step = one sweep, host buffer in -> pose out (upload, index /
     voxelisation when the keyframe switches, align, result download ALL inside the timed step).  The path is sequential in time:
-    replicas only at N > 1."""
+    replicas only at N > 1.  SURVEY 8d's stream drives at 8 m/s (0.8 m per sweep); the line also carries the same measurement at
+    3 m/s (`at_3_mps`, the speed rounds 1-2 reported) and, for both, how far the CPU oracle run through the same caller ends from
+    the device's trajectory (`oracle_stream`): whether NDT at resolution 1.0 keeps track is a property of the algorithm on this
+    scene, identical on both sides."""
+    a = ctx["args"]
+    speeds = [a.speed] if a.speed > 0 else [8.0, 3.0]
+    out = odometry_at_speed(ctx, speeds[0], ctx["n_seeds"], not a.no_cpu_baseline)
+    for sp in speeds[1:]:
+        o = odometry_at_speed(ctx, sp, 1, False)
+        out[f"at_{sp:g}_mps".replace(".", "_")] = {k: o[k] for k in ("value", "ms_per_step", "steps", "latency_ms", "mean_iterations", "max_iterations", "keyframes",
+                                                                     "trajectory_error_vs_ground_truth", "oracle_stream")}
+    return out
+
+
+def odometry_at_speed(ctx, speed, n_seeds, with_cpu):
     a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
     from hdl_graph_slam_amd.odometry import ScanMatchingOdometry
     method = a.method or "NDT_OMP"
     sensor = a.sensor or "HDL-64E"
     steps = a.steps or 60
-    speed = 3.0   # m/s at 10 Hz: 0.3 m per sweep (at KITTI's 0.8 m per sweep the NDT basin at resolution 1.0 loses track on this scene; the oracle does identically)
     pnh = {"registration_method": method, "reg_resolution": 1.0}
     kf = dict(keyframe_delta_trans=5.0, keyframe_delta_angle=2.0, keyframe_delta_time=10000.0)
     reg = ctx["select_registration_method"](pnh, device_id=ctx["local_rank"])
@@ -541,9 +605,9 @@ def run_odometry(ctx):
         dt = time.perf_counter() - t0
         gt0 = np.linalg.inv(stream.poses[0])
         err = [synth.pose_error(e, gt0 @ p) for e, p in zip(est, stream.poses)]
-        return dt, per, its, err, stream, od
+        return dt, per, its, err, stream, od, est
 
-    dt, per_step, its, err, stream, od = run(0, a.warmup, steps)
+    dt, per_step, its, err, stream, od, est = run(0, a.warmup, steps)
     dt = max_over_ranks(ctx, dt)
     n_pts = int(np.mean([len(c) for c in stream.scans]))
 
@@ -562,34 +626,50 @@ def run_odometry(ctx):
 
     by_seed = [round(world * steps / dt, 2)]
     n_extra = max(10, steps // 3)
-    for seed in range(1, ctx["n_seeds"]):
-        dts, _, _, _, _, _ = run(seed, 1, n_extra)
+    for seed in range(1, n_seeds):
+        dts, _, _, _, _, _, _ = run(seed, 1, n_extra)
         by_seed.append(round(world * n_extra / max_over_ranks(ctx, dts), 2))
 
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    # ---- the CPU oracle through the same caller on the head of the same stream: rate (cpu_baseline) and agreement of the trajectories
+    cpu, oracle_stream = None, None
+    if rank == 0 and world == 1 and (with_cpu or a.oracle_sweeps > 0):
         O, p = oracle_params(reg)
         k = max(2, min(a.cpu_sample, 4))
-
-        def sample(O):
+        if a.oracle_sweeps > 0:
+            O.set_num_threads(min(32, os.cpu_count() or 1))
+            n_o = min(a.oracle_sweeps, len(stream.scans) - 1)
             oo = ScanMatchingOdometry(O.OracleRegistration(p), **kf)
-            oo.matching(stream.stamps[0], stream.scans[0])
-            tc = time.perf_counter()
-            for t, c in zip(stream.stamps[1:k + 1], stream.scans[1:k + 1]):
-                oo.matching(t, c)
-            return k / (time.perf_counter() - tc), {}
-        cpu = best_cpu(sample, "registrations/sec", f"the first {k} sweeps of the same stream through the same caller (setInputSource + align per sweep)")
+            eo = [oo.matching(t, c) for t, c in zip(stream.stamps[:n_o + 1], stream.scans[:n_o + 1])]
+            d = [synth.pose_error(x, y) for x, y in zip(est[:n_o + 1], eo)]
+            gt0 = np.linalg.inv(stream.poses[0])
+            eo_err = [synth.pose_error(e, gt0 @ pp) for e, pp in zip(eo, stream.poses)]
+            oracle_stream = {"sweeps": n_o, "max_translation_diff_vs_device_m": float(max(x[0] for x in d)), "max_rotation_diff_vs_device_rad": float(max(x[1] for x in d)),
+                             "oracle_final_translation_error_vs_ground_truth_m": round(float(eo_err[-1][0]), 4),
+                             "device_translation_error_at_the_same_sweep_m": round(float(err[n_o][0]), 4), "keyframes_oracle": oo.num_keyframes}
+        if with_cpu:
+            def sample(O):
+                oc = ScanMatchingOdometry(O.OracleRegistration(p), **kf)
+                oc.matching(stream.stamps[0], stream.scans[0])
+                tc = time.perf_counter()
+                for t, c in zip(stream.stamps[1:k + 1], stream.scans[1:k + 1]):
+                    oc.matching(t, c)
+                return k / (time.perf_counter() - tc), {}
+            cpu = best_cpu(sample, "registrations/sec", f"the first {k} sweeps of the same stream through the same caller (setInputSource + align per sweep)",
+                           single_thread=(lambda O: sample(O)) if a.cpu_single_thread else None)
 
+    rmse_t = float(np.sqrt(np.mean([e[0] ** 2 for e in err])))
     out = base_line(ctx, world * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
-                    f"config 3: {sensor} odometry stream (~{n_pts} pts/sweep, {speed} m/s at 10 Hz), {method}, frame-to-keyframe with the KITTI keyframe rule "
-                    f"(5 m / 2 rad), host buffer in -> pose out per sweep: H2D upload INCLUDED in every step",
-                    {"points_per_cloud": n_pts, "method": method, "parallelism": f"{world} replicas (the path is sequential in time)" if world > 1 else "single GPU"})
+                    f"config 3: {sensor} odometry stream (~{n_pts} pts/sweep, {speed:g} m/s at 10 Hz = {speed / 10:g} m per sweep), {method}, frame-to-keyframe with the KITTI "
+                    f"keyframe rule (5 m / 2 rad), host buffer in -> pose out per sweep: H2D upload INCLUDED in every step",
+                    {"points_per_cloud": n_pts, "method": method, "speed_mps": speed, "parallelism": f"{world} replicas (the path is sequential in time)" if world > 1 else "single GPU"})
     out.update({"latency_ms": dict(percentiles(per_step), p99=round(float(np.percentile(per_step, 99)), 3)), "step_ms": percentiles(per_step), "timed_region_s": round(dt, 3),
                 "mean_iterations": float(np.mean(its)), "max_iterations": int(max(its)), "keyframes": od.num_keyframes,
+                "us_per_iteration_p50": round(float(np.median(np.array(per_step) / np.maximum(np.array(its), 1))) * 1e3, 1),
                 "value_by_scene_seed": by_seed, "value_mean_std_over_seeds": [round(float(np.mean(by_seed)), 2), round(float(np.std(by_seed)), 2)],
-                "trajectory_error_vs_ground_truth": {"final_translation_m": round(err[-1][0], 4), "rmse_translation_m": round(float(np.sqrt(np.mean([e[0] ** 2 for e in err]))), 4),
-                                                     "rmse_rotation_rad": round(float(np.sqrt(np.mean([e[1] ** 2 for e in err]))), 5)},
-                "roofline": roofline, "cpu_baseline": cpu})
+                "trajectory_error_vs_ground_truth": {"final_translation_m": round(err[-1][0], 4), "rmse_translation_m": round(rmse_t, 4),
+                                                     "rmse_rotation_rad": round(float(np.sqrt(np.mean([e[1] ** 2 for e in err]))), 5),
+                                                     "keeps_track": bool(err[-1][0] < 2.0)},
+                "oracle_stream": oracle_stream, "roofline": roofline, "cpu_baseline": cpu})
     reg.close()
     return out
 

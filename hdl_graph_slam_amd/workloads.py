@@ -17,13 +17,16 @@ class LoopClosureSet:
     guesses: List[np.ndarray]         # initial guesses: GT + noise, z forced to 0 (loop_detector.hpp:137-142)
 
 
-def make_loop_closure_set(sensor: str, scene_seed: int, n_candidates: int, n_distinct: int = 8, downsample: float | None = None,
-                          guess_noise=(0.3, 1.0), spread: float = 4.0) -> LoopClosureSet:
-    """1 query keyframe + n_candidates candidate keyframes (config 4).
+def make_loop_closure_set(sensor: str, scene_seed: int, n_candidates: int, n_distinct: int = 16, downsample: float | None = None,
+                          guess_noise=(0.5, 2.0), spread: float = 20.0) -> LoopClosureSet:
+    """1 query keyframe + n_candidates candidate keyframes (config 4, SURVEY 8d: candidates at poses within 20 m of the query —
+    the gate of launch/hdl_graph_slam.launch:121 —, guesses = ground truth + noise of 0.5 m / 2 deg, z forced to 0 as
+    loop_detector.hpp:142 does).
 
-    `n_distinct` scans are ray-cast at poses within `spread` metres of the query (candidates pass the reference's
-    distance gate, launch/hdl_graph_slam.launch:121); every candidate is one of those scans expressed in its own randomly
-    displaced sensor frame, so each has a distinct, known ground-truth pose relative to the query."""
+    `n_distinct` scans are ray-cast at poses within `spread` metres of the query along the scene's free corridor; every
+    candidate is one of those scans expressed in its own randomly displaced sensor frame, so each has a distinct, known
+    ground-truth pose relative to the query.  guess_noise = (RMS translation error in metres, RMS rotation error in degrees).
+    Rounds 1 and 2 benchmarked a milder set (8 distinct scans within 4 m, noise 0.3 m / 1 deg): MILD_LOOP_SET below."""
     rng = np.random.default_rng(7000 + scene_seed)
     scene = synth.make_scene(scene_seed)
     pose_t = synth.pose_matrix([0.0, 0.0, 0.0], [0.0, 0.0, 0.0])
@@ -33,7 +36,7 @@ def make_loop_closure_set(sensor: str, scene_seed: int, n_candidates: int, n_dis
     scans, poses = [], []
     for j in range(n_distinct):
         xy = rng.uniform(-spread, spread, 2)
-        xy[1] *= 0.3   # stay inside the free corridor of the scene
+        xy[1] *= 0.3 * min(1.0, 4.0 / spread)   # stay inside the free corridor of the scene (+-1.2 m across)
         pose = synth.pose_matrix([xy[0], xy[1], 0.0], np.deg2rad([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-8, 8)]))
         sc = synth.scan(scene, sensor, pose, 3000 + 17 * scene_seed + j)
         if downsample:
@@ -53,6 +56,9 @@ def make_loop_closure_set(sensor: str, scene_seed: int, n_candidates: int, n_dis
         T_gt.append(Tg)
         guesses.append(g)
     return LoopClosureSet(target, cands, T_gt, guesses)
+
+
+MILD_LOOP_SET = dict(n_distinct=8, guess_noise=(0.3, 1.0), spread=4.0)   # the candidate set of the round-1 / round-2 bench lines
 
 
 @dataclasses.dataclass

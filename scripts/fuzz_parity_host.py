@@ -67,6 +67,7 @@ def make_engine(params):
 
 BACKEND = "emul"
 GUESS_SALT = 0
+SERIAL_SUM_DEVIATION = []   # (case, resolution, search, dt, dr) of the 3-iteration NDT prefixes against the oracle's serial-sum mode
 
 
 def run_case(name, tgt, src, T, quick):
@@ -98,10 +99,13 @@ def run_case(name, tgt, src, T, quick):
     for res, search in ((1.0, O.HGS_DIRECT7), (0.5, O.HGS_DIRECT1), (2.0, O.HGS_KDTREE)):
         p = O.default_params(O.HGS_NDT_OMP)
         p.resolution, p.neighbor_search, p.max_iterations = res, search, 3
-        # the product sums the per-point terms exactly (order-independent); the oracle's exact-sum mode is the like-for-like partner.
-        # Its default serial sum differs in the last bits, which a nearly singular Newton system (DIRECT1 at 0.5 m) turns into
-        # 1e-5 .. 1e-3 m within two iterations on some guesses — the same spread ndt_omp shows between thread counts.
+        # the product sums the per-point terms exactly (order-independent); the oracle's exact-sum mode (1) is the like-for-like
+        # partner and must agree to 1e-6.  The upstream-faithful serial sum (mode 0; ndt_omp reduces serially in index order) differs
+        # from it in the last bits of every pass, which a nearly singular Newton system (DIRECT1 at 0.5 m) can turn into
+        # 1e-5 .. 1e-3 m within the three iterations of this prefix on some guesses: BOTH comparisons are reported, the second
+        # as a number (the to-convergence measurement is scripts/ndt_sum_mode_deviation.py and the -m gpu test of the same name).
         e, o = make_engine(p), O.OracleRegistration(p).set_ndt_sum_mode(1)
+        o_serial = O.OracleRegistration(p)
         PC.load_pair(e, o, tgt, src)
         if len(o.ndt_cells()[0]) == 0:
             continue
@@ -112,6 +116,10 @@ def run_case(name, tgt, src, T, quick):
             if abs(so) > 0:
                 PC.check_ndt_derivatives(e, o, p6)
         PC.check_align(e, o, near, tol_m=1e-6, tol_rad=1e-6)
+        o_serial.setInputTarget(tgt)
+        o_serial.setInputSource(src)
+        dt, dr = synth.pose_error(e.align(near).matrix(), o_serial.align(near).matrix())
+        SERIAL_SUM_DEVIATION.append((name, res, int(search), float(dt), float(dr)))
     done.append("ndt")
     return done
 
@@ -141,6 +149,11 @@ def main():
             failures += 1
             print(f"FAIL {name}", flush=True)
             traceback.print_exc()
+    if SERIAL_SUM_DEVIATION:
+        dev = SERIAL_SUM_DEVIATION
+        beyond = [d for d in dev if d[3] > 1e-3 or d[4] > 1e-3]
+        print(f"NDT 3-iteration prefixes vs the SERIAL sum (ndt_omp's association, oracle mode 0): {len(dev)} runs, max {max(d[3] for d in dev):.2e} m / "
+              f"{max(d[4] for d in dev):.2e} rad, {len(beyond)} beyond 1e-3: {[(d[0], d[1], d[2]) for d in beyond]}")
     print(f"{failures} failing case(s), {time.time() - t0:.0f}s")
     sys.exit(1 if failures else 0)
 

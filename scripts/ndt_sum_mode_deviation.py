@@ -16,9 +16,10 @@ from hdl_graph_slam_amd import synth  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seeds = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2]
     O.set_num_threads(min(32, os.cpu_count() or 1))
     rows = []
-    for seed in (1, 2):
+    for seed in seeds:
         tgt, src, T = synth.make_pair("HDL-64E", seed, downsample=0.2)
         for r in PC.ndt_serial_sum_deviation(lambda p: PC.make_oracle(p).set_ndt_sum_mode(1), tgt, src, T, n_guesses=n, seed=seed):
             r["scene_seed"], r["points"] = seed, int(len(src))

@@ -172,10 +172,10 @@ def check_ndt_to_convergence(engine, params, tgt, src, guesses, bitwise=True, re
     accumulation; the oracle implements the same definition (sum mode 1) and ndt_omp's serial double sum (sum mode 0).
       * against sum mode 1: the final transformation is BIT-IDENTICAL with equal iteration and derivative-pass counts
         (bitwise=False, KDTREE neighbourhoods whose per-point cell order differs: 1e-9);
-      * against sum mode 0 (the upstream-faithful association): within the north-star tolerance 1e-3 m / 1e-3 rad with equal
-        iteration counts; runs that separate are counted, reported and must stay below a quarter of the guesses (they are
-        runs on which ndt_omp's iteration amplifies a last-bit difference of the sum, i.e. on which two builds of
-        ndt_omp itself would part)."""
+      * against sum mode 0 (the upstream-faithful association: ndt_omp adds the per-point results serially in index order, whatever
+        its thread count): within the north-star tolerance 1e-3 m / 1e-3 rad with equal iteration counts.  Runs that separate
+        are counted and reported; the bound is the measured one (profiles/r03_ndt_sum_mode_deviation.md: 0 of 2100 runs to
+        convergence): at most 2 % of the guesses, i.e. none of a set of fewer than 50."""
     exact, serial = make_oracle(params).set_ndt_sum_mode(1), make_oracle(params)
     for o in (exact, serial):
         o.setInputTarget(tgt)
@@ -200,7 +200,7 @@ def check_ndt_to_convergence(engine, params, tgt, src, guesses, bitwise=True, re
     if report is not None:
         report.append({"case": label, "points": int(len(src)), "guesses": len(guesses), "separated_from_serial_sum": separated,
                        "max_iterations_run": max(r["iterations"] for r in rows), "runs": rows})
-    assert separated * 4 <= len(guesses), (label, separated, rows)
+    assert separated * 50 <= len(guesses), (label, separated, rows)
     return rows
 
 

@@ -48,12 +48,17 @@ SMALL = ["--candidates", "2", "--distinct", "2", "--sensor", "VLP-16", "--downsa
 
 
 def test_single_rank_line():
-    rec = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", *SMALL, "--cpu-sample", "1"])
+    rec = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", *SMALL, "--cpu-sample", "1", "--ndt-steps", "2"])
     _check(rec, 1, 2, 1, 2)
     cpu = rec["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "registrations/sec" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     assert rec["roofline"]["kernel"] in ("k_gicp_linearize", "k_knn_cov", "k_ndt_pass", "k_fitness", "k_gicp_error")
     assert {"p10", "p50", "p90"} <= set(rec["step_ms"]) and len(rec["value_by_scene_seed"]) == 1
+    # the default command also measures the factory-default engine (registrations.cpp:26) on the same candidate set
+    nd = rec["ndt_omp"]
+    assert nd["value"] > 0 and nd["unit"] == "registrations/sec" and nd["steps"] == 2 and nd["dtype"] == "f32" and "NDT_OMP" in nd["workload"]
+    assert ROOFLINE <= set(nd["roofline"]) and nd["roofline"]["kernel"] in ("k_ndt_pass", "k_fitness") and nd["cpu_baseline"]["value"] > 0
+    assert "SURVEY 8d" in rec["config"]["workload"] and rec["config"]["distinct_scans"] == 2
 
 
 def test_two_ranks_through_torch_distributed_run():
