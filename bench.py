@@ -250,15 +250,21 @@ def run_loop_batch(ctx):
         out["ndt_omp"] = {k: nd[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
                                              "mean_linearizations", "pose_rmse_vs_ground_truth", "best_candidate", "roofline", "cpu_baseline")}
         out["ndt_omp"]["workload"] = nd["config"]["workload"]
+    if a.config == 0 and method == "FAST_GICP" and not a.mild_set and not a.no_ndt_record and world == 1:
+        # continuity with BENCH_r01 / BENCH_r02: the candidate set those lines were measured on (never `value`)
+        r2 = measure_loop_batch(ctx, method, B, max(4, steps // 2), 1, with_cpu=False, with_resident=False, max_range=None, mild=True)
+        out["r02_candidate_set"] = {k: r2[k] for k in ("value", "unit", "steps", "ms_per_step", "mean_iterations", "converged")}
+        out["r02_candidate_set"]["workload"] = r2["config"]["workload"]
     return out
 
 
-def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, max_range):
+def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, max_range, mild=None):
     a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
     cfg4 = a.config == 4
     sensor = a.sensor or ("HDL-32E" if cfg4 else "HDL-64E")
     fit_range = L.DBL_MAX if max_range is None else float(max_range)
-    set_kwargs = dict(ctx["workloads"].MILD_LOOP_SET) if a.mild_set else {}
+    mild = a.mild_set if mild is None else mild
+    set_kwargs = dict(ctx["workloads"].MILD_LOOP_SET) if mild else {}
     if a.distinct:
         set_kwargs["n_distinct"] = a.distinct
     pnh = {"registration_method": method}
@@ -374,7 +380,7 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
     roofline = roofline_of(method, prof, units, prof_steps,
                            "whole-device launches (all candidates of the rank in one launch, HIP events on the engine's stream); the timed region "
                            "runs the same kernels split over 2 to 4 concurrent lanes (by batch size), whose launches overlap each other",
-                           pmc_ok=(sensor == "HDL-64E" and B == 64 and not a.downsample and not a.mild_set))
+                           pmc_ok=(sensor == "HDL-64E" and B == 64 and not a.downsample and not mild))
 
     # ---- the other scene seeds (informational: spread of the metric over scenes)
     by_seed = [round(world * B * steps / dt, 1)]
@@ -418,7 +424,7 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
                     f"{method}{' with the opt-in More-Thuente line search (not the reference behaviour)' if pnh.get('reg_ndt_line_search') else ''}"
                     f"{' (covariance regularisation ' + a.regularization + ')' if a.regularization else ''}"
                     f" + getFitnessScore{'' if max_range is None else f' (max_range {max_range})'}, cold (index + covariances rebuilt every step); candidate set: "
-                    + ("rounds 1-2 'mild' set (8 distinct scans within 4 m, guess noise 0.3 m / 1 deg)" if a.mild_set else
+                    + ("rounds 1-2 'mild' set (8 distinct scans within 4 m, guess noise 0.3 m / 1 deg)" if mild else
                        "SURVEY 8d (distinct ray-casts at poses within 20 m of the query, guess = ground truth + 0.5 m / 2 deg noise, z forced to 0)"),
                     {"candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": method,
                      "distinct_scans": min(set_kwargs.get("n_distinct", 16), B),

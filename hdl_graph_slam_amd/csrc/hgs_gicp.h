@@ -139,6 +139,16 @@ HGS_HD void gicp_terms_rr(const GicpPointResidual& r, const Sym3& M, double* o /
   o[5] = y * A[0][2] - x * A[1][2];
 }
 
+// all 28 terms of one point in accumulator order (what gicp_point_terms adds to acc[28])
+HGS_HD void gicp_point_terms_by_slot(const GicpPointResidual& r, const Sym3& M, double* t /*[28]*/) {
+  double rr[6], rt[9], tt[6], bb[7];
+  gicp_terms_rr(r, M, rr), gicp_terms_rt(r, M, rt), gicp_terms_tt(M, tt), gicp_terms_b(r, bb);
+  t[0] = rr[0], t[1] = rr[1], t[2] = rr[2], t[3] = rt[0], t[4] = rt[1], t[5] = rt[2];
+  t[6] = rr[3], t[7] = rr[4], t[8] = rt[3], t[9] = rt[4], t[10] = rt[5];
+  t[11] = rr[5], t[12] = rt[6], t[13] = rt[7], t[14] = rt[8];
+  for (int k = 0; k < 6; k++) t[15 + k] = tt[k];
+  for (int k = 0; k < 7; k++) t[21 + k] = bb[k];
+}
 // residual e = b - T a, returns e^T M e; optionally adds J^T M J, J^T M e to acc[28] (upper triangle row-major, b, -)
 template <bool WITH_JACOBIAN>
 HGS_HD double gicp_point_terms(const Pose& T, const Sym3& M, float ax, float ay, float az, double bx, double by, double bz, double* acc) {

@@ -102,6 +102,50 @@ __device__ __forceinline__ void wave_sums_to(const double (&v)[N], const int (&s
   }
 }
 
+// ---- transposing wave sums (round 3) -------------------------------------------------------------------------------------------
+// Summing N doubles over the wave one by one costs N x 6 shuffle steps (a 64-bit __shfl_down is two cross-lane moves plus
+// an add: ~500 instructions for the 28 sums of k_gicp_linearize, a third of what the kernel ran outside the tree walk).  The swap
+// instructions of gfx950 halve the number of VALUES at every step instead: v_permlane32_swap exchanges the upper half of one register
+// with the lower half of another, so ONE add folds two values over the wave's halves (lanes < 32 keep the first value's partial
+// sums, lanes >= 32 the second's), v_permlane16_swap does the same over 16-lane rows, and only the last 16 -> 1 steps run per
+// register (DPP row shifts).  32 values -> 16 -> 8 registers -> 8 row reductions.  The order of the additions is fixed: results are
+// bitwise reproducible (they differ in the last bits from the shuffle tree's, which associated differently).
+__device__ __forceinline__ double swap_add32(double x, double y) {  // lanes < 32: x[l] + x[l + 32]; lanes >= 32: y[l - 32] + y[l]
+  const unsigned long long bx = (unsigned long long)__double_as_longlong(x), by = (unsigned long long)__double_as_longlong(y);
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)bx, (unsigned)by, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(bx >> 32), (unsigned)(by >> 32), false, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+__device__ __forceinline__ double swap_add16(double x, double y) {  // rows 0 / 2: x's rows 0+1 / 2+3; rows 1 / 3: y's rows 0+1 / 2+3
+  const unsigned long long bx = (unsigned long long)__double_as_longlong(x), by = (unsigned long long)__double_as_longlong(y);
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)bx, (unsigned)by, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(bx >> 32), (unsigned)(by >> 32), false, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+__device__ __forceinline__ double row_sum16(double v) {  // lane 15 of every 16-lane row: the row's sum (row_shr:1, 2, 4, 8, zero fill)
+#define HGS_ROW_STEP(ctrl)                                                                                                         \
+  {                                                                                                                                \
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);                                                       \
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)b, ctrl, 0xf, 0xf, true);                                         \
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(b >> 32), ctrl, 0xf, 0xf, true);                                 \
+    v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));                                                    \
+  }
+  HGS_ROW_STEP(0x111) HGS_ROW_STEP(0x112) HGS_ROW_STEP(0x114) HGS_ROW_STEP(0x118)
+#undef HGS_ROW_STEP
+  return v;
+}
+// even[j] / odd[j] = the lane's values for output slots 2j / 2j + 1, j < 14 (slots 0..27); the wave's sums land in row[0..27].
+// Slot p = 4i + r ends up in lane 15 of row r of register i: r = 0 even[2i], 1 odd[2i], 2 even[2i+1], 3 odd[2i+1].
+__device__ __forceinline__ void wave_sums28_to(const double (&even)[14], const double (&odd)[14], double* row, int lane) {
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    const double a = swap_add32(even[2 * i], even[2 * i + 1]);  // halves: slot 4i | slot 4i + 2
+    const double c = swap_add32(odd[2 * i], odd[2 * i + 1]);    // halves: slot 4i + 1 | slot 4i + 3
+    const double u = row_sum16(swap_add16(a, c));               // rows: 4i, 4i + 1, 4i + 2, 4i + 3
+    if ((lane & 15) == 15) row[4 * i + (lane >> 4)] = u;
+  }
+}
+
 // Second reduction stage: out[k] = sum over tiles of p[tile*N + k], k < N, for a 256-thread block.
 // ROWS x N threads (ROWS = 256 / N: 9 x 28 for GICP, 5 x 43 for NDT) read ROWS*N consecutive doubles per step (fully
 // coalesced), each thread owns one (row, column) and walks tiles row, row+ROWS, ... ; the rows are then added in a
@@ -348,20 +392,18 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   const bool active = lane < qpw && i < n;
   BvhView tv;
   tv.nodes = d.nodes, tv.pts = d.pts, tv.lpts = d.lpts, tv.P = d.P, tv.n = n;
-  const int height = 31 - __clz(tv.P);
   const float4 qp = active ? d.pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const F3 q = {qp.x, qp.y, qp.z};
   const int live = k < KMAX ? k : KMAX;
-  __shared__ __attribute__((aligned(128))) float walk_slots[kBlock / 64][32];
+  __shared__ __attribute__((aligned(512))) float walk_slots[kBlock / 64][kParkFloats];
   __shared__ unsigned leaf_log[REPLAY ? kBlock / 64 : 1][REPLAY ? kKnnLeafLog : 1];
-  float* slot = walk_slots[threadIdx.x >> 6];
+  float* slot = walk_slots[threadIdx.x >> 6];  // the quad walk's parking area; its first 128 bytes stage the replayed records
   LeafLog log = {leaf_log[REPLAY ? threadIdx.x >> 6 : 0], REPLAY ? kKnnLeafLog : 0, 0};
   const int i0 = i - lane;
   float r2;
   int ties;
   {
-    PacketWalk<KnnRadiusLane<KMAX, REPLAY>> w[1];
-    KnnRadiusLane<KMAX, REPLAY>& L = w[0].lane;
+    KnnRadiusLane<KMAX, REPLAY> L;
     L.init(live, active);
     // The wave's own 64 points (8 whole leaves of the Hilbert order) are every lane's first candidates: all-pairs
     // through v_readlane, no memory traffic — the walk then starts with every list full and a bound within ~1.2x of
@@ -373,16 +415,12 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
       const float dd = dist2f(q, px, py, pz);
       if (dd < L.worst()) L.insert(dd);
     }
-    if (n > qpw) {  // otherwise the own window was the whole cloud
-      w[0].start(tv, q, height);
-      w[0].order_lane = qpw >> 1;
-      w[0].skip_lo = (unsigned)(tv.P + (i0 >> 3)), w[0].skip_n = (unsigned)(qpw >> 3);
-      wave_walk_multi<KnnRadiusLane<KMAX, REPLAY>, 1>(tv, w, slot, REPLAY ? &log : nullptr);
-    }
-    r2 = w[0].lane.worst();
+    if (n > qpw)  // otherwise the own window was the whole cloud
+      wave_walk_quad(tv, L, q, slot, qpw >> 1, (unsigned)(tv.P + (i0 >> 3)), (unsigned)(qpw >> 3), REPLAY ? &log : nullptr);
+    r2 = L.worst();
     int n_lt = 0;
 #pragma unroll
-    for (int j = 0; j < KMAX; j++) n_lt += (w[0].lane.d[j] >= 0.f && w[0].lane.d[j] < r2) ? 1 : 0;
+    for (int j = 0; j < KMAX; j++) n_lt += (L.d[j] >= 0.f && L.d[j] < r2) ? 1 : 0;
     ties = live - n_lt;
   }
   // pass 2 (TIES = 1 unless some lane of this wave needs several points at exactly its k-th distance)
@@ -415,32 +453,22 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
         L.visit_leaf(lo, hi, qx, qy, qz, (int)this_leaf * kLeaf);
       }
     } else {
-      PacketWalk<KnnGatherLane<1>> g[1];
-      g[0].lane = L;
-      g[0].start(tv, q, height);
-      g[0].order_lane = qpw >> 1;
-      wave_walk_multi<KnnGatherLane<1>, 1>(tv, g, slot);
-      L = g[0].lane;
+      wave_walk_quad(tv, L, q, slot, qpw >> 1);
     }
     L.finish(d.pts);
     s1[0] = L.s1[0], s1[1] = L.s1[1], s1[2] = L.s1[2], found = L.found;
     s2 = Sym3{L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
   } else {
-    PacketWalk<KnnGatherLane<4>> g[1];
-    g[0].lane.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
-    g[0].start(tv, q, height);
-    g[0].order_lane = qpw >> 1;
-    wave_walk_multi<KnnGatherLane<4>, 1>(tv, g, slot);
-    g[0].lane.finish(d.pts);
+    KnnGatherLane<4> L;
+    L.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
+    wave_walk_quad(tv, L, q, slot, qpw >> 1);
+    L.finish(d.pts);
     for (int taken = 4; __ballot(active && ties > taken) != 0ull; taken += 4) {  // more than 4 at the k-th distance
       const bool more = active && ties > taken;
-      g[0].lane.rearm_ties(more ? r2 : -1.f, more ? ties - taken : 0);
-      g[0].start(tv, q, height);
-      g[0].order_lane = qpw >> 1;
-      wave_walk_multi<KnnGatherLane<4>, 1>(tv, g, slot);
-      g[0].lane.finish(d.pts);
+      L.rearm_ties(more ? r2 : -1.f, more ? ties - taken : 0);
+      wave_walk_quad(tv, L, q, slot, qpw >> 1);
+      L.finish(d.pts);
     }
-    const KnnGatherLane<4>& L = g[0].lane;
     s1[0] = L.s1[0], s1[1] = L.s1[1], s1[2] = L.s1[2], found = L.found;
     s2 = Sym3{L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
   }
@@ -581,38 +609,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINE
     const float4 bp = tgt.pts[jj];
     r = gicp_point_residual(T, M, a.x, a.y, a.z, bp.x, bp.y, bp.z);
   }
-  // The 28 sums of the wave, one block of the normal equations at a time: only that block's terms are live while it is
-  // reduced (all 28 at once need more registers than the search runs at, and spilled — 12 bytes of scratch per thread).
+  // The 28 sums of the wave by transposing swap-adds (wave_sums28_to), the even output slots first, then the odd ones: the terms are
+  // recomputed for the second half (a few fp64 multiplies each, the unused ones are dead code) so that at most 14 are live.
   int lane;
   HGS_LANE_ID(lane);
   double* row = lds + wave * kAcc;
+  double even[14], odd[14];
   {
-    double v[7];
-    gicp_terms_b(r, v);
-    const int slot[7] = {21, 22, 23, 24, 25, 26, 27};
-    wave_sums_to<7>(v, slot, row, lane);
+    double t[kAcc];
+    gicp_point_terms_by_slot(r, M, t);
+#pragma unroll
+    for (int j = 0; j < 14; j++) even[j] = t[2 * j];
   }
   __builtin_amdgcn_sched_barrier(0);
   {
-    double v[6];
-    gicp_terms_tt(M, v);
-    const int slot[6] = {15, 16, 17, 18, 19, 20};
-    wave_sums_to<6>(v, slot, row, lane);
+    double t[kAcc];
+    gicp_point_terms_by_slot(r, M, t);
+#pragma unroll
+    for (int j = 0; j < 14; j++) odd[j] = t[2 * j + 1];
   }
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    double v[9];
-    gicp_terms_rt(r, M, v);
-    const int slot[9] = {3, 4, 5, 8, 9, 10, 12, 13, 14};
-    wave_sums_to<9>(v, slot, row, lane);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    double v[6];
-    gicp_terms_rr(r, M, v);
-    const int slot[6] = {0, 1, 2, 6, 7, 11};
-    wave_sums_to<6>(v, slot, row, lane);
-  }
+  wave_sums28_to(even, odd, row, lane);
   last_wave_stores<kAcc>(lds, &arrivals, partials + ((size_t)b * max_blocks + tile) * kAcc, lane);
 }
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,

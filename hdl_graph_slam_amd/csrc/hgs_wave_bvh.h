@@ -430,6 +430,104 @@ __device__ __forceinline__ void nn1_resolve_leaf(const BvhView& t, const F3& q, 
   pos_out = pos, orig_out = pos >= 0 ? orig : -1;
 }
 
+// The quad walk for any Lane (concept of PacketWalk above): what k_knn_cov and the prefilter's outlier walks run.  Same
+// traversal as wave_walk_multi<Lane, 1> — nearest-first by the order lane, leaves of a leaf-parent group in place with the
+// bounds re-tested after every visit, pending children entered directly, the skip window, the leaf log — with the records
+// fetched four at a time and parked per level (fetch_quad): one memory wait per group that has wanted children.
+template <class Lane>
+__device__ __forceinline__ void wave_walk_quad(const BvhView& t, Lane& lane, const F3& q, float* park /* kParkFloats */, int order_lane, unsigned skip_lo = 0,
+                                               unsigned skip_n = 0, LeafLog* log = nullptr) {
+  const int k = 31 - __clz(t.P);
+  if (t.n <= 0) return;
+  const hgs_f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+  auto visit = [&](const float* rec, unsigned ldnode) {
+    if (log) {
+      if (log->count < log->cap && (__lane_id() & 63u) == 0u) log->ids[log->count] = ldnode;
+      log->count++;
+    }
+    const hgs_f16v xy = *reinterpret_cast<const hgs_f16v*>(rec);
+    const hgs_f16v zw = *reinterpret_cast<const hgs_f16v*>(rec + 16);
+    lane.visit_leaf(xy, zw, qx, qy, qz, ((int)ldnode - t.P) * kLeaf);
+  };
+  if (k <= 1) {
+    const int l = (int)(__lane_id() & 31u);
+    for (int lf = 0; lf < t.P; lf++) {
+      if ((unsigned)(t.P + lf) - skip_lo < skip_n) continue;
+      const float v = reinterpret_cast<const float*>(t.lpts + 8 * lf)[l];
+      __builtin_amdgcn_wave_barrier();
+      park[l] = v;
+      __builtin_amdgcn_wave_barrier();
+      visit(park, (unsigned)(t.P + lf));
+    }
+    return;
+  }
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+  auto wanted = [&]() -> unsigned {
+    return (__ballot(lane.wants(d0)) != 0ull ? 1u : 0u) | (__ballot(lane.wants(d1)) != 0ull ? 2u : 0u) | (__ballot(lane.wants(d2)) != 0ull ? 4u : 0u) |
+           (__ballot(lane.wants(d3)) != 0ull ? 8u : 0u);
+  };
+  unsigned node = (k & 1) ? 0u : 1u;
+  int bd = (k & 1) ? -1 : 0;
+  unsigned long long pend = 0;
+  const auto slot_of = [&](int depth) { const int s = (k - depth) >> 1; return park + 128 * (s < kParkLevels ? s : kParkLevels); };
+  fetch_quad(t.nodes, slot_of(bd));
+  for (;;) {
+    {
+      const float* rec = slot_of(bd) + 32 * (node & 3u);
+      const hgs_f16v lo = *reinterpret_cast<const hgs_f16v*>(rec);
+      const hgs_f8v hi = *reinterpret_cast<const hgs_f8v*>(rec + 16);
+      const hgs_f2 d01 = pk_box_dist2(qx, qy, qz, hgs_f2{lo[0], lo[1]}, hgs_f2{lo[4], lo[5]}, hgs_f2{lo[8], lo[9]}, hgs_f2{lo[12], lo[13]}, hgs_f2{hi[0], hi[1]},
+                                      hgs_f2{hi[4], hi[5]});
+      const hgs_f2 d23 = pk_box_dist2(qx, qy, qz, hgs_f2{lo[2], lo[3]}, hgs_f2{lo[6], lo[7]}, hgs_f2{lo[10], lo[11]}, hgs_f2{lo[14], lo[15]}, hgs_f2{hi[2], hi[3]},
+                                      hgs_f2{hi[6], hi[7]});
+      d0 = d01.x, d1 = d01.y, d2 = d23.x, d3 = d23.y;
+    }
+    const unsigned any = wanted();
+    if (any) {
+      int cstar = __builtin_ctz(any);
+      {  // the nearest child the middle lane of the packet wants (else the lowest wanted slot)
+        const float w0 = lane.wants(d0) ? d0 : INFINITY, w1 = lane.wants(d1) ? d1 : INFINITY, w2 = lane.wants(d2) ? d2 : INFINITY, w3 = lane.wants(d3) ? d3 : INFINITY;
+        const float dmin = fminf(fminf(w0, w1), fminf(w2, w3));
+        const int pref = dmin == INFINITY ? -1 : (w0 == dmin ? 0 : (w1 == dmin ? 1 : (w2 == dmin ? 2 : 3)));
+        const int p = __builtin_amdgcn_readlane(pref, order_lane);
+        if (p >= 0) cstar = p;
+      }
+      const int cd = bd + 2;
+      const unsigned base = node << 2;
+      if (cd == k) {
+        unsigned todo = any;
+        for (unsigned c = 0; c < 4; c++)
+          if (base + c - skip_lo < skip_n) todo &= ~(1u << c);  // leaves the caller has handled
+        if (todo) {
+          fetch_quad(t.lpts + 8 * (size_t)(base - (unsigned)t.P), park);
+          int c = (todo >> cstar) & 1u ? cstar : __builtin_ctz(todo);
+          while (todo) {
+            todo &= ~(1u << c);
+            visit(park + 32 * c, base + (unsigned)c);
+            todo &= wanted();
+            c = todo ? __builtin_ctz(todo) : 0;
+          }
+        }
+      } else {
+        pend |= (unsigned long long)(any & ~(1u << cstar)) << (4 * (cd >> 1));
+        fetch_quad(t.nodes + 8 * (size_t)base, slot_of(cd));
+        node = base + (unsigned)cstar;
+        bd = cd;
+        continue;
+      }
+    }
+    if (!pend) return;
+    const int idx = (63 - __clzll((long long)pend)) >> 2;
+    const unsigned nib = (unsigned)(pend >> (4 * idx)) & 0xfu;
+    const int c = __builtin_ctz(nib);
+    pend &= ~(1ull << (4 * idx + c));
+    const int pcd = 2 * idx + (k & 1);
+    node = ((node >> (bd - pcd)) & ~3u) + (unsigned)c;
+    bd = pcd;
+    if (((k - bd) >> 1) >= kParkLevels) fetch_quad(t.nodes + 8 * (size_t)(node & ~3u), slot_of(bd));
+  }
+}
+
 // ---- k-NN radius: sorted list of the k smallest squared distances only (no positions) -----------------------------
 // With d ascending, inserting x makes the new d[i] the median of (d[i-1], d[i], x): one v_med3_f32 per slot.
 // INCLUSIVE: prune with box_d2 <= bound instead of <, see wants().

@@ -294,3 +294,23 @@ def ndt_serial_sum_deviation(make_exact, tgt, src, T, n_guesses=100, seed=0, mod
         if hasattr(exact, "close"):
             exact.close()
     return out
+
+
+def check_nn1_with_equidistant_targets(make_engine):
+    """The 1-NN of k_gicp_linearize / k_fitness where several target points are EXACTLY equally near: the quad walk keeps only the
+    minimum distance per leaf and resolves the index from the lane's best leaf, and must fall back to the exact keyed walk when the
+    minimum was reached in two different leaves.  Target: the tie-heavy cloud (duplicated planes, a 3-fold lattice, a regular grid);
+    source: its own points at the identity (distance 0 to every copy of a duplicated point: the lowest original index wins) and
+    shifted by exactly half a grid step (0.125 m: every grid query is equidistant to two grid points — float-exact arithmetic)."""
+    tgt = tie_heavy_cloud()
+    src = tgt[::3].copy()
+    p = O.default_params(O.HGS_FAST_GICP)
+    e, o = make_engine(p), make_oracle(p)
+    load_pair(e, o, tgt, src)
+    for shift in ([0.0, 0.0, 0.0], [0.125, 0.0, 0.0], [0.125, 0.125, 0.0], [0.0, 0.0, 0.25]):
+        T = synth.pose_matrix(shift, [0.0, 0.0, 0.0])
+        check_gicp_linearize(e, o, T)
+        check_gicp_linearize(e, o, T)      # again, now seeded by the correspondences just found (the unordered walk)
+        check_fitness(e, o, T, max_ranges=(np.finfo(np.float64).max, 0.02))
+    if hasattr(e, "close"):
+        e.close()

@@ -340,3 +340,7 @@ def test_ndt_deviation_from_the_serial_sum():
     for r in rows:
         limit = 0 if r["neighbor_search"] == O.HGS_DIRECT7 else 2
         assert r["beyond_1e-3"] <= limit and r["other_iteration_count"] <= limit, r
+
+
+def test_nn1_with_equidistant_target_points():
+    PC.check_nn1_with_equidistant_targets(_hip)

@@ -604,3 +604,8 @@ def test_sharded_batch_flags_a_candidate_two_ranks_report(simt_library):
         return rc, bool(rec["converged"].all())
     res = _two_ranks(world, body)
     assert [r[0] for r in res] == [L.HGS_ERR_INVALID_ARGUMENT] * 2 and all(r[1] for r in res)
+
+
+def test_nn1_with_equidistant_target_points(simt_library):
+    """The quad walk's min-only leaves + resolve + keyed-walk fallback on duplicated / regular-grid targets (PC docstring)."""
+    PC.check_nn1_with_equidistant_targets(_engine)
