@@ -133,6 +133,7 @@ struct hgs_handle {
   // block-per-problem solve / decide kernels of one lane run under the point kernels of the others
   hipStream_t lane_stream[3] = {};
   hipEvent_t lane_event[4] = {};
+  int nn_qpw = 0;  // 0: chosen per launch (nn_queries_per_wave)
   hipEvent_t comm_event = nullptr;  // hgs_loop_match_batch_sharded: the gathered headers have reached the host
   // measured on the 16 x 120 k-point loop batch: 1 -> 2 -> 4 lanes = 2850 -> 2935 -> 2975 GICP reg/s, 735 -> 772 -> 797 NDT;
   // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default).  Round 2, 64 x 119 k-point batch:
@@ -721,7 +722,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   size_t total_q = 0;
   for (hgs_cloud* c : sources) total_q += c->n_input;
   (void)total_q;
-  const int qpw = 64;  // measured: 16- or 32-query packets do not shorten a single registration's linearize (97 -> 90 us) and cost the batch
+  const int qpw = h->nn_qpw > 0 ? h->nn_qpw : 64;  // round 2 measured: 16- or 32-query packets do not shorten a single registration's linearize (97 -> 90 us) and cost the batch
   const int nn_tile = (kBlock / 64) * qpw * kNW;                 // points per block of k_gicp_linearize / k_fitness (their own tiling formula)
   const int max_blocks = std::max(1, (max_n + nn_tile - 1) / nn_tile);  // >= the tile count of every kernel of the loop
   const CloudDesc* d_descs = nullptr;
@@ -843,7 +844,7 @@ int run_fitness(hgs_handle* h, const std::vector<hgs_cloud*>& sources, double ma
   HGS_TRY(ensure_index(h, all));
   int max_n = 0;
   for (hgs_cloud* c : sources) max_n = std::max(max_n, (int)c->n_input);
-  const int qpw = 64;
+  const int qpw = h->nn_qpw > 0 ? h->nn_qpw : 64;
   const int nn_tile = (kBlock / 64) * qpw * kNW;
   const int max_blocks = std::max(1, (max_n + nn_tile - 1) / nn_tile);
   const CloudDesc* d_descs = nullptr;
@@ -970,6 +971,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
   if (const char* e = std::getenv("HGS_KNN_REPLAY")) h->knn_replay = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("HGS_NDT_RESIDENT")) h->ndt_resident_blocks = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("HGS_NDT_CHUNK")) h->ndt_chunk = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("HGS_NN_QPW")) h->nn_qpw = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 32 ? 32 : 64);  // A/B: queries per packet of the 1-NN kernels
   if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     g_create_error = "hipSetDevice / hipStreamCreate failed";
     delete h;

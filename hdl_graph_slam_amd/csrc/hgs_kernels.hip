@@ -28,8 +28,11 @@ namespace hgs {
 // lane id recomputed where it is needed (2 VALU) instead of kept in a register across a long search: not CSE'd with an earlier one
 #define HGS_LANE_ID(dst) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(dst))
 #endif
+#ifndef HGS_COMPILER_MEMORY_BARRIER
+#define HGS_COMPILER_MEMORY_BARRIER() asm volatile("" ::: "memory")
+#endif
 #ifndef HGS_LINEARIZE_WAVES
-#define HGS_LINEARIZE_WAVES 7  // waves per SIMD k_gicp_linearize is compiled for (A/B knob)
+#define HGS_LINEARIZE_WAVES 7  // waves per SIMD k_gicp_linearize is compiled for (A/B knob; 6 / 7 / 8 measured equal: 68 VGPRs, no scratch)
 #endif
 #ifndef HGS_FITNESS_WAVES
 #define HGS_FITNESS_WAVES 8
@@ -958,23 +961,28 @@ void launch_ndt_pack_hash(hipStream_t s, const int* keys, const int* vals, int2*
 // column across rounds, so a lane reads the columns the other lanes rotated in the round before; the wave barrier between
 // rounds emits no instruction — it states the lock-step dependence (and is where the host emulation of tests/emul lets the
 // three lanes meet).
-__device__ __forceinline__ void solve_svd6_wave(const double* A, const double* b, volatile double* U, volatile double* V, double* x) {
+__device__ __forceinline__ void solve_svd6_wave(const double* A, const double* b, double* U, double* V, double* x) {
   const int lane = (int)(threadIdx.x & 63);
   if (lane < 36) U[lane] = A[lane], V[lane] = (lane % 7 == 0) ? 1.0 : 0.0;
+  HGS_COMPILER_MEMORY_BARRIER();
   __builtin_amdgcn_wave_barrier();
   for (int sweep = 0; sweep < 60; sweep++) {
     bool rotated = false;
     for (int round = 0; round < 5; round++) {
+      // the three pairs of a round are disjoint columns: each lane loads its four columns (24 LDS reads in flight together), rotates
+      // in registers, stores.  Plain pointers + a compiler-level memory barrier per round instead of volatile accesses, which were
+      // issued and waited for one at a time (~48 LDS round trips per rotation: 40 us of a 92 us odometry iteration in round 2).
       if (lane < 3) {
         int p, q;
         svd6_pair(round, lane, &p, &q);
-        if (svd6_rotate<volatile double*>(U, V, p, q)) rotated = true;
+        if (svd6_rotate<double*>(U, V, p, q)) rotated = true;
       }
+      HGS_COMPILER_MEMORY_BARRIER();
       __builtin_amdgcn_wave_barrier();
     }
     if (__ballot(rotated) == 0ull) break;
   }
-  if (lane == 0) svd6_backsolve<volatile double*>(U, V, b, x);
+  if (lane == 0) svd6_backsolve<const double*>(U, V, b, x);
 }
 
 // Four registers' values partially summed across the wave by two transposing steps (v_permlane32_swap / v_permlane16_swap:
@@ -1026,11 +1034,17 @@ struct NdtPassShared {
   double svd[72];
   unsigned long long next;
   int next_chunk, last, out_of_range;
+  // copies of the kernel arguments the out-of-line helpers need: passing them by reference put them into scratch memory
+  NdtConsts consts;
+  Progress prog;
+  int debug;
 };
 
 // The block that completed problem b's tile count: totals -> doubles, Newton step.  All threads of the block call it.
-__device__ __noinline__ void ndt_finish_problem(NdtPassShared& S, NdtAccum& A, NdtState& st, NdtAngles& angles_b, const NdtConsts& c, int debug, Progress prog) {
+__device__ __noinline__ void ndt_finish_problem(NdtPassShared& S, NdtAccum& A, NdtState& st, NdtAngles& angles_b) {
   const int t = (int)threadIdx.x;
+  const NdtConsts& c = S.consts;
+  const int debug = S.debug;
   // read-and-clear (the next pass starts from zero), one exchange per thread so that they are all in flight together
   if (t < kAccNdt * 4) S.w[t] = atomicExch(&A.w[t], 0ull);
   else if (t == kAccNdt * 4 + 1) S.w[t] = atomicExch(&A.tiles_done, 0u);
@@ -1057,7 +1071,7 @@ __device__ __noinline__ void ndt_finish_problem(NdtPassShared& S, NdtAccum& A, N
     if (t == 0) {
       ndt_after_derivatives(st, S.acc, c, dp_newton);
       if (st.phase != NDT_DONE) ndt_angle_tables(st.p, c.upstream_hd1_sign, angles_b);
-      progress_tick(prog, st.phase == NDT_DONE);
+      progress_tick(S.prog, st.phase == NDT_DONE);
     }
   }
   __syncthreads();
@@ -1106,7 +1120,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
   // first tile; the queue head counts from gridDim.x * first_chunk on.
   const int first_chunk = max(1, min(chunk, tile_base[B] / (2 * (int)gridDim.x)));
   const unsigned long long static_items = (unsigned long long)gridDim.x * (unsigned long long)first_chunk;
-  if (threadIdx.x == 0) S.out_of_range = 0, S.next = (unsigned long long)blockIdx.x * (unsigned long long)first_chunk, S.next_chunk = first_chunk;
+  if (threadIdx.x == 0) S.out_of_range = 0, S.next = (unsigned long long)blockIdx.x * (unsigned long long)first_chunk, S.next_chunk = first_chunk, S.consts = c, S.prog = prog, S.debug = debug;
   __syncthreads();
   const CloudMeta* m = tgt.meta;
   const int mnx = m->ndt_min_b[0], mny = m->ndt_min_b[1], mnz = m->ndt_min_b[2];
@@ -1129,7 +1143,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
       if (item < cur_first || item >= cur_end) {
         // another problem: hand in what was gathered for the previous one, then look the new one up
         if (cur_b >= 0 && cur_active && ndt_flush(S, accum[cur_b], cur_tiles, tile_base[cur_b + 1] - tile_base[cur_b]))
-          ndt_finish_problem(S, accum[cur_b], states[cur_b], angles[cur_b], c, debug, prog);
+          ndt_finish_problem(S, accum[cur_b], states[cur_b], angles[cur_b]);
         int b0 = 0, b1 = B;  // tile_base[b0] <= item < tile_base[b1]
         while (b1 - b0 > 1) {
           const int mid = (b0 + b1) >> 1;
@@ -1264,7 +1278,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
     w = S.next;
   }
   if (cur_b >= 0 && cur_active && ndt_flush(S, accum[cur_b], cur_tiles, tile_base[cur_b + 1] - tile_base[cur_b]))
-    ndt_finish_problem(S, accum[cur_b], states[cur_b], angles[cur_b], c, debug, prog);
+    ndt_finish_problem(S, accum[cur_b], states[cur_b], angles[cur_b]);
 }
 void launch_ndt_pass(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt, NdtState* states, NdtAngles* angles, NdtConsts c, NdtAccum* accum, const int* tile_base,
                      unsigned long long* queues, int B, int parity, int blocks, int chunk, int sorted, int debug, Progress prog) {

@@ -243,11 +243,14 @@ HGS_HD void svd6_pair(int round, int j, int* p, int* q) {
 
 // One Hestenes rotation of columns p < q of U (and V); false if the pair is already orthogonal to working precision.
 // P is `double*` (local arrays on the host) or `volatile double*` (LDS shared by the lanes of a wave on the device).
+// The four columns are read up front (24 independent loads: on the device they are all in flight together — LDS round trips,
+// not arithmetic, bounded the wave version of round 2), rotated in registers and written back; the arithmetic and its order are
+// those of the in-place form.
 template <typename P>
 HGS_HD bool svd6_rotate(P U, P V, int p, int q) {
   HGS_FP_STRICT
-  double up[6], uq[6];
-  for (int k = 0; k < 6; k++) up[k] = U[k * 6 + p], uq[k] = U[k * 6 + q];
+  double up[6], uq[6], vp[6], vq[6];
+  for (int k = 0; k < 6; k++) up[k] = U[k * 6 + p], uq[k] = U[k * 6 + q], vp[k] = V[k * 6 + p], vq[k] = V[k * 6 + q];
   double alpha = 0, beta = 0, gamma = 0;
   for (int k = 0; k < 6; k++) {
     alpha += up[k] * up[k];
@@ -261,9 +264,8 @@ HGS_HD bool svd6_rotate(P U, P V, int p, int q) {
   for (int k = 0; k < 6; k++) {
     U[k * 6 + p] = c * up[k] - s * uq[k];
     U[k * 6 + q] = s * up[k] + c * uq[k];
-    const double vp = V[k * 6 + p], vq = V[k * 6 + q];
-    V[k * 6 + p] = c * vp - s * vq;
-    V[k * 6 + q] = s * vp + c * vq;
+    V[k * 6 + p] = c * vp[k] - s * vq[k];
+    V[k * 6 + q] = s * vp[k] + c * vq[k];
   }
   return true;
 }

@@ -19,6 +19,9 @@
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define HGS_COMPILER_MEMORY_BARRIER() asm volatile("" ::: "memory")
 #define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))  /* one OS thread runs every fiber (atomicAdd below) */
 
 #include <math.h>

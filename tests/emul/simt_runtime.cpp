@@ -373,7 +373,9 @@ int comm_all_gather(Comm* c, const void* send, void* recv, size_t bytes_per_rank
     if (g.generation == gen) return aborted();
   }
   for (int r = 0; r < g.world; r++) memmove((char*)recv + (size_t)r * bytes_per_rank, g.send[r], bytes_per_rank);
+  // like the real collective, nobody's operation completes before its send buffer has been read by everyone (a rank may free it next)
   if (--g.departed == 0) g.cv.notify_all();
+  else g.cv.wait(lock, [&] { return g.departed == 0 || g.aborted; });
   return 0;
 }
 }  // namespace hgs
