@@ -34,7 +34,7 @@ struct CloudDesc {
   int n_input;
   int P;
   int sort_off;       // offset of this cloud's segment in the batch sort arrays
-  int pad;
+  int pad;            // index build only: 1 = also clear corr[] (the cloud was invalidated); 0 everywhere else
 };
 
 struct TargetView {
@@ -86,6 +86,7 @@ struct Progress {
 };
 
 constexpr int kBlock = 256;
+constexpr int kKnnLaneList = 16;          // leaves a lane of k_knn_cov remembers as its own candidates' (more: the wave falls back to the replay / walk)
 constexpr int kKnnLeafLog = 128;           // leaves pass 1 of k_knn_cov remembers per wave for pass 2 (more: pass 2 walks the tree)
 constexpr int kNW = 1;                    // packets of 64 queries a wave walks in lock-step in the 1-NN kernels (hgs_wave_bvh.h)
 constexpr int kTileNN = kBlock * kNW;     // source points per block of k_gicp_linearize / k_fitness
@@ -97,7 +98,8 @@ void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals);
 void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int max_slots, const unsigned* sorted_vals);
 void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int max_P);
-void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, bool replay);
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method,
+                    int gather /* pass 2: 0 tree walk, 1 leaf-log replay, 2 per-lane leaf lists */);
 
 void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog);
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B,

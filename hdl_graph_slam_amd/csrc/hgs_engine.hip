@@ -97,6 +97,7 @@ struct hgs_cloud {
   CloudDesc desc{};
   float* intensity = nullptr;  // [n_input] PointXYZI intensity (what hgs_cloud_download / the prefilter hand back)
   bool has_index = false;
+  bool corr_stale = false;  // hgs_cloud_invalidate: the correspondence seeds are forgotten when the index is rebuilt (k_gather_sorted)
   bool has_cov = false;
   int cov_k = 0;
   // NDT target tables
@@ -139,7 +140,7 @@ struct hgs_handle {
   // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default).  Round 2, 64 x 119 k-point batch:
   // 1 / 2 / 3 / 4 lanes = 3680 / 3999 / 3937 / 3913 GICP reg/s and 1064 / 1403 / 1384 / 1326 NDT — with 32 problems per lane a lane's
   // launches fill the device on their own and two chains are enough to cover each other's solves and tails.
-  int knn_replay = -1;  // k_knn_cov gather: -1 by launch shape, 0 tree walk, 1 leaf-log replay; HGS_KNN_REPLAY (A/B runs, tests)
+  int knn_replay = -1;  // k_knn_cov gather: -1 default (2), 0 tree walk, 1 leaf-log replay, 2 per-lane leaf lists; HGS_KNN_REPLAY (A/B runs, tests)
   int batch_lanes = 0;  // 0: by batch size (4 up to 32 problems, 2 above); HGS_BATCH_LANES fixes it (A/B runs)
   std::string err;
   hgs_cloud* target = nullptr;
@@ -344,7 +345,9 @@ int ensure_index(hgs_handle* h, const std::vector<hgs_cloud*>& all) {
     StageTimer tm(h, HGS_STAGE_INDEX);
     const CloudDesc* d_descs = nullptr;
     size_t total = 0;
+    for (hgs_cloud* c : chunk) c->desc.pad = c->corr_stale ? 1 : 0;  // read by k_gather_sorted
     HGS_TRY(upload_descs(h, chunk, true, &d_descs, &total));
+    for (hgs_cloud* c : chunk) c->desc.pad = 0, c->corr_stale = false;
     int max_n = 0, max_P = 1;
     for (hgs_cloud* c : chunk) max_n = std::max(max_n, (int)c->n_input), max_P = std::max(max_P, c->P);
     const int nc = (int)chunk.size();
@@ -402,8 +405,10 @@ int ensure_cov(hgs_handle* h, const std::vector<hgs_cloud*>& all, int k) {
   for (hgs_cloud* c : todo) total_q += c->n_input;
   const int qpw = queries_per_wave(total_q, 32);  // >= k points in the pre-fill window
   // the leaf-log gather pays for batches of LiDAR keyframes, not for one or two (dense) clouds: see launch_knn_cov
-  const bool replay = h->knn_replay >= 0 ? h->knn_replay != 0 : (todo.size() >= 8 && qpw == 64);
-  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, qpw, h->prm.regularization_method, replay);
+  // pass 2 of k_knn_cov: per-lane leaf lists (mode 2; measured against the leaf-log replay and the second tree walk: 64 LiDAR clouds
+  // 4.25 -> 4.0 ms, dense 1 M-point pair 1.46 -> 1.27 ms, one HDL-32E pair unchanged); HGS_KNN_REPLAY=0|1|2 forces a mode (tests, A/B)
+  const int gather = h->knn_replay >= 0 ? h->knn_replay : 2;
+  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, qpw, h->prm.regularization_method, gather);
   HGS_HIP(h, hipGetLastError());
   HGS_HIP(h, hipStreamSynchronize(h->stream));
   for (hgs_cloud* c : todo) c->has_cov = true, c->cov_k = key;
@@ -607,7 +612,9 @@ struct BatchLane {
 // so far (indices, covariances, descriptors, guesses).  Profiling keeps one lane: the stage timers bracket launches on the
 // main stream and are meant to time kernels that have the device to themselves.
 int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t partial_err_bytes_per_problem, std::vector<BatchLane>& lanes) {
-  const int wanted = h->batch_lanes > 0 ? h->batch_lanes : (B <= 32 ? 4 : 2);
+  // round 3, 64 x 119 k FAST_GICP batch: 1 / 2 / 3 / 4 lanes = 5615 / 5755 / 5787 / 5811 registrations/s (round 2's kernels preferred 2 above 32 problems)
+  // NDT (one launch per iteration, work queue inside): 1 / 2 / 3 / 4 lanes = 1064 / 1403 / 1384 / 1326 on the same batch (round 2)
+  const int wanted = h->batch_lanes > 0 ? h->batch_lanes : (h->prm.method == HGS_NDT_OMP && B > 32 ? 2 : 4);
   const int n = h->profiling ? 1 : std::max(1, std::min(std::min(wanted, kMaxLanes), B));
   lanes.assign(n, BatchLane{});
   for (int i = 0, b0 = 0; i < n; i++) {
@@ -968,7 +975,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
   for (int i = 0; i < HGS_STAGE_COUNT; i++) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
   if (const char* e = std::getenv("HGS_BATCH_LANES")) h->batch_lanes = std::max(1, std::min(kMaxLanes, std::atoi(e)));  // A/B measurements
   if (const char* e = std::getenv("HGS_NDT_SORT")) h->ndt_sort = std::max(-1, std::min(1, std::atoi(e)));
-  if (const char* e = std::getenv("HGS_KNN_REPLAY")) h->knn_replay = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("HGS_KNN_REPLAY")) h->knn_replay = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("HGS_NDT_RESIDENT")) h->ndt_resident_blocks = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("HGS_NDT_CHUNK")) h->ndt_chunk = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("HGS_NN_QPW")) h->nn_qpw = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 32 ? 32 : 64);  // A/B: queries per packet of the 1-NN kernels
@@ -985,7 +992,9 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
 
 int hgs_destroy(hgs_handle* h) try {
   if (!h) return HGS_OK;
-  { std::lock_guard<std::recursive_mutex> wait_for_running_call(h->api_mutex); }  // a call still running on another thread finishes first
+  // a call still running on another thread finishes first; a call that STARTS after this line races with the deletion below —
+  // hgs_destroy must not be called concurrently with other calls on the engine or its clouds (include/hgs_registration.h)
+  { std::lock_guard<std::recursive_mutex> wait_for_running_call(h->api_mutex); }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (hipStream_t ls : h->lane_stream)
@@ -1086,9 +1095,10 @@ int hgs_cloud_destroy(hgs_cloud* c) try {
     if (h->source == c) h->source = nullptr, h->own_source = false;
   }
   cloud_free(c);
+  c = nullptr;  // gone: the handler below must not look at it
   return HGS_OK;
 } catch (...) {
-  return status_of_current_exception((c ? c->owner : nullptr));
+  return status_of_current_exception(nullptr);
 }
 
 size_t hgs_cloud_size(const hgs_cloud* c) { return c ? c->n_input : 0; }
@@ -1098,11 +1108,10 @@ int hgs_cloud_invalidate(hgs_cloud* c) try {
   if (c && c->owner) api_lock__ = std::unique_lock<std::recursive_mutex>(c->owner->api_mutex);
   if (!c) return HGS_ERR_INVALID_ARGUMENT;
   c->has_index = false, c->has_cov = false, c->has_ndt = false, c->has_vg = false;
-  // also forget the correspondences of earlier registrations (they seed the next search): a truly cold cloud
-  if (c->owner && c->block) {
-    (void)hipSetDevice(c->owner->device);
-    (void)hipMemsetAsync(c->desc.corr, 0xff, (size_t)c->P * kLeaf * sizeof(int), c->owner->stream);
-  }
+  // also forget the correspondences of earlier registrations (they seed the next search): a truly cold cloud.  No launch here — 65
+  // memsets per loop-closure batch were 65 launches of ~3 us —: the kernel that rebuilds the cloud's sorted arrays clears them
+  // (a cloud without an index cannot be searched before ensure_index has run).
+  c->corr_stale = true;
   return HGS_OK;
 } catch (...) {
   return status_of_current_exception((c ? c->owner : nullptr));

@@ -34,6 +34,10 @@ namespace hgs {
 #ifndef HGS_LINEARIZE_WAVES
 #define HGS_LINEARIZE_WAVES 7  // waves per SIMD k_gicp_linearize is compiled for (A/B knob; 6 / 7 / 8 measured equal: 68 VGPRs, no scratch)
 #endif
+#ifndef HGS_KNN_WAVES
+#define HGS_KNN_WAVES 5  // waves per SIMD k_knn_cov is compiled for.  Measured on the 64-cloud pass: the compiler's own choice (108 VGPRs, 4 waves) 3.98 ms,
+#endif                  // 5 waves (96 VGPRs, 64 bytes of spills outside the walk) 3.66 ms, 6 waves (80 VGPRs, spills inside the insertion chains) 6.7 ms
+#define HGS_KNN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(HGS_KNN_WAVES)))
 #ifndef HGS_FITNESS_WAVES
 #define HGS_FITNESS_WAVES 8
 #endif
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_sorted(const CloudDesc* descs
   d.pts[i] = p;
   float* leaf = reinterpret_cast<float*>(d.lpts) + 32 * (size_t)(i >> 3) + (i & 7);  // SoA copy for the wave walk
   leaf[0] = p.x, leaf[8] = p.y, leaf[16] = p.z, leaf[24] = p.w;
+  if (d.pad) d.corr[i] = -1;  // hgs_cloud_invalidate: the seeds of earlier registrations are forgotten with the index
 }
 void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int max_slots, const unsigned* sorted_vals) {
   if (max_slots <= 0) return;
@@ -383,8 +388,11 @@ void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 // packets walk fewer nodes, so the dependent-load chain that bounds a small launch gets shorter; lanes >= qpw idle).
 // REG_GENERAL = false: FROBENIUS (the mode hdl_graph_slam runs); true: any hgs_regularization (3x3 eigen-decomposition per
 // point), a separate instantiation so that the default kernel carries none of it.
-template <int KMAX, bool REG_GENERAL, bool REPLAY>
-__global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int k, int qpw, int reg_method) {
+// GATHER: how pass 2 finds a lane's neighbours again — 0: a second tree walk bounded by r2; 1: replay of the leaves pass 1 visited (all
+// lanes over the union); 2: per-lane leaf lists (every lane over the leaves that gave IT a candidate; own leaves in lock-step).
+template <int KMAX, bool REG_GENERAL, int GATHER>
+__global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const CloudDesc* descs, int k, int qpw, int reg_method) {
+  constexpr bool REPLAY = GATHER == 1, LISTS = GATHER == 2;
   const CloudDesc d = descs[blockIdx.y];
   const int n = d.meta->nvalid;
   const int tile_pts = (kBlock / 64) * qpw;
@@ -400,14 +408,16 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   const int live = k < KMAX ? k : KMAX;
   __shared__ __attribute__((aligned(512))) float walk_slots[kBlock / 64][kParkFloats];
   __shared__ unsigned leaf_log[REPLAY ? kBlock / 64 : 1][REPLAY ? kKnnLeafLog : 1];
+  __shared__ unsigned lane_lists[LISTS ? kKnnLaneList : 1][LISTS ? kBlock : 1];  // [entry][thread]: conflict-free for equal counts
   float* slot = walk_slots[threadIdx.x >> 6];  // the quad walk's parking area; its first 128 bytes stage the replayed records
   LeafLog log = {leaf_log[REPLAY ? threadIdx.x >> 6 : 0], REPLAY ? kKnnLeafLog : 0, 0};
   const int i0 = i - lane;
   float r2;
-  int ties;
+  int ties, list_cnt = 0;
   {
-    KnnRadiusLane<KMAX, REPLAY> L;
+    KnnRadiusLane<KMAX, GATHER != 0, LISTS> L;
     L.init(live, active);
+    L.list = &lane_lists[0][LISTS ? threadIdx.x : 0], L.stride = kBlock, L.cnt = 0, L.cap = kKnnLaneList;
     // The wave's own 64 points (8 whole leaves of the Hilbert order) are every lane's first candidates: all-pairs
     // through v_readlane, no memory traffic — the walk then starts with every list full and a bound within ~1.2x of
     // the final radius instead of +inf, which is what keeps it from wandering (3x fewer insertions and leaves).
@@ -421,6 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
     if (n > qpw)  // otherwise the own window was the whole cloud
       wave_walk_quad(tv, L, q, slot, qpw >> 1, (unsigned)(tv.P + (i0 >> 3)), (unsigned)(qpw >> 3), REPLAY ? &log : nullptr);
     r2 = L.worst();
+    list_cnt = L.cnt;
     int n_lt = 0;
 #pragma unroll
     for (int j = 0; j < KMAX; j++) n_lt += (L.d[j] >= 0.f && L.d[j] < r2) ? 1 : 0;
@@ -433,14 +444,40 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   if (__ballot(active && ties > 1) == 0ull) {
     KnnGatherLane<1> L;
     L.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
-    if (REPLAY && n > qpw && log.count <= log.cap) {
+    if (LISTS && n > qpw && __ballot(active && list_cnt > kKnnLaneList) == 0ull) {
+      // The wave's own leaves in lock-step (nearly every lane needs them), then every lane over ITS list: entry r of all lanes at
+      // once, each lane gathering its own 128-byte leaf record.  ~8 rounds instead of ~36 logged leaves, and every lane's
+      // arithmetic is on a leaf that matters to it.
+      const hgs_f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+      const int l32 = lane & 31;
+      const int n_own = max(0, min(qpw >> 3, tv.P - (i0 >> 3)));
+      for (int j = 0; j < n_own; j++) {
+        const unsigned leaf = (unsigned)(i0 >> 3) + (unsigned)j;
+        const float v = reinterpret_cast<const float*>(tv.lpts + 8 * (size_t)leaf)[l32];
+        __builtin_amdgcn_wave_barrier();
+        slot[l32] = v;
+        __builtin_amdgcn_wave_barrier();
+        const hgs_f16v* r = reinterpret_cast<const hgs_f16v*>(slot);
+        const hgs_f16v lo = r[0], hi = r[1];
+        L.visit_leaf(lo, hi, qx, qy, qz, (int)leaf * kLeaf);
+      }
+      for (int r = 0; __ballot(active && r < list_cnt) != 0ull; r++) {
+        if (active && r < list_cnt) {
+          const unsigned leaf = lane_lists[r][threadIdx.x];
+          const hgs_f16v* rec = reinterpret_cast<const hgs_f16v*>(tv.lpts + 8 * (size_t)leaf);
+          const hgs_f16v lo = rec[0], hi = rec[1];
+          L.visit_leaf(lo, hi, qx, qy, qz, (int)leaf * kLeaf);
+        }
+      }
+    } else if (REPLAY && n > qpw && log.count <= log.cap) {
       // No second tree walk: every leaf with a point within r2 of some lane (box_d2 <= r2 <= the bound pass 1 had when it met the
       // leaf) is either one of the wave's own 8 leaves or in pass 1's log.  The records are fetched by index, so the next one is
       // in flight while the current one is summed — no dependent chain, no box tests.
-      const int n_own = qpw >> 3, total = n_own + log.count;
+      // (the wave's own leaves that exist: a tail wave of a tiny cloud would otherwise read leaf records past the array)
+      const int n_own = max(0, min(qpw >> 3, tv.P - (i0 >> 3))), total = n_own + log.count;
       const hgs_f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
       const int l32 = lane & 31;
-      unsigned leaf = (unsigned)(i0 >> 3);  // leaf index (node id - P)
+      unsigned leaf = n_own > 0 ? (unsigned)(i0 >> 3) : (total > 0 ? log.ids[0] - (unsigned)tv.P : 0u);  // leaf index (node id - P)
       float v = reinterpret_cast<const float*>(tv.lpts + 8 * (size_t)leaf)[l32];
       for (int j = 0; j < total; j++) {
         __builtin_amdgcn_wave_barrier();  // the previous record's reads are issued before the slot is overwritten
@@ -480,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_knn_cov(const CloudDesc* descs, int 
   d.cov[2 * i] = make_float4((float)c.xx, (float)c.xy, (float)c.xz, (float)c.yy);
   d.cov[2 * i + 1] = make_float4((float)c.yz, (float)c.zz, 0.f, 0.f);
 }
-template <bool REG_GENERAL, bool REPLAY>
+template <bool REG_GENERAL, int REPLAY>
 static void launch_knn_cov_t(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method) {
   const int tile_pts = (kBlock / 64) * qpw;
   const dim3 grid((max_n + tile_pts - 1) / tile_pts, ncloud), block(kBlock);
@@ -493,14 +530,16 @@ static void launch_knn_cov_t(hipStream_t s, const CloudDesc* descs, int ncloud, 
 // replay: the gather pass replays pass 1's leaf log instead of walking the tree again.  Measured (same-box A/B): 64 LiDAR clouds in one
 // launch 6.28 -> 6.14 ms; a single HDL-32E pair 0.33 -> 0.41 ms and a dense 1 M-point pair 1.91 -> 2.15 ms (a dense cloud's first walk
 // visits far more leaves than the gather needs) — hence two instantiations and a choice per launch (hgs_engine.hip).
-void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, bool replay) {
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, int gather) {
   if (max_n <= 0) return;
   if (reg_method == 0) {
-    if (replay) launch_knn_cov_t<false, true>(s, descs, ncloud, max_n, k, qpw, reg_method);
-    else launch_knn_cov_t<false, false>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    if (gather == 2) launch_knn_cov_t<false, 2>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    else if (gather == 1) launch_knn_cov_t<false, 1>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    else launch_knn_cov_t<false, 0>(s, descs, ncloud, max_n, k, qpw, reg_method);
   } else {
-    if (replay) launch_knn_cov_t<true, true>(s, descs, ncloud, max_n, k, qpw, reg_method);
-    else launch_knn_cov_t<true, false>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    if (gather == 2) launch_knn_cov_t<true, 2>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    else if (gather == 1) launch_knn_cov_t<true, 1>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    else launch_knn_cov_t<true, 0>(s, descs, ncloud, max_n, k, qpw, reg_method);
   }
 }
 

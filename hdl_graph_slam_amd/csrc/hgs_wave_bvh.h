@@ -531,8 +531,14 @@ __device__ __forceinline__ void wave_walk_quad(const BvhView& t, Lane& lane, con
 // ---- k-NN radius: sorted list of the k smallest squared distances only (no positions) -----------------------------
 // With d ascending, inserting x makes the new d[i] the median of (d[i-1], d[i], x): one v_med3_f32 per slot.
 // INCLUSIVE: prune with box_d2 <= bound instead of <, see wants().
-template <int KMAX, bool INCLUSIVE = false>
+// MARK: the lane also remembers WHICH leaves gave it a candidate (a point at or within its bound of the moment — a superset of the
+// leaves that hold its final k nearest, equidistant candidates at the k-th distance included): list[e * stride], e < cnt.  cnt runs
+// past cap when the list overflows (the caller then must not use it).  k_knn_cov's gather pass reads it: every lane sums over ITS
+// leaves instead of all lanes over the union of everybody's.
+template <int KMAX, bool INCLUSIVE = false, bool MARK = false>
 struct KnnRadiusLane {
+  unsigned* list;
+  int stride, cnt, cap;
   float d[KMAX];  // slots [KMAX-k, KMAX) are live, the others hold -1 and never move
   __device__ __forceinline__ void init(int k, bool active) {
 #pragma unroll
@@ -550,11 +556,20 @@ struct KnnRadiusLane {
     d[0] = fminf(d[0], x);
   }
   __device__ __forceinline__ void visit_leaf(const hgs_f16v& xy, const hgs_f16v& zw, hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, int base) {
+    hgs_f2 dd[4];
 #pragma unroll
-    for (int l = 0; l < 8; l += 2) {
-      const hgs_f2 dd = pk_dist2(qx, qy, qz, hgs_f2{xy[l], xy[l + 1]}, hgs_f2{xy[8 + l], xy[9 + l]}, hgs_f2{zw[l], zw[l + 1]});
-      if (dd.x < worst()) insert(dd.x);
-      if (dd.y < worst()) insert(dd.y);
+    for (int l = 0; l < 8; l += 2) dd[l >> 1] = pk_dist2(qx, qy, qz, hgs_f2{xy[l], xy[l + 1]}, hgs_f2{xy[8 + l], xy[9 + l]}, hgs_f2{zw[l], zw[l + 1]});
+    if (MARK) {
+      const float m = fminf(fminf(fminf(dd[0].x, dd[0].y), fminf(dd[1].x, dd[1].y)), fminf(fminf(dd[2].x, dd[2].y), fminf(dd[3].x, dd[3].y)));
+      if (m <= worst()) {  // <=: a point exactly at the bound cannot enter the list but may be one of the equidistant k-th neighbours
+        if (cnt < cap) list[cnt * stride] = (unsigned)(base >> 3);
+        cnt++;
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      if (dd[l].x < worst()) insert(dd[l].x);
+      if (dd[l].y < worst()) insert(dd[l].y);
     }
   }
 };

@@ -9,6 +9,11 @@
  * hgs_handle owns one HIP stream and its device buffers, so the two engine instances that live in one
  * nodelet manager (odometry: apps/scan_matching_odometry_nodelet.cpp:106, loop closure:
  * include/hdl_graph_slam/loop_detector.hpp:47) can run concurrently from different threads.
+ * Thread safety: calls on ONE engine (and on its clouds) are serialised by a per-engine mutex, different engines are
+ * independent.  hgs_destroy is the exception: it must not race with ANY other call on that engine or on one of its clouds
+ * (including hgs_cloud_destroy / hgs_cloud_download from a garbage-collector thread) — the mutex it would have to wait on is
+ * part of the object it deletes.  Destroy the engine after the threads that use it have finished with it; clouds that outlive
+ * it are orphaned safely (hgs_cloud_destroy still frees them).
  *
  * Conventions
  *  - points: array of records with three consecutive floats x,y,z at the start of each record and a byte stride
@@ -192,6 +197,10 @@ int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, 
 
 /* ---- "next" row f2: the prefilter in front of the path (apps/prefiltering_nodelet.cpp:131-182) -------------------- */
 enum hgs_downsample_method { HGS_DOWNSAMPLE_NONE = 0, HGS_DOWNSAMPLE_VOXELGRID = 1, HGS_DOWNSAMPLE_APPROX_VOXELGRID = 2 }; /* :51-72; pcl::VoxelGrid / pcl::ApproximateVoxelGrid */
+/* Deviation from PCL, stated: HGS_DOWNSAMPLE_APPROX_VOXELGRID drops non-finite input points, pcl::ApproximateVoxelGrid has no
+ * finiteness check (a NaN point hashes into some bucket and poisons that voxel's centroid).  With use_distance_filter = 1 (the
+ * nodelet's default) the distance filter in front has removed them already and the outputs are identical; they differ only for
+ * use_distance_filter = 0 on an is_dense = false cloud, where PCL's output contains NaN centroids. */
 enum hgs_outlier_removal { HGS_OUTLIER_NONE = 0, HGS_OUTLIER_STATISTICAL = 1, HGS_OUTLIER_RADIUS = 2 }; /* :73-93 */
 typedef struct hgs_prefilter_params {
   int32_t use_distance_filter;     /* use_distance_filter   (true)   :94                                  */

@@ -76,7 +76,7 @@ def check_covariances_both_gathers(make_engine):
     clouds = [synth.scan(scene, "VLP-16", synth.pose_matrix([0, 0, 0], [0, 0, 0]), 31), tie_heavy_cloud(), outlier_cloud()]
     old = os.environ.get("HGS_KNN_REPLAY")
     try:
-        for replay in ("0", "1"):
+        for replay in ("0", "1", "2"):
             os.environ["HGS_KNN_REPLAY"] = replay          # read in hgs_create
             for cloud in clouds:
                 e = make_engine(O.default_params(O.HGS_FAST_GICP))
