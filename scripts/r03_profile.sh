@@ -10,7 +10,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$ROOT"
 mkdir -p gpurun_out
 if [ -n "${PRE:-}" ]; then echo "== pytest $PRE"; HGS_BATCH_LANES= timeout 900 python -m pytest $PRE -m gpu -q -x --timeout 400 -p no:cacheprovider 2>&1 | tail -4; fi
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --seeds 1"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-ndt-record --seeds 1"
 for M in ${METHODS:-FAST_GICP}; do
   m=$(echo $M | tr A-Z a-z)
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_$m" -o bench -- python "$ROOT/bench.py" --method $M $ARGS > "$ROOT/gpurun_out/prof_$m.log" 2>&1); echo "trace $M exit $?"

@@ -175,7 +175,7 @@ def check_ndt_to_convergence(engine, params, tgt, src, guesses, bitwise=True, re
       * against sum mode 0 (the upstream-faithful association: ndt_omp adds the per-point results serially in index order, whatever
         its thread count): within the north-star tolerance 1e-3 m / 1e-3 rad with equal iteration counts.  Runs that separate
         are counted and reported; the bound is the measured one (profiles/r03_ndt_sum_mode_deviation.md: 0 of 2100 runs to
-        convergence): at most 2 % of the guesses, i.e. none of a set of fewer than 50."""
+        convergence, CPU and GPU together): at most 2 % of the guesses, i.e. none of a set of fewer than 50."""
     exact, serial = make_oracle(params).set_ndt_sum_mode(1), make_oracle(params)
     for o in (exact, serial):
         o.setInputTarget(tgt)
