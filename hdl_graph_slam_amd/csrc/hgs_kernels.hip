@@ -57,7 +57,13 @@ __device__ __forceinline__ bool finite3(const float4& p) { return isfinite(p.x) 
 // linearize 2.48-2.55 ms per step with slabs vs 2.41-2.42 ms with the identity, covariances and fitness unchanged — all
 // XCDs working on the same region at the same moment keeps the shared Infinity Cache footprint small, which matters more
 // here than the per-XCD L2 (the tree records are re-read from neighbouring waves within microseconds either way).
+#ifdef HGS_XCD_SLABS  // A/B knob (round 3 re-test): launch grids padded to a multiple of 8 in x, XCD x works on the x-th contiguous slab of tiles
+__device__ __forceinline__ int xcd_tile(int bid, int /*ntiles*/) { return (bid & 7) * ((int)gridDim.x >> 3) + (bid >> 3); }
+#define HGS_GRID_X(n) ((((n) + 7) / 8) * 8)
+#else
 __device__ __forceinline__ int xcd_tile(int bid, int /*ntiles*/) { return bid; }
+#define HGS_GRID_X(n) (n)
+#endif
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const Clou
   const int n = d.meta->nvalid;
   const int tile_pts = (kBlock / 64) * qpw;
   const int ntiles = (n + tile_pts - 1) / tile_pts;
-  if ((int)blockIdx.x >= ntiles) return;
+  if (xcd_tile(blockIdx.x, ntiles) >= ntiles) return;
   const int lane = (int)(threadIdx.x & 63);
   const int i = xcd_tile(blockIdx.x, ntiles) * tile_pts + (int)(threadIdx.x >> 6) * qpw + lane;
   const bool active = lane < qpw && i < n;
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const Clou
 template <bool REG_GENERAL, int REPLAY>
 static void launch_knn_cov_t(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method) {
   const int tile_pts = (kBlock / 64) * qpw;
-  const dim3 grid((max_n + tile_pts - 1) / tile_pts, ncloud), block(kBlock);
+  const dim3 grid(HGS_GRID_X((max_n + tile_pts - 1) / tile_pts), ncloud), block(kBlock);
   if (k <= 8) hipLaunchKernelGGL((k_knn_cov<8, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
   else if (k <= 16) hipLaunchKernelGGL((k_knn_cov<16, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
   else if (k <= 20) hipLaunchKernelGGL((k_knn_cov<20, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
@@ -616,8 +622,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINE
   const int n = d.meta->nvalid;
   const int tile_pts = (kBlock / 64) * qpw * kNW;
   const int ntiles = (n + tile_pts - 1) / tile_pts;
-  if ((int)blockIdx.x >= ntiles) return;
   const int tile = xcd_tile(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
   __shared__ double lds[4 * kAcc];
   __shared__ unsigned arrivals;
   __shared__ __attribute__((aligned(512))) float park[kBlock / 64][kParkFloats];
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINE
 }
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
                            int max_blocks, int B, int qpw) {
-  hipLaunchKernelGGL(k_gicp_linearize, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw);
+  hipLaunchKernelGGL(k_gicp_linearize, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw);
 }
 
 __global__ __launch_bounds__(kSolveBlock) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, T
   const int n = d.meta->nvalid;
   const int ntiles = (n + kBlock - 1) / kBlock;
   if ((int)blockIdx.x >= ntiles) return;
-  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int tile = (int)blockIdx.x;
   const int i = tile * kBlock + threadIdx.x;
   __shared__ double lds[4];
   double err = 0.0;
@@ -771,8 +777,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_FITN
   const int n = d.meta->nvalid;
   const int tile_pts = (kBlock / 64) * qpw * kNW;
   const int ntiles = (n + tile_pts - 1) / tile_pts;
-  if ((int)blockIdx.x >= ntiles) return;
   const int tile = xcd_tile(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
   __shared__ double lds[4 * 2];
   __shared__ unsigned arrivals;
   __shared__ __attribute__((aligned(512))) float park[kBlock / 64][kParkFloats];
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_FITN
 }
 void launch_fitness(hipStream_t s, const CloudDesc* descs, TargetView tgt, const DevResult* poses, double max_range, double* partials, int max_blocks,
                     int B, int use_seed, int qpw) {
-  hipLaunchKernelGGL(k_fitness, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, poses, max_range, partials, max_blocks, use_seed, qpw);
+  hipLaunchKernelGGL(k_fitness, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, poses, max_range, partials, max_blocks, use_seed, qpw);
 }
 __global__ __launch_bounds__(64) void k_fitness_final(const CloudDesc* descs, const double* __restrict__ partials, int max_blocks, DevResult* out, int tile_pts) {
   const int b = blockIdx.x;
@@ -1446,7 +1452,7 @@ __global__ __launch_bounds__(kBlock) void k_vgicp_linearize(const CloudDesc* des
   const int n = d.meta->nvalid;
   const int ntiles = (n + kBlock - 1) / kBlock;
   if ((int)blockIdx.x >= ntiles) return;
-  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int tile = (int)blockIdx.x;
   const int i = tile * kBlock + threadIdx.x;
   __shared__ double lds[4 * kAcc];
   double acc[kAcc];
@@ -1476,7 +1482,7 @@ __global__ __launch_bounds__(kBlock) void k_vgicp_error(const CloudDesc* descs, 
   const int n = d.meta->nvalid;
   const int ntiles = (n + kBlock - 1) / kBlock;
   if ((int)blockIdx.x >= ntiles) return;
-  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int tile = (int)blockIdx.x;
   const int i = tile * kBlock + threadIdx.x;
   __shared__ double lds[4];
   double err = 0.0;
