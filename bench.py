@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=3, help="units registered by the CPU oracle for cpu_baseline")
     args = ap.parse_args()
 
+    # the CPU legs run the OpenMP oracle in this process: idle OpenMP workers must sleep, not spin, or they compete with the host
+    # thread that keeps the GPU's queues filled in the GPU measurements that follow (NDT sub-record, continuity record, other seeds)
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: every call goes through the table below
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
