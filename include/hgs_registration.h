@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 3
+#define HGS_ABI_VERSION 4
 
 enum hgs_status {
   HGS_OK = 0,
