@@ -23,7 +23,10 @@ def _hipcc() -> str:
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    objs = [os.path.join(LIB_DIR, src.replace(".hip", ".o")) for src in SOURCES]
+    if not all(os.path.exists(o) for o in objs):
+        return True
+    t = min([os.path.getmtime(LIB_PATH)] + [os.path.getmtime(o) for o in objs])   # the oldest object decides: a relink alone is not a rebuild
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "hgs_registration.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -37,8 +40,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         src_path = os.path.join(CSRC, src)
-        if force or not os.path.exists(obj) or any(
-                os.path.getmtime(os.path.join(CSRC, f)) > os.path.getmtime(obj) for f in os.listdir(CSRC) if f.endswith(".h") or f == src):
+        deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f == src] + [os.path.join(_HERE, "..", "include", "hgs_registration.h")]
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
             cmd = [hipcc, *FLAGS, "-c", src_path, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
