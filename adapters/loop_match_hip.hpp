@@ -74,13 +74,21 @@ public:
   }
 
   // Registers every candidate against the new keyframe; records[i] is filled for candidates[i].  Returns the index the
-  // sequential rule of loop_detector.hpp:146-153 selects, or -1.  Throws std::runtime_error with the engine's message.
+  // sequential rule of loop_detector.hpp:146-153 selects, or -1.  Never throws into the caller (LoopDetector::matching has no
+  // handler and the nodelet would die): when an engine fails, ITS candidates stay "not converged" (fitness DBL_MAX — the rule
+  // skips them, like the sharded C entry point does for a rank that failed), the other engines' results stand, and
+  // last_error() says what happened.
   int match(const void* target_points, size_t target_n, size_t target_stride, const std::vector<Candidate>& candidates, double max_range,
             std::vector<hgs_result>* records) {
     const size_t N = engines_.size();
     std::vector<std::vector<size_t>> mine(N);
     for (size_t i = 0; i < candidates.size(); i++) mine[owner_index(candidates[i].keyframe_id)].push_back(i);
     records->assign(candidates.size(), hgs_result{});
+    for (size_t i = 0; i < candidates.size(); i++) {
+      (*records)[i].candidate_id = (int32_t)i;
+      (*records)[i].fitness_score = 1.7976931348623157e308;  // DBL_MAX: not converged until an engine says otherwise
+    }
+    last_error_.clear();
     std::vector<std::string> errors(N);
     auto work = [&](size_t e) {
       try {
@@ -118,12 +126,14 @@ public:
       for (size_t e = 0; e < N; e++) threads.emplace_back(work, e);
       for (std::thread& t : threads) t.join();
     }
-    for (const std::string& e : errors)
-      if (!e.empty()) throw std::runtime_error(e);
+    for (size_t e = 0; e < N; e++)
+      if (!errors[e].empty()) last_error_ += "engine " + std::to_string(e) + ": " + errors[e] + "; ";
     int32_t best = -1;
-    if (!candidates.empty() && hgs_select_best(records->data(), records->size(), &best) != HGS_OK) throw std::runtime_error("hgs_select_best failed");
+    if (!candidates.empty() && hgs_select_best(records->data(), records->size(), &best) != HGS_OK) last_error_ += "hgs_select_best failed; ", best = -1;
     return best;
   }
+  // empty after a clean match(); otherwise which engine failed and why (its candidates were left not converged)
+  const std::string& last_error() const { return last_error_; }
 
 private:
   struct Engine {
@@ -131,6 +141,7 @@ private:
     std::unordered_map<long, hgs_cloud*> clouds;
   };
   std::vector<Engine> engines_;
+  std::string last_error_;
 
   size_t owner_index(long keyframe_id) const { return (size_t)((keyframe_id % (long)engines_.size() + (long)engines_.size()) % (long)engines_.size()); }
   Engine& owner(long keyframe_id) { return engines_[owner_index(keyframe_id)]; }
