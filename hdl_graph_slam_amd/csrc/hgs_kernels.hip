@@ -37,7 +37,9 @@ namespace hgs {
 #ifndef HGS_KNN_WAVES
 #define HGS_KNN_WAVES 5  // waves per SIMD k_knn_cov is compiled for.  Measured on the 64-cloud pass: the compiler's own choice (108 VGPRs, 4 waves) 3.98 ms,
 #endif                  // 5 waves (96 VGPRs, 64 bytes of spills outside the walk) 3.66 ms, 6 waves (80 VGPRs, spills inside the insertion chains) 6.7 ms
-#define HGS_KNN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(KMAX <= 20 ? HGS_KNN_WAVES : 1)))  // the 32- / 64-slot lists keep the compiler's choice
+// (the 32- / 64-slot lists and the instantiation with the per-point eigen-decomposition keep the compiler's choice: capped at 96 VGPRs the
+// latter spills 536 bytes and its covariance pass takes 5.8 instead of 3.5 ms)
+#define HGS_KNN_OCCUPANCY __attribute__((amdgpu_waves_per_eu((KMAX <= 20 && !REG_GENERAL) ? HGS_KNN_WAVES : 1)))
 #ifndef HGS_FITNESS_WAVES
 #define HGS_FITNESS_WAVES 8
 #endif
