@@ -314,3 +314,35 @@ def check_nn1_with_equidistant_targets(make_engine):
         check_fitness(e, o, T, max_ranges=(np.finfo(np.float64).max, 0.02))
     if hasattr(e, "close"):
         e.close()
+
+
+def check_nn1_on_small_trees(make_engine, sizes=(21, 24, 25, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 511, 513, 1025)):
+    """The quad walk on every small tree shape: 3 to 129 leaves, odd and even heights (an odd height starts at the virtual node 0),
+    partly filled last leaves, the top quad that reaches past a tiny tree's own groups — correspondences (bit-exact) and fitness
+    against the oracle, unseeded and seeded, for sources larger and smaller than a packet."""
+    rng = np.random.default_rng(11)
+    p = O.default_params(O.HGS_FAST_GICP)
+    for n in sizes:
+        tgt = synth.to_xyzi(rng.normal(0, 2.0, (n, 3)).astype(np.float32))
+        for m in (7, 150):
+            src = synth.to_xyzi((rng.normal(0, 2.0, (m, 3)) + [0.3, 0.0, 0.0]).astype(np.float32))
+            if m < 21:
+                src = np.concatenate([src, synth.to_xyzi(rng.normal(0, 2.0, (21 - m, 3)).astype(np.float32))])   # covariances need k + 1 points
+            e, o = make_engine(p), make_oracle(p)
+            load_pair(e, o, tgt, src)
+            T = synth.pose_matrix([0.05, -0.02, 0.01], [0.0, 0.0, 0.01])
+            check_gicp_linearize(e, o, T)
+            check_gicp_linearize(e, o, synth.pose_matrix([0.06, -0.02, 0.01], [0.0, 0.0, 0.012]))   # seeded by the first call
+            check_fitness(e, o, T, max_ranges=(np.finfo(np.float64).max, 1.0))
+            if hasattr(e, "close"):
+                e.close()
+    # one or two leaves (no boxes to test: the walk scans the leaves) and a single point: getFitnessScore needs no covariances
+    pn = O.default_params(O.HGS_NDT_OMP)
+    for n in (1, 3, 8, 9, 16):
+        tgt = synth.to_xyzi(rng.normal(0, 2.0, (n, 3)).astype(np.float32))
+        src = synth.to_xyzi(rng.normal(0, 2.0, (70, 3)).astype(np.float32))
+        e, o = make_engine(pn), make_oracle(pn)
+        load_pair(e, o, tgt, src)
+        check_fitness(e, o, synth.pose_matrix([0.1, 0.0, 0.0], [0.0, 0.0, 0.02]), max_ranges=(np.finfo(np.float64).max, 4.0))
+        if hasattr(e, "close"):
+            e.close()

@@ -344,3 +344,7 @@ def test_ndt_deviation_from_the_serial_sum():
 
 def test_nn1_with_equidistant_target_points():
     PC.check_nn1_with_equidistant_targets(_hip)
+
+
+def test_nn1_on_small_trees():
+    PC.check_nn1_on_small_trees(_hip)

@@ -609,3 +609,8 @@ def test_sharded_batch_flags_a_candidate_two_ranks_report(simt_library):
 def test_nn1_with_equidistant_target_points(simt_library):
     """The quad walk's min-only leaves + resolve + keyed-walk fallback on duplicated / regular-grid targets (PC docstring)."""
     PC.check_nn1_with_equidistant_targets(_engine)
+
+
+def test_nn1_on_small_trees(simt_library):
+    """Quad walk on trees of 3 ... 129 leaves, odd and even heights (PC docstring)."""
+    PC.check_nn1_on_small_trees(_engine)
