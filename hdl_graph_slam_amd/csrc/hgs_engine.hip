@@ -613,8 +613,8 @@ struct BatchLane {
 // main stream and are meant to time kernels that have the device to themselves.
 int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t partial_err_bytes_per_problem, std::vector<BatchLane>& lanes) {
   // round 3, 64 x 119 k FAST_GICP batch: 1 / 2 / 3 / 4 lanes = 5615 / 5755 / 5787 / 5811 registrations/s (round 2's kernels preferred 2 above 32 problems)
-  // NDT (one launch per iteration, work queue inside): 1 / 2 / 3 / 4 lanes = 1064 / 1403 / 1384 / 1326 on the same batch (round 2)
-  const int wanted = h->batch_lanes > 0 ? h->batch_lanes : (h->prm.method == HGS_NDT_OMP && B > 32 ? 2 : 4);
+  // NDT (one launch per iteration, work queue inside): 2 / 3 / 4 lanes = 1679 / 1724 / 1652 on the 64-candidate batch (round 2: 1403 / 1384 / 1326)
+  const int wanted = h->batch_lanes > 0 ? h->batch_lanes : (h->prm.method == HGS_NDT_OMP && B > 32 ? 3 : 4);
   const int n = h->profiling ? 1 : std::max(1, std::min(std::min(wanted, kMaxLanes), B));
   lanes.assign(n, BatchLane{});
   for (int i = 0, b0 = 0; i < n; i++) {
