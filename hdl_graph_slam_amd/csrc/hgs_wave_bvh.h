@@ -555,6 +555,10 @@ struct KnnRadiusLane {
     for (int i = KMAX - 1; i > 0; i--) d[i] = __builtin_amdgcn_fmed3f(d[i - 1], d[i], x);
     d[0] = fminf(d[0], x);
   }
+  // The same from wave-uniform control flow (a lane with nothing to insert passes FLT_MAX, which leaves its list as it is): no
+  // divergent branch around the chain.  Stopping the chain early at the first five-slot segment no lane's value reaches (13 instead
+  // of 20 v_med3 on average) was measured and is slower (covariance stage 3.94 vs 3.56 ms: the ballots serialise the chain).
+  __device__ __forceinline__ void insert_wave(float x) { insert(x); }
   __device__ __forceinline__ void visit_leaf(const hgs_f16v& xy, const hgs_f16v& zw, hgs_f2 qx, hgs_f2 qy, hgs_f2 qz, int base) {
     hgs_f2 dd[4];
 #pragma unroll
@@ -568,8 +572,8 @@ struct KnnRadiusLane {
     }
 #pragma unroll
     for (int l = 0; l < 4; l++) {
-      if (dd[l].x < worst()) insert(dd[l].x);
-      if (dd[l].y < worst()) insert(dd[l].y);
+      if (__ballot(dd[l].x < worst()) != 0ull) insert_wave(dd[l].x < worst() ? dd[l].x : FLT_MAX);
+      if (__ballot(dd[l].y < worst()) != 0ull) insert_wave(dd[l].y < worst() ? dd[l].y : FLT_MAX);
     }
   }
 };
