@@ -31,6 +31,20 @@ namespace hgs {
 #ifndef HGS_COMPILER_MEMORY_BARRIER
 #define HGS_COMPILER_MEMORY_BARRIER() asm volatile("" ::: "memory")
 #endif
+#ifndef HGS_LOAD_GLOBAL_XYZ  // (the host emulation supplies its own spelling of these as well)
+// a float4 behind a pointer read from a descriptor in memory: the compiler cannot tell its address space and issues flat_load, which
+// counts on vmcnt AND lgkmcnt (every LDS wait then waits for it too); this is global_load
+__device__ __forceinline__ float4 hgs_load_global_xyz(const float4* p) {  // .w = 0: three dwords loaded, no fourth register to wait for
+  const __attribute__((address_space(1))) float* g = (const __attribute__((address_space(1))) float*)(p);
+  return make_float4(g[0], g[1], g[2], 0.f);
+}
+#define HGS_LOAD_GLOBAL_XYZ(p) hgs_load_global_xyz(p)
+// `off` = 0 the compiler cannot see through, added to a __shared__ address: the object is re-read where it is used (like HGS_OPAQUE_POINTER)
+// but stays an LDS address (ds_read instead of flat_load)
+#define HGS_OPAQUE_OFFSET(off) asm volatile("" : "+v"(off))
+// s_waitcnt vmcnt(0) the compiler's own wait insertion knows about (gfx9 encoding: expcnt and lgkmcnt fields at their maxima)
+#define HGS_WAIT_VMEM_TRACKED() __builtin_amdgcn_s_waitcnt(0x0F70)
+#endif
 #ifndef HGS_LINEARIZE_WAVES
 #define HGS_LINEARIZE_WAVES 7  // waves per SIMD k_gicp_linearize is compiled for (A/B knob; 6 / 7 / 8 measured equal: 68 VGPRs, no scratch)
 #endif
@@ -1092,6 +1106,102 @@ __device__ __forceinline__ int ndt_pop_cell(unsigned& mask, const int (&ci)[NOFF
   return c;
 }
 
+// ---- the three memory stages in front of a tile's arithmetic; k_ndt_pass runs them for tile t + 1 between the pieces of tile t's
+// digit reduction (point -> hash probes -> first cell record are dependent loads: with two waves per SIMD their latencies were exposed)
+struct NdtGridBox {
+  int mnx, mny, mnz, mxx, mxy, mxz, mul1, mul2;
+};
+
+// hash key of neighbourhood cell o of a transformed point; -1 outside the grid's box and for a lane without a point.
+// A transformed source point can be anything (non-finite, 1e30): clamp before the conversion — such a coordinate is
+// outside every grid either way, and float -> int of a NaN or an out-of-range value is not defined in C++
+__device__ __forceinline__ int ndt_front_key(const F3& xt, int have, const NdtTargetView& tgt, const NdtGridBox& g, int search, int o) {
+  const int cx = ndt_cell_coord(xt.x * tgt.inv_leaf), cy = ndt_cell_coord(xt.y * tgt.inv_leaf), cz = ndt_cell_coord(xt.z * tgt.inv_leaf);
+  int ox, oy, oz;
+  ndt_offset(search, o, &ox, &oy, &oz);
+  const int px = cx + ox, py = cy + oy, pz = cz + oz;
+  const bool in = have && px >= g.mnx && px <= g.mxx && py >= g.mny && py <= g.mxy && pz >= g.mnz && pz <= g.mxz;
+  return in ? (px - g.mnx) + (py - g.mny) * g.mul1 + (pz - g.mnz) * g.mul2 : -1;
+}
+
+// x: the lane's source point; have: the lane has one
+__device__ __forceinline__ void ndt_front_load(float4& x, int& have, const CloudDesc& d, int sorted, int i, int n) {
+  have = i < n ? 1 : 0;
+  x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (have) x = HGS_LOAD_GLOBAL_XYZ((sorted ? d.pts : d.raw) + i);
+}
+
+// xt: the point under the problem's current pose; kv: the first probe of every neighbourhood cell, in flight on return
+template <int NOFF>
+__device__ __forceinline__ void ndt_front_issue_probes(const float4& x, int& have, F3& xt, unsigned long long (&kv)[NOFF], const NdtAngles* ap, const NdtTargetView& tgt, const NdtGridBox& g,
+                                                       int search, int sorted) {
+  if (!sorted && !finite3(x)) have = 0;
+  xt = transform_point_f(ap->T, x.x, x.y, x.z);
+#pragma unroll
+  for (int o = 0; o < NOFF; o++) {
+    const int key = ndt_front_key(xt, have, tgt, g, search, o);
+    const unsigned slot = (ndt_hash(key) >> 7) & (unsigned)tgt.hash_mask;
+    kv[o] = key >= 0 ? reinterpret_cast<const unsigned long long*>(tgt.hash_kv)[slot] : ~0ull;  // {key, cell index}, raw
+  }
+}
+
+// ci: cell record index or -1 per neighbourhood cell; vmask: the valid ones
+template <int NOFF>
+__device__ __forceinline__ void ndt_front_resolve(const F3& xt, int have, unsigned long long (&kv)[NOFF], int (&ci)[NOFF], unsigned& vmask, const NdtTargetView& tgt, const NdtGridBox& g, int search) {
+  vmask = 0;
+#pragma unroll
+  for (int o = 0; o < NOFF; o++) {
+    const int key = ndt_front_key(xt, have, tgt, g, search, o);  // recomputed (a dozen integer operations) rather than carried through the reduction
+    unsigned slot = (ndt_hash(key) >> 7) & (unsigned)tgt.hash_mask;
+    unsigned long long e = kv[o];
+    while ((int)(unsigned)e != key && (int)(unsigned)e != -1) {  // linear probing (load factor <= 1/4: almost never taken)
+      slot = (slot + 1u) & (unsigned)tgt.hash_mask;
+      e = reinterpret_cast<const unsigned long long*>(tgt.hash_kv)[slot];
+    }
+    ci[o] = (key >= 0 && (int)(unsigned)e == key) ? (int)(unsigned)(e >> 32) : -1;
+    if (ci[o] >= 0) vmask |= 1u << o;
+  }
+}
+
+// Accumulators [K0, K1) of a tile's exact accumulation: per-point doubles -> four unsigned digits -> rows of the wave -> this wave's totals in LDS.
+// Digits of a chunk q (|q| < 2^49, carried as the mantissa field 2^51 + q): q mod 2^25 (the 64 lanes' sum stays below
+// 2^31) and 2^26 + floor(q / 2^25) — the 2^26 of the 64 lanes add up to 2^32 and vanish from the 32-bit wave sum, which
+// read as a signed integer is the sum of the floors (|.| < 2^30).
+// The last 16 -> 1 steps are DPP row shifts (LDS atomics with 16 lanes per address were measured at ~500 cycles each);
+// the row-end lanes then add into the wave's totals in LDS.
+template <int K0, int K1>
+__device__ __forceinline__ bool ndt_reduce_sums(const double (&acc)[kAccNdt], unsigned long long* tot_wave, int lane) {
+  bool bad = false;
+#pragma unroll
+  for (int k0 = K0; k0 < K1; k0 += 4) {
+    // four accumulators side by side: their dependent DPP chains fill each other's wait states
+    unsigned z[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = k0 + j < kAccNdt ? k0 + j : kAccNdt - 1;
+      double m0, m1;
+      if (!ndt_exact_split(acc[k], ndt_sum_exponent(k), &m0, &m1)) bad = true;
+      const unsigned long long b0 = (unsigned long long)__double_as_longlong(m0), b1 = (unsigned long long)__double_as_longlong(m1);
+      z[j] = wave_rows4_u32((unsigned)b0 & 0x1ffffffu, (unsigned)(b0 >> 25) & 0x7ffffffu, (unsigned)b1 & 0x1ffffffu, (unsigned)(b1 >> 25) & 0x7ffffffu);
+    }
+    // row_shr:1, 2, 4, 8: lane 15 of each 16-lane row ends up with the row's sum
+#pragma unroll
+    for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x111, 0xf, 0xf, true);
+#pragma unroll
+    for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x112, 0xf, 0xf, true);
+#pragma unroll
+    for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x114, 0xf, 0xf, true);
+#pragma unroll
+    for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x118, 0xf, 0xf, true);
+    if ((lane & 15) == 15) {  // rows: chunk0 low, chunk1 low, chunk0 high, chunk1 high
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (k0 + j < kAccNdt) tot_wave[(k0 + j) * 4 + (lane >> 4)] += lane < 32 ? (unsigned long long)z[j] : (unsigned long long)(long long)(int)z[j];
+    }
+  }
+  return bad;
+}
+
 struct NdtPassShared {
   NdtAngles ang;
   unsigned long long tot[kBlock / 64][kAccNdt * 4];  // per wave: digit sums of the tiles since the last flush
@@ -1189,10 +1299,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
   if (threadIdx.x == 0) S.out_of_range = 0, S.next = (unsigned long long)blockIdx.x * (unsigned long long)first_chunk, S.next_chunk = first_chunk, S.consts = c, S.prog = prog, S.debug = debug;
   __syncthreads();
   const CloudMeta* m = tgt.meta;
-  const int mnx = m->ndt_min_b[0], mny = m->ndt_min_b[1], mnz = m->ndt_min_b[2];
-  const int mxx = m->ndt_max_b[0], mxy = m->ndt_max_b[1], mxz = m->ndt_max_b[2];
-  const int mul1 = m->ndt_div_mul[1], mul2 = m->ndt_div_mul[2];
+  const NdtGridBox box = {m->ndt_min_b[0], m->ndt_min_b[1], m->ndt_min_b[2], m->ndt_max_b[0], m->ndt_max_b[1], m->ndt_max_b[2], m->ndt_div_mul[1], m->ndt_div_mul[2]};
   const float d1 = (float)c.gauss_d1, d2 = (float)c.gauss_d2;
+  // The tile at hand: point, transformed point, first hash probes, cell indices; `staged`: filled during the previous tile's reduction.
+  // Not for the 27-cell neighbourhood, whose 27 probes in flight do not fit the register file next to the 43 sums.
+  constexpr bool kStaged = NOFF <= 7;
+  float4 fx = make_float4(0.f, 0.f, 0.f, 0.f);
+  F3 fxt = {0.f, 0.f, 0.f};
+  int fhave = 0, fci[NOFF];
+  unsigned long long fkv[NOFF];
+  unsigned fvmask = 0;
+  bool staged = false;
   int cur_b = -1, cur_active = 0, cur_tiles = 0, cur_n = 0, cur_first = 0, cur_end = 0;  // block-uniform: the problem being worked on
   CloudDesc d{};
   unsigned long long w = S.next;
@@ -1233,110 +1350,59 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
       cur_tiles++;
       const int tile = item - cur_first;
       if (tile * kBlock >= cur_n && !(tile == 0)) continue;  // the host's tile count is an upper bound (non-finite points); tile 0 always runs
-      const NdtAngles* ap = &S.ang;
-      HGS_OPAQUE_POINTER(ap);  // re-read the tables from LDS every tile: hoisted out of the loop they would pin 81 VGPRs
+      unsigned ang_off = 0;
+      HGS_OPAQUE_OFFSET(ang_off);  // re-read the tables from LDS every tile: hoisted out of the loop they would pin 81 VGPRs
+      const NdtAngles* ap = reinterpret_cast<const NdtAngles*>(reinterpret_cast<const char*>(&S.ang) + ang_off);
+      if (!staged) {  // first tile of a run: the three dependent loads one after the other
+        ndt_front_load(fx, fhave, d, sorted, tile * kBlock + (int)threadIdx.x, cur_n);
+        ndt_front_issue_probes<NOFF>(fx, fhave, fxt, fkv, ap, tgt, box, c.search, sorted);
+        ndt_front_resolve<NOFF>(fxt, fhave, fkv, fci, fvmask, tgt, box, c.search);
+      }
+      // the next item is the next tile of the same problem: its point, probes and cell indices are fetched under this tile's reduction
+      const bool stage_next = kStaged && it + 1 < hi && item + 1 < cur_end && (tile + 1) * kBlock < cur_n;
       double acc[kAccNdt];
 #pragma unroll
       for (int k = 0; k < kAccNdt; k++) acc[k] = 0.0;
-      bool any_cell;
-      {
-        const int i = tile * kBlock + threadIdx.x;
-        bool have = i < cur_n;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (have) x = sorted ? d.pts[i] : d.raw[i];
-        if (!sorted && !finite3(x)) have = false;
-        const F3 xt = transform_point_f(ap->T, x.x, x.y, x.z);
-        int ci[NOFF];
-        unsigned vmask = 0;
-        {
-          // a transformed source point can be anything (non-finite, 1e30): clamp before the conversion — such a coordinate is
-          // outside every grid either way, and float -> int of a NaN or an out-of-range value is not defined in C++
-          const int cx = ndt_cell_coord(xt.x * tgt.inv_leaf), cy = ndt_cell_coord(xt.y * tgt.inv_leaf), cz = ndt_cell_coord(xt.z * tgt.inv_leaf);
-          int key[NOFF];
-          unsigned slot[NOFF];
-          int2 kv[NOFF];
-#pragma unroll
-          for (int o = 0; o < NOFF; o++) {
-            int ox, oy, oz;
-            ndt_offset(c.search, o, &ox, &oy, &oz);
-            const int px = cx + ox, py = cy + oy, pz = cz + oz;
-            const bool in = have && px >= mnx && px <= mxx && py >= mny && py <= mxy && pz >= mnz && pz <= mxz;
-            key[o] = in ? (px - mnx) + (py - mny) * mul1 + (pz - mnz) * mul2 : -1;
-            slot[o] = (ndt_hash(key[o]) >> 7) & (unsigned)tgt.hash_mask;
-            kv[o] = in ? tgt.hash_kv[slot[o]] : make_int2(-1, -1);
-          }
-#pragma unroll
-          for (int o = 0; o < NOFF; o++) {
-            while (kv[o].x != key[o] && kv[o].x != -1) {  // linear probing (load factor <= 1/4: almost never taken)
-              slot[o] = (slot[o] + 1u) & (unsigned)tgt.hash_mask;
-              kv[o] = tgt.hash_kv[slot[o]];
-            }
-            ci[o] = (key[o] >= 0 && kv[o].x == key[o]) ? kv[o].y : -1;
-            if (ci[o] >= 0) vmask |= 1u << o;
-          }
-        }
-        any_cell = __ballot(vmask != 0u) != 0ull;
-        if (any_cell) {
-          NdtPointDeriv pd;
-          ndt_point_derivatives(*ap, x.x, x.y, x.z, pd);
-          // Visit the point's valid cells in neighbourhood order, the record of visit k+1 in flight during the arithmetic of
-          // visit k.  A counted loop with a wave-uniform early exit: the `while (any lane has a cell)` form of the same loop
-          // made the register allocator keep two copies of the 43 double sums (368 VGPRs instead of 216).
-          int cur = ndt_pop_cell<NOFF>(vmask, ci);
-          NdtCellRec rc = tgt.cells[cur >= 0 ? cur : 0];
+      const F3 xt = fxt;
+      unsigned vmask = fvmask;
+      const bool any_cell = __ballot(vmask != 0u) != 0ull;
+      if (any_cell) {
+        // Visit the point's valid cells in neighbourhood order, the record of visit k+1 in flight during the arithmetic of
+        // visit k.  A counted loop with a wave-uniform early exit: the `while (any lane has a cell)` form of the same loop
+        // made the register allocator keep two copies of the 43 double sums (368 VGPRs instead of 216).
+        int cur = ndt_pop_cell<NOFF>(vmask, fci);
+        NdtCellRec rc = tgt.cells[cur >= 0 ? cur : 0];
+        NdtPointDeriv pd;
+        ndt_point_derivatives(*ap, fx.x, fx.y, fx.z, pd);
 #pragma unroll 1
-          for (int v = 0; v < NOFF; v++) {
-            if (__ballot(cur >= 0) == 0ull) break;
-            const int nx = ndt_pop_cell<NOFF>(vmask, ci);
-            NdtCellRec rn = rc;
-            if (nx >= 0) rn = tgt.cells[nx];
-            if (cur >= 0 && ndt_cell_in_reach(c, xt, rc.mean)) {
-              const float icov[6] = {rc.v0.x, rc.v0.y, rc.v0.z, rc.v0.w, rc.v1.x, rc.v1.y};
-              ndt_cell_terms_pk(d1, d2, pd, (float)((double)xt.x - rc.mean[0]), (float)((double)xt.y - rc.mean[1]), (float)((double)xt.z - rc.mean[2]), icov, acc);
-            }
-            cur = nx;
-            rc = rn;
+        for (int v = 0; v < NOFF; v++) {
+          if (__ballot(cur >= 0) == 0ull) break;
+          const int nx = ndt_pop_cell<NOFF>(vmask, fci);
+          NdtCellRec rn = rc;
+          if (nx >= 0) rn = tgt.cells[nx];
+          if (cur >= 0 && ndt_cell_in_reach(c, xt, rc.mean)) {
+            const float icov[6] = {rc.v0.x, rc.v0.y, rc.v0.z, rc.v0.w, rc.v1.x, rc.v1.y};
+            ndt_cell_terms_pk(d1, d2, pd, (float)((double)xt.x - rc.mean[0]), (float)((double)xt.y - rc.mean[1]), (float)((double)xt.z - rc.mean[2]), icov, acc);
           }
+          cur = nx;
+          rc = rn;
         }
       }
-      // ---- exact accumulation: per-point doubles -> four unsigned digits -> rows of the wave -> this wave's totals in LDS ----
-      // digits of a chunk q (|q| < 2^49, carried as the mantissa field 2^51 + q): q mod 2^25 (the 64 lanes' sum stays below
-      // 2^31) and 2^26 + floor(q / 2^25) — the 2^26 of the 64 lanes add up to 2^32 and vanish from the 32-bit wave sum, which
-      // read as a signed integer is the sum of the floors (|.| < 2^30).
-      // The last 16 -> 1 steps are DPP row shifts (LDS atomics with 16 lanes per address were measured at ~500 cycles each);
-      // the row-end lanes then add into the wave's totals in LDS.  A wave none of whose points met a cell has nothing but
-      // zeros to add and skips all of it.
+      // ---- exact accumulation of the tile's 43 sums (ndt_reduce_sums), in two pieces with the next tile's loads between them.
+      // A wave none of whose points met a cell has nothing but zeros to add and skips the arithmetic.
+      bool bad = false;
+      // (the cell loop's last record prefetch may still be in flight into registers the reduction reuses: waited for here, in front of
+      // the staged load, instead of where the compiler would put the wait — behind it, which made the load synchronous)
+      HGS_WAIT_VMEM_TRACKED();
+      if (stage_next) ndt_front_load(fx, fhave, d, sorted, (tile + 1) * kBlock + (int)threadIdx.x, cur_n);
+      if (any_cell) bad = ndt_reduce_sums<0, 20>(acc, S.tot[wave], lane);
+      if (stage_next) ndt_front_issue_probes<NOFF>(fx, fhave, fxt, fkv, ap, tgt, box, c.search, sorted);
       if (any_cell) {
-        bool bad = false;
-#pragma unroll
-        for (int k0 = 0; k0 < kAccNdt; k0 += 4) {
-          // four accumulators side by side: their dependent DPP chains fill each other's wait states
-          unsigned z[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int k = k0 + j < kAccNdt ? k0 + j : kAccNdt - 1;
-            double m0, m1;
-            if (!ndt_exact_split(acc[k], ndt_sum_exponent(k), &m0, &m1)) bad = true;
-            const unsigned long long b0 = (unsigned long long)__double_as_longlong(m0), b1 = (unsigned long long)__double_as_longlong(m1);
-            z[j] = wave_rows4_u32((unsigned)b0 & 0x1ffffffu, (unsigned)(b0 >> 25) & 0x7ffffffu, (unsigned)b1 & 0x1ffffffu, (unsigned)(b1 >> 25) & 0x7ffffffu);
-          }
-          // row_shr:1, 2, 4, 8: lane 15 of each 16-lane row ends up with the row's sum
-#pragma unroll
-          for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x111, 0xf, 0xf, true);
-#pragma unroll
-          for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x112, 0xf, 0xf, true);
-#pragma unroll
-          for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x114, 0xf, 0xf, true);
-#pragma unroll
-          for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x118, 0xf, 0xf, true);
-          if ((lane & 15) == 15) {  // rows: chunk0 low, chunk1 low, chunk0 high, chunk1 high
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-              if (k0 + j < kAccNdt) S.tot[wave][(k0 + j) * 4 + (lane >> 4)] += lane < 32 ? (unsigned long long)z[j] : (unsigned long long)(long long)(int)z[j];
-          }
-        }
+        if (ndt_reduce_sums<20, kAccNdt>(acc, S.tot[wave], lane)) bad = true;
         if (__ballot(bad) != 0ull && lane == 0) S.out_of_range = 1;
       }
+      if (stage_next) ndt_front_resolve<NOFF>(fxt, fhave, fkv, fci, fvmask, tgt, box, c.search);
+      staged = stage_next;
     }
     __syncthreads();  // everybody has read S.next_chunk
     if (threadIdx.x == 0) S.next = nxt, S.next_chunk = nxt_chunk;

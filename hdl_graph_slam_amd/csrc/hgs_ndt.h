@@ -98,6 +98,19 @@ struct NdtConsts {
 // the device library and glibc in the last place of a few results, and ndt_omp's iteration amplifies exactly that.
 // ndt_omp evaluates exp in float; here: Cody-Waite reduction + degree-13 Taylor polynomial in double (error < 1 ulp of the
 // double result), rounded once to float by the caller.  Only the range the float result can represent is resolved.
+#if defined(__HIP_DEVICE_COMPILE__)
+// A polynomial coefficient materialised where it is used (two s_mov_b32 into a scalar pair that v_fma_f64 reads directly): left to
+// itself the compiler hoists the dozen 64-bit constants out of k_ndt_pass's cell loop into VGPR pairs — 20 registers of a kernel
+// that sits at the two-waves-per-SIMD limit — and copies one into the accumulator in front of every v_fmac_f64.
+__device__ __forceinline__ double ndt_exp_coeff(double c) {
+  int lo = (int)(unsigned)((unsigned long long)__double_as_longlong(c) & 0xffffffffull), hi = (int)(unsigned)((unsigned long long)__double_as_longlong(c) >> 32);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return __hiloint2double(hi, lo);
+}
+#define HGS_NDT_EXP_COEFF(c) ndt_exp_coeff(c)
+#else
+#define HGS_NDT_EXP_COEFF(c) (c)
+#endif
 HGS_HD double ndt_exp(double x) {
   HGS_FP_STRICT
   if (x != x) return x;
@@ -106,16 +119,16 @@ HGS_HD double ndt_exp(double x) {
   const double kd = rint(x * 0x1.71547652b82fep+0);
   const double r = fma(-kd, 0x1.a39ef35793c76p-33, fma(-kd, 0x1.62e42fee00000p-1, x));
   double p = 0x1.6124613a86d09p-33;
-  p = fma(p, r, 0x1.1eed8eff8d898p-29);
-  p = fma(p, r, 0x1.ae64567f544e4p-26);
-  p = fma(p, r, 0x1.27e4fb7789f5cp-22);
-  p = fma(p, r, 0x1.71de3a556c734p-19);
-  p = fma(p, r, 0x1.a01a01a01a01ap-16);
-  p = fma(p, r, 0x1.a01a01a01a01ap-13);
-  p = fma(p, r, 0x1.6c16c16c16c17p-10);
-  p = fma(p, r, 0x1.1111111111111p-7);
-  p = fma(p, r, 0x1.5555555555555p-5);
-  p = fma(p, r, 0x1.5555555555555p-3);
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.1eed8eff8d898p-29));
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.ae64567f544e4p-26));
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.27e4fb7789f5cp-22));
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.71de3a556c734p-19));
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.a01a01a01a01ap-16));
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.a01a01a01a01ap-13));
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.6c16c16c16c17p-10));
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.1111111111111p-7));
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.5555555555555p-5));
+  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.5555555555555p-3));
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);

@@ -14,6 +14,9 @@
 #define HGS_SIMT_EMULATION 1
 #define HGS_OPAQUE_POINTER(p) asm volatile("" : "+r"(p))
 #define HGS_WAIT_VMEM() ((void)0)
+#define HGS_LOAD_GLOBAL_XYZ(p) make_float4((p)->x, (p)->y, (p)->z, 0.f)
+#define HGS_OPAQUE_OFFSET(off) asm volatile("" : "+r"(off))
+#define HGS_WAIT_VMEM_TRACKED() ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define HGS_LANE_ID(dst) ((dst) = (int)(threadIdx.x & 63))
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
