@@ -44,10 +44,12 @@ const Rccl* rccl(char* err, size_t cap) {
   static std::once_flag once;
   std::call_once(once, [] {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // an RCCL the process already holds (RTLD_NOLOAD matches the names and the SONAME it was loaded under), then $ROCM_PATH's, then the search path
+    for (int k = 0; k < 2 && !table.lib; k++) table.lib = dlopen(names[k], RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     const char* env = std::getenv("ROCM_PATH");
     char from_env[512] = "";
     if (env) snprintf(from_env, sizeof(from_env), "%s/lib/librccl.so", env);
-    if (from_env[0]) table.lib = dlopen(from_env, RTLD_NOW | RTLD_LOCAL);
+    if (!table.lib && from_env[0]) table.lib = dlopen(from_env, RTLD_NOW | RTLD_LOCAL);
     for (const char* n : names)
       if (!table.lib) table.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (!table.lib) {
