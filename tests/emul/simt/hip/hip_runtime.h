@@ -142,6 +142,25 @@ static inline unsigned update_dpp_row_shr(unsigned src, int ctrl, int site = 0) 
   if (ctrl < 0x111 || ctrl > 0x11f) abort();
   return (l & 15) >= n ? (unsigned)all[l - n] : 0u;
 }
+// v_mfma_f64_16x16x4_f64: D = A * B + C with one f64 of A and of B per lane, A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// and four f64 of C / D per lane, register r holding row (lane >> 4) + 4 r of column lane & 15 (MI355X_MICROARCH.md, "f64 MFMA does NOT use
+// these maps").  The products are accumulated by fma in k order — the callers feed integer-valued doubles, for which any order is exact.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+static inline f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c, int site = 0) {
+  unsigned long long A[64], B[64];
+  const unsigned long long live_a = wave_exchange(7 | (site << 4), to_bits(a), A);
+  wave_exchange(8 | (site << 4), to_bits(b), B);
+  if (live_a != ~0ull) abort();  // a matrix instruction of a partial wave: not what the kernels mean
+  const int l = g_cur->lane, col = l & 15;
+  f64x4 d = c;
+  for (int r = 0; r < 4; r++) {
+    const int row = (l >> 4) + 4 * r;
+    double acc = c[r];
+    for (int k = 0; k < 4; k++) acc = fma(from_bits<double>(A[row + 16 * k]), from_bits<double>(B[col + 16 * k]), acc);
+    d[r] = acc;
+  }
+  return d;
+}
 static inline void wave_barrier(int site = 0) {
   unsigned long long all[64];
   wave_exchange(4 | (site << 4), 0ull, all);
@@ -165,6 +184,7 @@ static inline void wave_barrier(int site = 0) {
 #define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) simt::permlane_swap((a), (b), 32, __LINE__)
 #define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) simt::permlane_swap((a), (b), 16, __LINE__)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt::update_dpp_row_shr((src), (ctrl), __LINE__)
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, cbsz, abid, blgp) simt::mfma_f64_16x16x4((a), (b), (c), __LINE__)
 #define __builtin_amdgcn_fmed3f(a, b, c) fmaxf(fminf((a), (b)), fminf(fmaxf((a), (b)), (c)))
 #define __threadfence_system() ((void)0)
 #define __threadfence() ((void)0)
@@ -219,6 +239,7 @@ static inline T atomicExch(T* p, T v) {
 }
 static inline long long __double_as_longlong(double d) { return simt::from_bits<long long>(simt::to_bits(d)); }
 static inline double __longlong_as_double(long long i) { return simt::from_bits<double>(simt::to_bits(i)); }
+static inline double __hiloint2double(int hi, int lo) { return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo)); }
 template <typename T>
 static inline T atomicCAS(T* p, T expected, T desired) {
   const T o = *p;
