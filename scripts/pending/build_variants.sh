@@ -1,11 +1,12 @@
 #!/bin/bash
-# CPU side of the A/B of scripts/pending: ab_libs/vH.so (the tree as it is), ab_libs/<patch>.so per patch, and the two combinations that
-# apply together (the two reduction patches exclude each other): items32_scalar.so, items32_mfma.so.
-# GPU side:  gpurun -- 'VARIANTS="vH ndt_pass_items32 ndt_reduction_scalar_scales ndt_reduction_mfma items32_mfma" bash scripts/r03_ab_ndt.sh'
+# CPU side of the A/B of scripts/pending: ab_libs/vH.so (the tree as it is), ab_libs/<patch>.so per patch, and mfma_all.so =
+# ndt_pass_items32 + ndt_reduction_mfma + gicp_linearize_sums_mfma (ndt_reduction_scalar_scales and ndt_reduction_mfma exclude each other).
+# GPU side (NDT):       gpurun -- 'VARIANTS="vH ndt_pass_items32 ndt_reduction_scalar_scales ndt_reduction_mfma mfma_all" bash scripts/r03_ab_ndt.sh'
+# GPU side (FAST_GICP): gpurun -- 'VARIANTS="vH gicp_linearize_sums_mfma mfma_all" BENCH_FLAGS=" " bash scripts/r03_ab.sh'
 set -eu
 cd "$(dirname "$0")/../.."
-git diff --quiet -- hdl_graph_slam_amd/csrc oracle tests/emul || { echo "uncommitted changes in the patched directories"; exit 1; }
-restore() { git checkout -- hdl_graph_slam_amd/csrc oracle tests/emul; }
+git diff --quiet -- hdl_graph_slam_amd/csrc oracle || { echo "uncommitted changes in the patched directories"; exit 1; }
+restore() { git checkout -- hdl_graph_slam_amd/csrc oracle; }
 trap restore EXIT
 scripts/build_variant.sh vH > /dev/null
 for p in scripts/pending/*.patch; do
@@ -14,9 +15,7 @@ for p in scripts/pending/*.patch; do
   scripts/build_variant.sh "$n" > /dev/null || echo "build of $n failed"
   restore
 done
-for r in scalar_scales mfma; do
-  git apply scripts/pending/ndt_pass_items32.patch scripts/pending/ndt_reduction_$r.patch
-  scripts/build_variant.sh items32_$r > /dev/null || echo "build of items32_$r failed"
-  restore
-done
+git apply scripts/pending/ndt_pass_items32.patch scripts/pending/ndt_reduction_mfma.patch scripts/pending/gicp_linearize_sums_mfma.patch
+scripts/build_variant.sh mfma_all > /dev/null || echo "build of mfma_all failed"
+restore
 ls -la ab_libs/
