@@ -9,6 +9,10 @@ export HGS_BATCH_LANES=1
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$ROOT"
 mkdir -p gpurun_out
+# LIB=ab_libs/<variant>.so profiles a library variant (scripts/build_variant.sh, scripts/pending/build_variants.sh) instead of the product library;
+# TAG names its outputs (gpurun_out/r03_<method><TAG>_kernel_stats.md, pmc_<method><TAG>/)
+if [ -n "${LIB:-}" ]; then cp "$LIB" hdl_graph_slam_amd/lib/libhgs_hip.so; fi
+TAG="${TAG:-}"
 if [ -n "${PRE:-}" ]; then echo "== pytest $PRE"; HGS_BATCH_LANES= timeout 900 python -m pytest $PRE -m gpu -q -x --timeout 400 -p no:cacheprovider 2>&1 | tail -4; fi
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-ndt-record --seeds 1"
 for M in ${METHODS:-FAST_GICP}; do
@@ -16,10 +20,10 @@ for M in ${METHODS:-FAST_GICP}; do
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_$m" -o bench -- python "$ROOT/bench.py" --method $M $ARGS > "$ROOT/gpurun_out/prof_$m.log" 2>&1); echo "trace $M exit $?"
   f=$(find gpurun_out/prof_$m -name "*kernel_stats.csv" | head -1)
   { echo "rocprofv3 --kernel-trace --stats -- python bench.py --method $M $ARGS   (HGS_BATCH_LANES=1)"; echo; echo '```'; grep '^{' gpurun_out/prof_$m.log | tail -1; echo '```'; echo;
-    [ -n "$f" ] && python scripts/prof_summary.py "$f"; } > gpurun_out/r03_${m}_kernel_stats.md
-  head -12 gpurun_out/r03_${m}_kernel_stats.md | cut -c1-300
+    [ -n "$f" ] && python scripts/prof_summary.py "$f"; } > gpurun_out/r03_${m}${TAG}_kernel_stats.md
+  head -12 gpurun_out/r03_${m}${TAG}_kernel_stats.md | cut -c1-300
   [ -n "${NO_PMC:-}" ] && continue
-  OUT="$ROOT/gpurun_out/pmc_$m"; mkdir -p "$OUT"
+  OUT="$ROOT/gpurun_out/pmc_$m$TAG"; mkdir -p "$OUT"
   run_pass() {
     local name="$1"; shift
     (cd /tmp && timeout 400 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o pmc -- python "$ROOT/bench.py" --method $M $ARGS > "$OUT/$name.log" 2>&1)
