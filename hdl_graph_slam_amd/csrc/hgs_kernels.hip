@@ -1065,18 +1065,6 @@ __device__ __forceinline__ void solve_svd6_wave(const double* A, const double* b
   if (lane == 0) svd6_backsolve<const double*>(U, V, b, x);
 }
 
-// Four registers' values partially summed across the wave by two transposing steps (v_permlane32_swap / v_permlane16_swap:
-// swap halves of two registers, add — one add reduces two values): afterwards every lane of 16-lane row 0 / 1 / 2 / 3 holds
-// the sum of four lanes' values of a / c / b / d, and the 16 lanes of a row together cover all 64 lanes.  Inputs < 2^27.
-__device__ __forceinline__ unsigned wave_rows4_u32(unsigned a, unsigned b, unsigned c, unsigned d) {
-  const auto ab = __builtin_amdgcn_permlane32_swap(a, b, false, false);  // {a.lo | b.lo}, {a.hi | b.hi}
-  const unsigned x = ab[0] + ab[1];                                      // lanes 0..31: a, lanes 32..63: b
-  const auto cd = __builtin_amdgcn_permlane32_swap(c, d, false, false);
-  const unsigned y = cd[0] + cd[1];
-  const auto xy = __builtin_amdgcn_permlane16_swap(x, y, false, false);  // rows {x0, y0, x2, y2}, {x1, y1, x3, y3}
-  return xy[0] + xy[1];                                                  // rows: a, c, b, d
-}
-
 // One NDT iteration of a batch in ONE launch (computeDerivatives + the Newton step of computeTransformation /
 // computeStepLengthMT).  Work items are (problem, tile of 256 points); the resident blocks pull chunks of consecutive items
 // from a queue in HBM, so the load balances itself whatever the sizes of the clouds and however many problems of the batch
@@ -1085,7 +1073,8 @@ __device__ __forceinline__ unsigned wave_rows4_u32(unsigned a, unsigned b, unsig
 //      together, the cell records are fetched one visit ahead of the arithmetic), accumulate the point's score /
 //      gradient / Hessian over its cells in neighbourhood order (double, like ndt_omp's per-point sums);
 //   2. the per-point doubles are split into fixed-grid integer chunks (hgs_ndt.h "exact accumulation") and summed as
-//      integers: wave (wave_rows4_u32 on 25/27-bit digits + LDS atomics) -> block (LDS, over all the tiles of one problem the
+//      integers: lane (every lane adds its chunks to its own 64-bit slot of the block's table in LDS, ndt_reduce_sums: no cross-lane
+//      step per tile) -> block (the 64 lanes of a slot added up once per flush, over all the tiles of one problem the
 //      block works on in a row) -> problem (64-bit atomics in HBM, one per digit total and flush).  Integer addition is
 //      associative: the totals do not depend on tiling, on which block took which tile or on the order the points are
 //      stored in, so the points are read in whatever order is resident (Hilbert order when the cloud has a search index —
@@ -1163,53 +1152,66 @@ __device__ __forceinline__ void ndt_front_resolve(const F3& xt, int have, unsign
   }
 }
 
-// Accumulators [K0, K1) of a tile's exact accumulation: per-point doubles -> four unsigned digits -> rows of the wave -> this wave's totals in LDS.
-// Digits of a chunk q (|q| < 2^49, carried as the mantissa field 2^51 + q): q mod 2^25 (the 64 lanes' sum stays below
-// 2^31) and 2^26 + floor(q / 2^25) — the 2^26 of the 64 lanes add up to 2^32 and vanish from the 32-bit wave sum, which
-// read as a signed integer is the sum of the floors (|.| < 2^30).
-// The last 16 -> 1 steps are DPP row shifts (LDS atomics with 16 lanes per address were measured at ~500 cycles each);
-// the row-end lanes then add into the wave's totals in LDS.
+// Accumulators [K0, K1) of a tile's exact accumulation (round 4): every lane adds the two integer chunks of its per-point double to ITS OWN
+// 64-bit slot of the block's accumulator table in LDS — slot [2k + chunk][lane], consecutive lanes on consecutive 8-byte words: ds_add_u64 without
+// return, no bank conflict, nothing to wait for — and the 64 lanes of a slot are added up once per flush (ndt_flush) instead of once per tile.
+// The chunk q (|q| < 2^49) arrives as the double 1.5 * 2^52 + q, whose bit pattern is 0x4338000000000000 + q: the constant's low word is zero, so
+// ONE 32-bit subtraction on the high word leaves q in two's complement.  Integer addition is associative: the totals are the ones the per-tile
+// cross-lane reduction of rounds 2-3 produced (25/27-bit digits through v_permlane32_swap / v_permlane16_swap / DPP: 31 vector instructions per sum
+// and tile, 38 % of the kernel's; now 8 + two LDS atomics).  A slot takes at most kNdtFlushTiles tiles x 4 waves between flushes: |sum| < 2^56.
+constexpr int kNdtFlushTiles = 32;  // a block's totals of one flush stay below 2^(49 + 5 + 8) = 2^62
+constexpr unsigned long long kNdtMagicBits = 0x4338000000000000ull;
+#ifndef HGS_OPAQUE_VGPR64  // (the host emulation supplies its own spelling)
+#define HGS_OPAQUE_VGPR64(x) asm volatile("" : "+v"(x))
+#endif
+// The slots receive the RAW bit patterns (magic constant included): every slot of the table gets exactly one addition per wave and tile,
+// so the flush takes 64 * (number of wave-tile additions) * 0x4338000000000000 off a slot's lane sum, modulo 2^64, instead of every lane
+// subtracting it from every chunk.  The magic constant stays in a vector register pair the compiler cannot see through and the three powers
+// of two in scalar pairs: a split is v_fma_f64, v_add_f64, v_fma_f64, v_fma_f64 and a compare (the literal-operand v_fmac_f64 the compiler
+// prefers needs its 64-bit addend copied into the destination first: two v_mov per fma).
 template <int K0, int K1>
-__device__ __forceinline__ bool ndt_reduce_sums(const double (&acc)[kAccNdt], unsigned long long* tot_wave, int lane) {
+__device__ __forceinline__ bool ndt_reduce_class(const double (&acc)[kAccNdt], unsigned long long (*slots)[64], int lane, double magic) {
+  HGS_FP_STRICT
   bool bad = false;
+  if (K0 < K1) {
+    // the accumulators [K0, K1) share one exponent: its three powers of two and the range bound, once, as scalars
+    const int E = ndt_sum_exponent(K0);
+    const double s0 = HGS_NDT_EXP_COEFF(ldexp(1.0, -(E + kNdtChunkBits))), S0 = HGS_NDT_EXP_COEFF(ldexp(1.0, E + kNdtChunkBits)), s1 = HGS_NDT_EXP_COEFF(ldexp(1.0, -E));
+    const double bound = HGS_NDT_EXP_COEFF(ldexp(1.0, E + 2 * kNdtChunkBits - 1));
 #pragma unroll
-  for (int k0 = K0; k0 < K1; k0 += 4) {
-    // four accumulators side by side: their dependent DPP chains fill each other's wait states
-    unsigned z[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int k = k0 + j < kAccNdt ? k0 + j : kAccNdt - 1;
-      double m0, m1;
-      if (!ndt_exact_split(acc[k], ndt_sum_exponent(k), &m0, &m1)) bad = true;
-      const unsigned long long b0 = (unsigned long long)__double_as_longlong(m0), b1 = (unsigned long long)__double_as_longlong(m1);
-      z[j] = wave_rows4_u32((unsigned)b0 & 0x1ffffffu, (unsigned)(b0 >> 25) & 0x7ffffffu, (unsigned)b1 & 0x1ffffffu, (unsigned)(b1 >> 25) & 0x7ffffffu);
-    }
-    // row_shr:1, 2, 4, 8: lane 15 of each 16-lane row ends up with the row's sum
-#pragma unroll
-    for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x111, 0xf, 0xf, true);
-#pragma unroll
-    for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x112, 0xf, 0xf, true);
-#pragma unroll
-    for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x114, 0xf, 0xf, true);
-#pragma unroll
-    for (int j = 0; j < 4; j++) z[j] += __builtin_amdgcn_update_dpp(0u, z[j], 0x118, 0xf, 0xf, true);
-    if ((lane & 15) == 15) {  // rows: chunk0 low, chunk1 low, chunk0 high, chunk1 high
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (k0 + j < kAccNdt) tot_wave[(k0 + j) * 4 + (lane >> 4)] += lane < 32 ? (unsigned long long)z[j] : (unsigned long long)(long long)(int)z[j];
+    for (int k = K0; k < K1; k++) {
+      const double t = acc[k];
+      const double a = fma(t, s0, magic);  // ndt_exact_split, operation for operation
+      const double q0 = a - magic;
+      const double r = fma(-q0, S0, t);
+      const double m1 = fma(r, s1, magic);
+      if (!(fabs(t) < bound)) bad = true;
+      atomicAdd(&slots[2 * k][lane], (unsigned long long)__double_as_longlong(a));
+      atomicAdd(&slots[2 * k + 1][lane], (unsigned long long)__double_as_longlong(m1));
     }
   }
+  return bad;
+}
+template <int K0, int K1>
+__device__ __forceinline__ bool ndt_reduce_sums(const double (&acc)[kAccNdt], unsigned long long (*slots)[64], int lane) {
+  double magic = kNdtMagic;
+  HGS_OPAQUE_VGPR64(magic);
+  constexpr int H1 = K1 < 36 ? K1 : 36, G0 = K0 > 36 ? K0 : 36, G1 = K1 < 42 ? K1 : 42, S0 = K0 > 42 ? K0 : 42;  // Hessian | gradient | score
+  bool bad = ndt_reduce_class<K0, H1>(acc, slots, lane, magic);
+  if (ndt_reduce_class<G0, G1>(acc, slots, lane, magic)) bad = true;
+  if (ndt_reduce_class<S0, K1>(acc, slots, lane, magic)) bad = true;
   return bad;
 }
 
 struct NdtPassShared {
   NdtAngles ang;
-  unsigned long long tot[kBlock / 64][kAccNdt * 4];  // per wave: digit sums of the tiles since the last flush
+  unsigned long long slots[kAccNdt * 2][64];         // [accumulator * 2 + chunk][lane]: integer chunk sums of the tiles since the last flush (43 KB)
+  unsigned long long part[kAccNdt * 2][4];           // flush: a slot's four 16-lane partial sums
+  unsigned adds;                                     // wave-tile additions since the last flush (each put one magic constant into every lane of every slot)
   unsigned long long w[kAccNdt * 4 + 4];             // finish: the problem's totals (+ ticket, overflow)
   double acc[kAccNdt];
   double svd[72];
-  unsigned long long next;
-  int next_chunk, last, out_of_range;
+  int next, next_chunk, last, out_of_range;
   // copies of the kernel arguments the out-of-line helpers need: passing them by reference put them into scratch memory
   NdtConsts consts;
   Progress prog;
@@ -1258,14 +1260,34 @@ __device__ __noinline__ void ndt_finish_problem(NdtPassShared& S, NdtAccum& A, N
 __device__ __noinline__ bool ndt_flush(NdtPassShared& S, NdtAccum& A, int tiles, int tiles_total) {
   const int t = (int)threadIdx.x;
   __syncthreads();
-  if (t < kAccNdt * 4) {
-    unsigned long long v = 0;
+  // 86 slots x 64 lanes -> 86 signed totals: thread (slot, quarter) adds 16 lanes (rotated by the slot so that the 64 threads of a wave read 64
+  // different lanes' words), clears them, and the four quarters meet in S.part
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; w++) v += S.tot[w][t], S.tot[w][t] = 0;
+  for (int s0 = 0; s0 < kAccNdt * 2; s0 += kBlock / 4) {
+    const int s = s0 + (t >> 2), qd = t & 3;
+    if (s < kAccNdt * 2) {
+      unsigned long long v = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int l = qd * 16 + ((j + (t >> 2)) & 15);
+        v += S.slots[s][l], S.slots[s][l] = 0;
+      }
+      S.part[s][qd] = v;
+    }
+  }
+  __syncthreads();
+  if (t < kAccNdt * 4) {
+    // the HBM totals keep the digit format of rounds 2-3 (a problem's chunk sum can exceed 64 bits): total = high * 2^25 + low, high signed
+    const int k = t >> 2, r = t & 3;  // r: chunk0 low, chunk1 low, chunk0 high, chunk1 high
+    const long long tot = (long long)((S.part[2 * k + (r & 1)][0] + S.part[2 * k + (r & 1)][1]) + (S.part[2 * k + (r & 1)][2] + S.part[2 * k + (r & 1)][3]) -
+                                      (unsigned long long)S.adds * (kNdtMagicBits << 6));
+    const unsigned long long v = r < 2 ? (unsigned long long)(tot & 0x1ffffffll) : (unsigned long long)(tot >> 25);
     if (v) atomicAdd(&A.w[t], v);
   } else if (t == kAccNdt * 4 + 1) {
     if (S.out_of_range) atomicOr(&A.overflow, 1u), S.out_of_range = 0;
   }
+  __syncthreads();  // S.adds has been read
+  if (t == 0) S.adds = 0;
   // The ticket below must not overtake the additions above.  Everything involved is a device-scope atomic read-modify-write
   // (performed at the coherence point, never cached), so it is enough that this thread's have been acknowledged before the
   // barrier: no __threadfence() here — on gfx950 its L2 write-back + invalidate would throw the cell table out of the
@@ -1283,20 +1305,22 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
                                                          int parity, int chunk, int sorted, int debug, Progress prog) {
   __shared__ NdtPassShared S;
   const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-  for (int k = threadIdx.x; k < (kBlock / 64) * kAccNdt * 4; k += kBlock) (&S.tot[0][0])[k] = 0;
+  for (int k = threadIdx.x; k < kAccNdt * 2 * 64; k += kBlock) (&S.slots[0][0])[k] = 0;
   // two queue heads used alternately: this pass counts on queues[parity] from 0 and zeroes the other one for the next pass
   // (which starts after this kernel has ended, and the pass before, which used it, has)
   unsigned long long* queue = queues + parity;
   if (blockIdx.x == 0 && threadIdx.x == 0) queues[parity ^ 1] = 0ull;
-  const unsigned long long base = 0ull, end = (unsigned long long)tile_base[B];
+  // the pass's items (tiles of all problems): a scalar, and the item arithmetic below in 32 bits — 64-bit compares have no scalar form and kept a
+  // VGPR pair alive (and spilled) through the whole pass.  The host bounds the count (launch_ndt_pass) so that head + blocks * chunk fits.
+  const int n_items = __builtin_amdgcn_readfirstlane(tile_base[B]);
   // Guided self-scheduling: a grab takes (items left) / (2 * blocks) items, between 1 and `chunk` — long runs of one problem's
   // tiles while there is plenty of work (every change of problem costs a flush: ~170 atomics and a ticket round trip), single
   // tiles at the end of the pass (when the blocks must finish together).  "Items left" is judged from this block's last grab.
   // The first run of every block is static (block x starts at item x * first_chunk): no atomic round trip in front of the
   // first tile; the queue head counts from gridDim.x * first_chunk on.
-  const int first_chunk = max(1, min(chunk, tile_base[B] / (2 * (int)gridDim.x)));
-  const unsigned long long static_items = (unsigned long long)gridDim.x * (unsigned long long)first_chunk;
-  if (threadIdx.x == 0) S.out_of_range = 0, S.next = (unsigned long long)blockIdx.x * (unsigned long long)first_chunk, S.next_chunk = first_chunk, S.consts = c, S.prog = prog, S.debug = debug;
+  const int first_chunk = max(1, min(chunk, n_items / (2 * (int)gridDim.x)));
+  const int static_items = (int)gridDim.x * first_chunk;
+  if (threadIdx.x == 0) S.out_of_range = 0, S.adds = 0, S.next = (int)blockIdx.x * first_chunk, S.next_chunk = first_chunk, S.consts = c, S.prog = prog, S.debug = debug;
   __syncthreads();
   const CloudMeta* m = tgt.meta;
   const NdtGridBox box = {m->ndt_min_b[0], m->ndt_min_b[1], m->ndt_min_b[2], m->ndt_max_b[0], m->ndt_max_b[1], m->ndt_max_b[2], m->ndt_div_mul[1], m->ndt_div_mul[2]};
@@ -1312,17 +1336,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
   bool staged = false;
   int cur_b = -1, cur_active = 0, cur_tiles = 0, cur_n = 0, cur_first = 0, cur_end = 0;  // block-uniform: the problem being worked on
   CloudDesc d{};
-  unsigned long long w = S.next;
-  while (w < end) {
+  int w = S.next;
+  while (w < n_items) {
     __syncthreads();  // everybody has read S.next
-    unsigned long long nxt = 0;
+    int nxt = 0;
     const int my_chunk = S.next_chunk;
-    const long long left = (long long)(end - w) - my_chunk;
-    const int nxt_chunk = (int)max(1ll, min((long long)chunk, left / (2 * (long long)gridDim.x)));
-    if (threadIdx.x == 0) nxt = static_items + atomicAdd(queue, (unsigned long long)nxt_chunk);  // the next grab is in flight during this chunk
-    const unsigned long long lo = w < base ? base : w, hi = w + (unsigned long long)my_chunk < end ? w + (unsigned long long)my_chunk : end;
-    for (unsigned long long it = lo; it < hi; it++) {
-      const int item = (int)(it - base);
+    const int left = n_items - w - my_chunk;
+    const int nxt_chunk = max(1, min(chunk, left / (2 * (int)gridDim.x)));
+    if (threadIdx.x == 0) nxt = (int)min((unsigned long long)n_items, (unsigned long long)static_items + atomicAdd(queue, (unsigned long long)nxt_chunk));  // the next grab is in flight during this chunk
+    const int hi = min(w + my_chunk, n_items);
+    for (int it = w; it < hi; it++) {
+      const int item = it;
       if (item < cur_first || item >= cur_end) {
         // another problem: hand in what was gathered for the previous one, then look the new one up
         if (cur_b >= 0 && cur_active && ndt_flush(S, accum[cur_b], cur_tiles, tile_base[cur_b + 1] - tile_base[cur_b]))
@@ -1346,6 +1370,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
       if (!cur_active) {  // finished in an earlier round: its first item carries the round's progress tick
         if (item == cur_first && threadIdx.x == 0 && !debug) progress_tick(prog, false);
         continue;
+      }
+      if (cur_tiles >= kNdtFlushTiles) {  // keeps the LDS slots' integer sums in range (a long run of one problem's tiles: one cloud on few blocks)
+        ndt_flush(S, accum[cur_b], cur_tiles, tile_base[cur_b + 1] - tile_base[cur_b]);  // cannot complete the problem: this tile is still to come
+        cur_tiles = 0;
       }
       cur_tiles++;
       const int tile = item - cur_first;
@@ -1395,10 +1423,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
       // the staged load, instead of where the compiler would put the wait — behind it, which made the load synchronous)
       HGS_WAIT_VMEM_TRACKED();
       if (stage_next) ndt_front_load(fx, fhave, d, sorted, (tile + 1) * kBlock + (int)threadIdx.x, cur_n);
-      if (any_cell) bad = ndt_reduce_sums<0, 20>(acc, S.tot[wave], lane);
+      if (any_cell) {
+        if (lane == 0) atomicAdd(&S.adds, 1u);
+        bad = ndt_reduce_sums<0, 20>(acc, S.slots, lane);
+      }
       if (stage_next) ndt_front_issue_probes<NOFF>(fx, fhave, fxt, fkv, ap, tgt, box, c.search, sorted);
       if (any_cell) {
-        if (ndt_reduce_sums<20, kAccNdt>(acc, S.tot[wave], lane)) bad = true;
+        if (ndt_reduce_sums<20, kAccNdt>(acc, S.slots, lane)) bad = true;
         if (__ballot(bad) != 0ull && lane == 0) S.out_of_range = 1;
       }
       if (stage_next) ndt_front_resolve<NOFF>(fxt, fhave, fkv, fci, fvmask, tgt, box, c.search);

@@ -14,6 +14,7 @@
 #define HGS_SIMT_EMULATION 1
 #define HGS_OPAQUE_POINTER(p) asm volatile("" : "+r"(p))
 #define HGS_WAIT_VMEM() ((void)0)
+#define HGS_OPAQUE_VGPR64(x) ((void)0)
 #define HGS_LOAD_GLOBAL_XYZ(p) make_float4((p)->x, (p)->y, (p)->z, 0.f)
 #define HGS_OPAQUE_OFFSET(off) asm volatile("" : "+r"(off))
 #define HGS_WAIT_VMEM_TRACKED() ((void)0)
