@@ -63,6 +63,11 @@ public:
 
   // ---- setters the factory calls (registrations.cpp:30-34,41-44,51-55,107-119). They must precede the first cloud.
   void setNumThreads(int) {}  // reg_num_threads has no meaning on the device
+  // extension: the GPU this engine runs on (the constructor's device_id); the clouds already set follow it to the new device
+  void setDevice(int device_id) {
+    params_.device_id = device_id;
+    recreate();
+  }
   void setTransformationEpsilon(double eps) { params_.transformation_epsilon = eps; Base::setTransformationEpsilon(eps); recreate(); }
   void setMaximumIterations(int n) { params_.max_iterations = n; Base::setMaximumIterations(n); recreate(); }
   void setMaxCorrespondenceDistance(double d) { params_.max_correspondence_distance = d; Base::setMaxCorrespondenceDistance(d); recreate(); }
@@ -79,12 +84,22 @@ public:
   void setInputSource(const PointCloudSourceConstPtr& cloud) override {
     if (cloud == this->input_ && handle_) return;  // fast_gicp: same pointer -> keep the cached structures
     Base::setInputSource(cloud);
-    check(hgs_set_source(handle(), cloud->points.data(), cloud->points.size(), sizeof(PointSource)), "hgs_set_source");
+    const bool fresh = !handle_;  // a handle created by this call has uploaded the clouds pcl::Registration holds, this one included
+    if (hgs_handle* hh = handle()) {
+      if (!fresh) check(hgs_set_source(hh, cloud->points.data(), cloud->points.size(), sizeof(PointSource)), "hgs_set_source");
+    } else {
+      check(HGS_ERR_NO_DEVICE, "hgs_set_source");
+    }
   }
   void setInputTarget(const PointCloudTargetConstPtr& cloud) override {
     if (cloud == this->target_ && handle_) return;
     Base::setInputTarget(cloud);
-    check(hgs_set_target(handle(), cloud->points.data(), cloud->points.size(), sizeof(PointTarget)), "hgs_set_target");
+    const bool fresh = !handle_;
+    if (hgs_handle* hh = handle()) {
+      if (!fresh) check(hgs_set_target(hh, cloud->points.data(), cloud->points.size(), sizeof(PointTarget)), "hgs_set_target");
+    } else {
+      check(HGS_ERR_NO_DEVICE, "hgs_set_target");
+    }
   }
 
   // ---- device versions of the two non-virtual queries the callers use
@@ -128,19 +143,25 @@ private:
   // ends with hasConverged() == false and the guess as the final transformation — the failure signal the callers test
   // (apps/scan_matching_odometry_nodelet.cpp:214, include/hdl_graph_slam/loop_detector.hpp:147).  Creation is retried on the
   // next call.
+  // A (re)created engine holds no clouds: the ones pcl::Registration already has (set while creation was failing, or before a parameter
+  // change) are uploaded right away — otherwise a keyframe set during one transient failure would be lost for good, because a repeated
+  // setInputTarget with the same pointer returns early and scan_matching_odometry only replaces the keyframe after a successful match.
   hgs_handle* handle() {
-    if (!handle_ && hgs_create(&params_, &handle_) != HGS_OK) {
+    if (handle_) return handle_;
+    if (hgs_create(&params_, &handle_) != HGS_OK) {
       PCL_ERROR("[%s] hgs_create failed: %s\n", this->reg_name_.c_str(), hgs_last_error(nullptr));
       handle_ = nullptr;
+      return nullptr;
     }
+    if (this->target_) check(hgs_set_target(handle_, this->target_->points.data(), this->target_->points.size(), sizeof(PointTarget)), "hgs_set_target");
+    if (this->input_) check(hgs_set_source(handle_, this->input_->points.data(), this->input_->points.size(), sizeof(PointSource)), "hgs_set_source");
     return handle_;
   }
-  void recreate() {  // parameters are fixed at creation: drop the engine; clouds are re-uploaded on the next set*
+  void recreate() {  // parameters are fixed at creation: drop the engine; handle() uploads the current clouds into the new one
     if (!handle_) return;
     hgs_destroy(handle_);
     handle_ = nullptr;
-    if (this->target_) check(hgs_set_target(handle(), this->target_->points.data(), this->target_->points.size(), sizeof(PointTarget)), "hgs_set_target");
-    if (this->input_) check(hgs_set_source(handle(), this->input_->points.data(), this->input_->points.size(), sizeof(PointSource)), "hgs_set_source");
+    (void)handle();
   }
   void check(int rc, const char* what) {
     if (rc != HGS_OK) PCL_ERROR("[%s] %s failed (%d): %s\n", this->reg_name_.c_str(), what, rc, hgs_last_error(handle_));

@@ -20,15 +20,27 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the MI355X backend cannot be built")
 
 
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(_HERE, "..", "include", "hgs_registration.h")]
+
+
+def _obj_stale(src: str) -> bool:
+    """An object is stale when it is older than ITS source or any header (not than the other .hip files: an edit to one
+    source must not make the untouched objects look stale for ever)."""
+    obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, src)] + _headers())
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
-    objs = [os.path.join(LIB_DIR, src.replace(".hip", ".o")) for src in SOURCES]
-    if not all(os.path.exists(o) for o in objs):
+    if any(_obj_stale(src) for src in SOURCES):
         return True
-    t = min([os.path.getmtime(LIB_PATH)] + [os.path.getmtime(o) for o in objs])   # the oldest object decides: a relink alone is not a rebuild
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "hgs_registration.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(LIB_DIR, src.replace(".hip", ".o"))) > t for src in SOURCES)
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
@@ -39,19 +51,25 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        src_path = os.path.join(CSRC, src)
-        deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f == src] + [os.path.join(_HERE, "..", "include", "hgs_registration.h")]
-        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
-            cmd = [hipcc, *FLAGS, "-c", src_path, "-o", obj]
+        if force or _obj_stale(src):
+            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
         objs.append(obj)
-    # no -lrccl: hgs_comm.hip loads RCCL with dlopen at the first hgs_comm_* call, the registration path does not depend on it
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-ldl"]
+    # no -lrccl: hgs_comm.hip loads RCCL with dlopen at the first hgs_comm_* call, the registration path does not depend on it.
+    # Linked next to the target and renamed into place: a process that has the old library mapped keeps its (unlinked) file, and
+    # ranks / tests that start together never see a half-written one.
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 

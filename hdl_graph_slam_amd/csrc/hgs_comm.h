@@ -17,6 +17,9 @@ int comm_create(Comm** out, int rank, int world, const void* id /* kCommUniqueId
 void comm_destroy(Comm* c);
 // tears the communicator down unilaterally: the peers' pending / future collectives on it fail instead of blocking
 void comm_abort(Comm* c);
+// non-zero (and `err` filled) when the communicator has been aborted or reports an asynchronous error (ncclCommGetAsyncError): polled by a rank
+// that waits behind a collective, because a peer's abort is not guaranteed to end this rank's own all-gather kernel
+int comm_async_error(Comm* c, char* err, size_t err_cap);
 int comm_rank(const Comm* c);
 int comm_world(const Comm* c);
 // recv[r * bytes_per_rank ...] <- rank r's send[0 .. bytes_per_rank), device pointers, asynchronous on `stream`

@@ -35,6 +35,7 @@ struct Rccl {
   decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional: older libraries without it are only covered by the deadline
   char why[256] = "";
 };
 
@@ -62,6 +63,7 @@ const Rccl* rccl(char* err, size_t cap) {
     table.CommAbort = reinterpret_cast<decltype(table.CommAbort)>(dlsym(table.lib, "ncclCommAbort"));
     table.AllGather = reinterpret_cast<decltype(table.AllGather)>(dlsym(table.lib, "ncclAllGather"));
     table.GetErrorString = reinterpret_cast<decltype(table.GetErrorString)>(dlsym(table.lib, "ncclGetErrorString"));
+    table.CommGetAsyncError = reinterpret_cast<decltype(table.CommGetAsyncError)>(dlsym(table.lib, "ncclCommGetAsyncError"));
     if (!table.GetUniqueId || !table.CommInitRank || !table.CommDestroy || !table.CommAbort || !table.AllGather || !table.GetErrorString) {
       snprintf(table.why, sizeof(table.why), "librccl.so lacks an expected ncclXxx symbol");
       table.lib = nullptr;
@@ -126,6 +128,20 @@ void comm_abort(Comm* c) {
   const Rccl* R = rccl(nullptr, 0);
   if (c->comm && R) (void)R->CommAbort(c->comm);
   c->comm = nullptr;
+}
+
+int comm_async_error(Comm* c, char* err, size_t err_cap) {
+  if (!c || !c->comm) {
+    if (err && err_cap) snprintf(err, err_cap, "the communicator has been aborted");
+    return 1;
+  }
+  const Rccl* R = rccl(nullptr, 0);
+  if (!R || !R->CommGetAsyncError) return 0;
+  ncclResult_t async = ncclSuccess;
+  const ncclResult_t r = R->CommGetAsyncError(c->comm, &async);
+  if (r != ncclSuccess) return fail(R, r, "ncclCommGetAsyncError", err, err_cap);
+  if (async != ncclSuccess && async != ncclInProgress) return fail(R, async, "a collective on this communicator", err, err_cap);
+  return 0;
 }
 
 int comm_rank(const Comm* c) { return c->rank; }

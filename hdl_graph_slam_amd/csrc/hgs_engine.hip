@@ -10,14 +10,18 @@
 // HBM, so there is no per-iteration host decision — the host only polls a done-counter.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <limits>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hgs_registration.h"
@@ -347,7 +351,7 @@ int ensure_index(hgs_handle* h, const std::vector<hgs_cloud*>& all) {
     size_t total = 0;
     for (hgs_cloud* c : chunk) c->desc.pad = c->corr_stale ? 1 : 0;  // read by k_gather_sorted
     HGS_TRY(upload_descs(h, chunk, true, &d_descs, &total));
-    for (hgs_cloud* c : chunk) c->desc.pad = 0, c->corr_stale = false;
+    for (hgs_cloud* c : chunk) c->desc.pad = 0;  // (corr_stale is cleared where has_index is set: a failure below must not lose the invalidate request)
     int max_n = 0, max_P = 1;
     for (hgs_cloud* c : chunk) max_n = std::max(max_n, (int)c->n_input), max_P = std::max(max_P, c->P);
     const int nc = (int)chunk.size();
@@ -381,7 +385,7 @@ int ensure_index(hgs_handle* h, const std::vector<hgs_cloud*>& all) {
     // descs buffer is reused by later stages: make sure this chunk's kernels were enqueued before it is overwritten
     // (stream order guarantees that; the pinned staging copy needs the H2D to have completed)
     HGS_HIP(h, hipStreamSynchronize(h->stream));
-    for (hgs_cloud* c : chunk) c->has_index = true;
+    for (hgs_cloud* c : chunk) c->has_index = true, c->corr_stale = false;
   }
   return HGS_OK;
 }
@@ -1407,6 +1411,69 @@ int hgs_debug_merge_shard_records(const hgs_result* gathered, const int32_t* cou
   return status_of_current_exception(nullptr);
 }
 
+}  // extern "C"
+namespace {
+// Waits for something enqueued behind a collective (query = hipEventQuery / hipStreamQuery) WITHOUT an unbounded blocking call.  A rank that aborts
+// its communicator only raises its own abort flag: on the intra-node transports (P2P / xGMI / shared memory) RCCL does not promise that the peers'
+// all-gather kernel stops spinning, so hipEventSynchronize / hipStreamSynchronize behind it could wait forever.  The wait therefore polls, asks
+// the communicator for an asynchronous error (ncclCommGetAsyncError) now and then, and gives up after the deadline (HGS_COMM_TIMEOUT_MS, default
+// 60 s, 0 = none; it has to cover the skew with which the SLAM processes enter the detection, not the exchange itself, which is microseconds).
+// On error or timeout this rank aborts ITS communicator (which ends its own stuck kernel) and the call returns HGS_ERR_COMM.
+long comm_timeout_ms() {
+  if (const char* e = std::getenv("HGS_COMM_TIMEOUT_MS")) return std::max(0l, std::atol(e));
+  return 60000;
+}
+template <typename Q>
+int comm_wait(hgs_handle* h, Q&& query, const char* what) {
+  const long limit_ms = comm_timeout_ms();
+  const auto t0 = std::chrono::steady_clock::now();
+  char err[256] = "";
+  for (long spins = 0;; spins++) {
+    const hipError_t e = query();
+    if (e == hipSuccess) return HGS_OK;
+    if (e != hipErrorNotReady) {
+      h->err = std::string("hgs_loop_match_batch_sharded: HIP error while waiting for ") + what + ": " + hipGetErrorString(e);
+      hgs::comm_abort(h->comm);
+      return HGS_ERR_HIP;
+    }
+    if ((spins & 63) == 63) {
+      if (hgs::comm_async_error(h->comm, err, sizeof(err)) != 0) {
+        h->err = std::string("hgs_loop_match_batch_sharded: the communicator reported an asynchronous error while waiting for ") + what + ": " + err;
+        hgs::comm_abort(h->comm);
+        return HGS_ERR_COMM;
+      }
+      const long waited = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (limit_ms > 0 && waited > limit_ms) {
+        h->err = std::string("hgs_loop_match_batch_sharded: gave up after ") + std::to_string(waited) + " ms waiting for " + what +
+                 " (a peer has left the collective or never entered it); the communicator has been aborted";
+        hgs::comm_abort(h->comm);
+        return HGS_ERR_COMM;
+      }
+      if (spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+}
+// Between the two collectives of a sharded batch the peers already count on this rank: whatever leaves that region without having enqueued the
+// record all-gather — an exception nobody expected — must not leave them waiting for it.
+struct CommAbortGuard {
+  hgs::Comm* comm;
+  bool armed = true;
+  ~CommAbortGuard() {
+    if (armed) hgs::comm_abort(comm);
+  }
+};
+// test hook (tests/test_simt_kernels_host.py, tests/test_distributed.py; never set in production): HGS_FAULT_AFTER_HEADER = "<kind>:<rank>" makes that
+// rank fail between the two collectives — kind "batch": std::bad_alloc where run_batch runs (handled: the rank sends padding and reports after the
+// exchange); kind "guard": an exception outside every handler (the guard aborts the communicator, the peers get HGS_ERR_COMM)
+bool fault_after_header(const char* kind, int rank) {
+  const char* e = std::getenv("HGS_FAULT_AFTER_HEADER");
+  if (!e) return false;
+  const size_t n = std::strlen(kind);
+  return std::strncmp(e, kind, n) == 0 && e[n] == ':' && std::atoi(e + n + 1) == rank;
+}
+}  // namespace
+extern "C" {
+
 // Collective.  Once the arguments that are the same on every rank have been checked, EVERY path of a rank reaches both
 // collectives — a rank whose own share is unusable (no target, an invalid or duplicated candidate cloud, a failed launch)
 // announces an empty shard / sends padding and reports its error AFTER the exchange, so that a bad keyframe on one rank costs
@@ -1469,6 +1536,9 @@ int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, si
     hgs::comm_abort(h->comm);  // whatever state the peers are in, they must not wait for this rank
     return HGS_ERR_COMM;
   };
+  // everything the region between the two collectives needs is allocated HERE, in front of the first one: past this point the
+  // peers count on this rank, and the only exits are the record all-gather or an abort of the communicator
+  std::vector<int32_t> counts(world, 0), statuses(world, 0);
   // ---- 1. headers: device layout comm_send = [header | records], comm_recv = [world headers | world x per records]
   int32_t* h_hdr = static_cast<int32_t*>(h->h_comm.p);  // pinned: [my header][world gathered headers]
   h_hdr[0] = (int32_t)n_send, h_hdr[1] = local, h_hdr[2] = 0, h_hdr[3] = 0;
@@ -1476,30 +1546,49 @@ int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, si
   char* d_recv = static_cast<char*>(h->comm_recv.p);
   bool hip_ok = hipMemcpyAsync(d_send, h_hdr, hdr_bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess;
   if (hgs::comm_all_gather(h->comm, d_send, d_recv, hdr_bytes, h->stream, err, sizeof(err)) != 0) return comm_failed("header all-gather");
+  CommAbortGuard guard{h->comm};  // from here to the enqueued record all-gather
   hip_ok = hip_ok && hipMemcpyAsync(h_hdr + 4, d_recv, (size_t)world * hdr_bytes, hipMemcpyDeviceToHost, h->stream) == hipSuccess;
   if (!h->comm_event) hip_ok = hip_ok && hipEventCreateWithFlags(&h->comm_event, hipEventDisableTiming) == hipSuccess;
   hip_ok = hip_ok && hipEventRecord(h->comm_event, h->stream) == hipSuccess;
-  // ---- 2. the batch
+  if (fault_after_header("guard", rank)) throw std::runtime_error("HGS_FAULT_AFTER_HEADER=guard");
+  // ---- 2. the batch.  A C++ exception in here (std::bad_alloc of a host-side vector, ...) is this rank's own problem like any other
+  // failure of its share: it sends padding and reports after the exchange
   size_t n_valid = 0;  // records this rank really has
   if (n_send > 0 && hip_ok) {
-    const int rc = run_batch(h, src, guesses, &max_range);
-    if (rc == HGS_OK) n_valid = n_send;
-    else fail_local(rc, h->err);
+    int rc;
+    try {
+      if (fault_after_header("batch", rank)) throw std::bad_alloc();
+      rc = run_batch(h, src, guesses, &max_range);
+    } catch (...) {
+      rc = status_of_current_exception(h);
+    }
+    if (rc == HGS_OK) {
+      n_valid = n_send;
+    } else if (local == HGS_OK) {
+      local = rc;
+      try {
+        local_err = h->err;
+      } catch (...) {  // no memory for the text: the status code stands
+      }
+    }
   }
   // ---- 3. records: everybody knows everybody's shard size now
-  hip_ok = hip_ok && hipEventSynchronize(h->comm_event) == hipSuccess;
+  if (hip_ok) {
+    const int rc = comm_wait(h, [&] { return hipEventQuery(h->comm_event); }, "the gathered shard headers");
+    if (rc != HGS_OK) {
+      guard.armed = false;  // comm_wait has aborted the communicator
+      return rc;
+    }
+  }
   size_t per = 1;
-  std::vector<int32_t> counts(world, 0), statuses(world, 0);
   if (hip_ok)
     for (int r = 0; r < world; r++) {
       counts[r] = std::max(0, std::min<int32_t>(h_hdr[4 + 4 * r], (int32_t)n_total));
       statuses[r] = h_hdr[4 + 4 * r + 1];
       per = std::max(per, (size_t)counts[r]);
     }
-  else per = n_total;  // the header never arrived here: this rank cannot know `per`; it aborts below
-  if (!hip_ok) {
+  if (!hip_ok) {  // the header never arrived here: this rank cannot know `per`; the guard aborts the communicator
     h->err = std::string("hgs_loop_match_batch_sharded: HIP error around the header exchange: ") + hipGetErrorString(hipGetLastError());
-    hgs::comm_abort(h->comm);
     return HGS_ERR_HIP;
   }
   hgs_result* d_records = reinterpret_cast<hgs_result*>(d_send + hdr_bytes);
@@ -1509,11 +1598,15 @@ int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, si
   }
   launch_results_to_records(h->stream, h->results.as<DevResult>(), h->comm_ids.as<int>(), (int)n_valid, (int)per, d_records);  // padding beyond n_valid
   hgs_result* d_gathered = reinterpret_cast<hgs_result*>(d_recv + (size_t)world * hdr_bytes);
-  if (hgs::comm_all_gather(h->comm, d_records, d_gathered, per * sizeof(hgs_result), h->stream, err, sizeof(err)) != 0) return comm_failed("record all-gather");
+  if (hgs::comm_all_gather(h->comm, d_records, d_gathered, per * sizeof(hgs_result), h->stream, err, sizeof(err)) != 0) {
+    guard.armed = false;  // comm_failed aborts
+    return comm_failed("record all-gather");
+  }
+  guard.armed = false;  // both collectives are enqueued: the peers depend on nothing further from this rank
   // ---- 4. merge
   hgs_result* gathered = reinterpret_cast<hgs_result*>(static_cast<char*>(h->h_comm.p) + rec_off);
   HGS_HIP(h, hipMemcpyAsync(gathered, d_gathered, (size_t)world * per * sizeof(hgs_result), hipMemcpyDeviceToHost, h->stream));
-  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  HGS_TRY(comm_wait(h, [&] { return hipStreamQuery(h->stream); }, "the gathered records"));
   int32_t dup = -1;
   HGS_TRY(hgs_debug_merge_shard_records(gathered, counts.data(), world, per, n_total, all_out, &dup));
   if (best) HGS_TRY(hgs_select_best(all_out, n_total, best));

@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
                                                          NdtAccum* accum, const int* __restrict__ tile_base /* [B + 1] */, unsigned long long* queues /* [2] */, int B,
                                                          int parity, int chunk, int sorted, int debug, Progress prog) {
   __shared__ NdtPassShared S;
-  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63);
   for (int k = threadIdx.x; k < kAccNdt * 2 * 64; k += kBlock) (&S.slots[0][0])[k] = 0;
   // two queue heads used alternately: this pass counts on queues[parity] from 0 and zeroes the other one for the next pass
   // (which starts after this kernel has ended, and the pass before, which used it, has)

@@ -185,8 +185,14 @@ int hgs_comm_finalize(hgs_handle* h); /* also done by hgs_destroy */
  * unusable (no target, a candidate that is not a cloud of this engine, duplicated clouds, a failed launch) still takes part:
  * it contributes no records, the peers see its candidates as "not converged" (fitness DBL_MAX), and it returns its error
  * AFTER the exchange.  A candidate id reported more than once makes every rank return HGS_ERR_INVALID_ARGUMENT (first report
- * kept).  A rank that cannot allocate the exchange buffers, or whose collective fails, aborts the communicator
- * (ncclCommAbort): the peers then get HGS_ERR_COMM instead of blocking; hgs_comm_init creates a new one.
+ * kept).  A C++ exception on a rank where its batch runs is treated like any other failure of its share (padding, error
+ * after the exchange); a rank that cannot allocate the exchange buffers, whose collective call fails, or that leaves the
+ * region between the two collectives any other way aborts ITS communicator (ncclCommAbort).  RCCL does not promise that a
+ * peer's abort ends this rank's own all-gather kernel on the intra-node transports, so no rank ever waits behind a
+ * collective with a blocking synchronise: it polls the stream, asks ncclCommGetAsyncError, and after a deadline
+ * (environment HGS_COMM_TIMEOUT_MS, default 60000, 0 = none; it has to cover the skew with which the processes enter the
+ * detection) aborts its own communicator and returns HGS_ERR_COMM; hgs_comm_init creates a new one.  What has run: the
+ * two-rank paths on the emulated communicator of tests/emul; on real RCCL only world size 1.
  * Traffic: one 16-byte header per rank (shard size, status) and max(shard size) record slots per rank. */
 int hgs_loop_match_batch_sharded(hgs_handle* h, hgs_cloud* const* candidates, size_t n_mine, const int32_t* candidate_ids,
                                  const float* guesses /* 16*n_mine */, size_t n_total, double max_range, hgs_result* all_out,

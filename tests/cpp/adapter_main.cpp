@@ -28,9 +28,8 @@ int main(int argc, char** argv) {
   }
   try {
     // what the new factory branch does: construct + setters from the reg_* rosparams
-    pcl::Registration<PointT, PointT>::Ptr registration;
-    {
-      auto reg = std::make_shared<hgs_hip::RegistrationHIP<PointT, PointT>>(std::atoi(argv[1]));
+    auto make = [&](int device) {
+      auto reg = std::make_shared<hgs_hip::RegistrationHIP<PointT, PointT>>(std::atoi(argv[1]), device);
       reg->setTransformationEpsilon(0.01);
       reg->setMaximumIterations(64);
       if (std::atoi(argv[1]) == HGS_FAST_GICP) {
@@ -40,8 +39,9 @@ int main(int argc, char** argv) {
         reg->setResolution(1.0);
         reg->setNeighborhoodSearchMethod(HGS_DIRECT7);
       }
-      registration = reg;
-    }
+      return reg;
+    };
+    pcl::Registration<PointT, PointT>::Ptr registration = make(0);
     auto keyframe = load(argv[2]);
     auto filtered = load(argv[3]);
     registration->setInputTarget(keyframe);
@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
     {
       // an engine that cannot be created (device 4096 does not exist) must not throw into the caller: the nodelets test
       // hasConverged() (apps/scan_matching_odometry_nodelet.cpp:214) and expect the guess back
-      pcl::Registration<PointT, PointT>::Ptr broken = std::make_shared<hgs_hip::RegistrationHIP<PointT, PointT>>(std::atoi(argv[1]), 4096);
+      pcl::Registration<PointT, PointT>::Ptr broken = make(4096);
       broken->setInputTarget(keyframe);
       broken->setInputSource(filtered);
       pcl::PointCloud<PointT> out;
@@ -67,6 +67,18 @@ int main(int argc, char** argv) {
       broken->align(out, guess);
       const auto Tb = broken->getFinalTransformation();
       std::printf("no_device converged %d guess_kept %d\n", (int)broken->hasConverged(), (int)(Tb.data()[12] == 0.25f && Tb.data()[0] == 1.0f));
+      // ... and the failure must not be permanent: scan_matching_odometry sets the keyframe ONCE (a repeated setInputTarget with the same
+      // pointer returns early), so the engine that can finally be created has to pick up the clouds that were set while it could not
+      auto* late = dynamic_cast<hgs_hip::RegistrationHIP<PointT, PointT>*>(broken.get());
+      late->setDevice(0);
+      broken->setInputTarget(keyframe);  // same pointers as before: early returns in a naive adapter
+      broken->setInputSource(filtered);
+      pcl::PointCloud<PointT> out2;
+      broken->align(out2, pcl::MockMatrix4f::Identity());
+      const auto Tl = broken->getFinalTransformation();
+      bool same = true;
+      for (int i = 0; i < 16; i++) same = same && Tl.data()[i] == T.data()[i];
+      std::printf("recovered converged %d same_pose %d\n", (int)broken->hasConverged(), (int)same);
     }
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());

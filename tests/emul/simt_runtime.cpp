@@ -350,6 +350,12 @@ void comm_abort(Comm* c) {
   c->group->aborted = true;
   c->group->cv.notify_all();
 }
+int comm_async_error(Comm* c, char* err, size_t cap) {
+  if (!c || !c->group) return 1;
+  std::lock_guard<std::mutex> lock(c->group->m);
+  if (c->group->aborted && err && cap) snprintf(err, cap, "the communicator has been aborted");
+  return c->group->aborted ? 1 : 0;
+}
 int comm_rank(const Comm* c) { return c->rank; }
 int comm_world(const Comm* c) { return c->world; }
 int comm_all_gather(Comm* c, const void* send, void* recv, size_t bytes_per_rank, hipStream_t, char* err, size_t cap) {

@@ -52,6 +52,7 @@ def test_adapter_matches_python_mirror(tmp_path, method):
     assert np.array_equal(Tc, r.matrix())                       # same library, same inputs: identical bits
     assert abs(float(out[2].split()[1]) - reg.getFitnessScore()) < 1e-9      # printed with 12 significant digits
     assert out[4] == "no_device converged 0 guess_kept 1"              # hgs_create failure: no exception, hasConverged() false, guess kept
+    assert out[5] == "recovered converged 1 same_pose 1"                # the engine created later holds the clouds set while creation failed
     reg.close()
 
 

@@ -5,6 +5,7 @@ driven through the same C-ABI and the same Python mirror as on the GPU.  What th
 is asserted here on small clouds without one: packet walks, the two-pass k-NN with its tie rule, tile reductions, the
 on-device LM / Newton state machines including the three-lane Jacobi SVD, the batch lanes and the progress mirror of the
 host loop, prefilter and map-cloud kernels.  (Performance, and anything that depends on real concurrency, is not.)"""
+import os
 import numpy as np
 import pytest
 
@@ -287,6 +288,7 @@ def test_cpp_adapter_end_to_end(simt_library, tmp_path, method):
     assert np.array_equal(Tc, r.matrix())
     assert abs(float(out[2].split()[1]) - e.getFitnessScore()) < 1e-9
     assert out[4] == "no_device converged 0 guess_kept 1"   # an engine that cannot be created does not throw into the caller
+    assert out[5] == "recovered converged 1 same_pose 1"                # the engine created later holds the clouds set while creation failed
     if method == 0:
         dt, dr = synth.pose_error(Tc.astype(np.float64), o.align(np.eye(4)).matrix())
         assert dt < 1e-5 and dr < 1e-5
@@ -604,6 +606,44 @@ def test_sharded_batch_flags_a_candidate_two_ranks_report(simt_library):
         return rc, bool(rec["converged"].all())
     res = _two_ranks(world, body)
     assert [r[0] for r in res] == [L.HGS_ERR_INVALID_ARGUMENT] * 2 and all(r[1] for r in res)
+
+
+def _rank_fails_after_the_header(kind):
+    from hdl_graph_slam_amd import _lib as L, workloads
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    n_total, world = 4, 2
+    wl = workloads.make_loop_closure_set("VLP-16", scene_seed=4, n_candidates=n_total, n_distinct=2, downsample=0.5)
+
+    def body(rank, uid):
+        reg = select_registration_method({"registration_method": "FAST_GICP"}, device_id=0)
+        reg.setInputTarget(wl.target)
+        reg.comm_init(rank, world, uid)
+        mine = [i for i in range(n_total) if i % world == rank]
+        rec, best, rc = reg.loop_match_batch_sharded([reg.upload(wl.candidates[i]) for i in mine], mine, [wl.guesses[i] for i in mine], n_total, 4.0,
+                                                     return_status=True)
+        reg.close()
+        return rec.copy(), best, rc
+    os.environ["HGS_FAULT_AFTER_HEADER"] = f"{kind}:1"   # rank 1 fails between the header gather and the record gather
+    try:
+        return L, _two_ranks(world, body)
+    finally:
+        del os.environ["HGS_FAULT_AFTER_HEADER"]
+
+
+def test_sharded_batch_rank_that_throws_in_its_batch_after_the_header_still_sends_padding(simt_library):
+    """A C++ exception on one rank where its batch runs (the peers already know its shard size): the rank takes part in the record
+    all-gather with padding and reports after the exchange; the other rank returns HGS_OK with that rank's candidates not converged."""
+    L, ((rec0, best0, rc0), (rec1, best1, rc1)) = _rank_fails_after_the_header("batch")
+    assert rc0 == L.HGS_OK and rc1 == L.HGS_ERR_OUT_OF_MEMORY
+    assert rec0.tobytes() == rec1.tobytes() and best0 == best1
+    assert rec0["converged"][0::2].all() and not rec0["converged"][1::2].any() and best0 in (0, 2)
+
+
+def test_sharded_batch_rank_that_leaves_between_the_collectives_aborts_the_communicator(simt_library):
+    """An exception outside every handler between the two collectives: the scope guard aborts the communicator, nobody blocks (the
+    thread join of _two_ranks), the peer's collective fails with HGS_ERR_COMM instead of waiting for records that never come."""
+    L, ((_, _, rc0), (_, _, rc1)) = _rank_fails_after_the_header("guard")
+    assert rc0 == L.HGS_ERR_COMM and rc1 == L.HGS_ERR_INTERNAL
 
 
 def test_nn1_with_equidistant_target_points(simt_library):
