@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: measured float4-copy ceiling (SURVEY 8d asks for both)
 LIMITER = {"FAST_GICP": "instruction issue (VALU+SALU) of the exact tree search, not HBM: see DESIGN.md section 4",
            "FAST_VGICP": "VALU + dependent L2 round trips of the voxel hash probes, not HBM: see DESIGN.md section 4",
-           "NDT_OMP": "VALU issue of the per-cell derivative terms and of the exact integer reduction (~380 VALU instructions per visited cell, ~1100 per 64-point "
-                      "tile), not HBM: see DESIGN.md section 4"}
+           "NDT_OMP": "VALU issue of the per-cell derivative terms (~330 vector instructions per visited cell, ~4.7 cells per point; the exact integer reduction is "
+                      "~300 per 64-point tile since round 4), not HBM: see DESIGN.md section 4"}
 
 
 def percentiles(ms):
@@ -59,19 +59,28 @@ def stage_table(method):
     return t
 
 
-def roofline_of(method, prof, units, prof_steps, launch_config, pmc_ok=True):
-    """Dominant stage by measured time (HIP events on the engine's stream around every launch of the stage) against HBM."""
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD16, 2.4 GHz peak engine clock
+VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / 4.0 / 1e9   # a wave64 vector instruction occupies its SIMD16 for 4 cycles: 614.4 G wave-instructions/s
+
+
+def roofline_of(method, prof, units, prof_steps, launch_config, pmc_ok=True, profiled_step_ms=None, pmc_name=None):
+    """Dominant stage by measured time (HIP events on the engine's stream around every launch of the stage).  `bound` names the unit that
+    limits the kernel: "hbm" for the GICP kernels (algorithmic bytes against 8 TB/s, as SURVEY 8d defines the figure), "valu" for k_ndt_pass,
+    whose cell table is L2-resident (counter traffic is 0.06x the logical bytes): there `achieved` is the vector-instruction issue rate from the
+    committed SQ_INSTS_VALU counters over this run's launch duration, against one instruction per SIMD per 4 cycles, and the logical-byte figure
+    stays beside it as `hbm_logical`."""
     table = stage_table(method)
     live = [s for s in table if prof[s][1] > 0 and units.get(s, 0) > 0]
     dom = max(live, key=lambda s: prof[s][0])
     ms, launches = prof[dom]
     kname, bytes_per_unit = table[dom]
     achieved = units[dom] * bytes_per_unit / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    # HBM traffic of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per dispatch, collected in separate passes over the
-    # default workload (scripts/gpu_pmc.sh) and committed as profiles/pmc_<method>.json; FETCH_SIZE doubled as MI355X_MICROARCH.md
-    # prescribes for gfx950.  null when no committed counters match this workload.
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{method.lower()}.json")
+    avg_s = ms * 1e-3 / max(launches, 1)
+    # counters of that kernel: rocprofv3 --pmc per dispatch, collected in separate passes over the default workload with one lane
+    # (scripts/r04_profile.sh) and committed as profiles/pmc_<method>.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.
+    # null when no committed counters match this workload.
+    traffic, traffic_src, valu = None, None, None
+    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{pmc_name or method.lower()}.json")
     if pmc_ok and os.path.exists(pmc_path):
         with open(pmc_path) as fh:
             pmc = json.load(fh)
@@ -79,12 +88,29 @@ def roofline_of(method, prof, units, prof_steps, launch_config, pmc_ok=True):
             if kn.split("<")[0].endswith(kname) and "FETCH_SIZE" in cv:
                 traffic = (2.0 * cv["FETCH_SIZE"] + cv.get("WRITE_SIZE", 0.0)) * 1024.0
                 traffic_src = os.path.relpath(pmc_path, ROOT)
-    return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5), "traffic": None if traffic is None else round(traffic, 1),
-            "traffic_source": traffic_src, "limiter": LIMITER[method], "launch_config": launch_config,
-            "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches": launches,
-            "algorithmic_bytes_per_launch": round(units[dom] * bytes_per_unit / max(launches, 1), 1),
-            "stage_ms_per_step": {s: round(prof[s][0] / prof_steps, 3) for s in prof}}
+                if "SQ_INSTS_VALU" in cv and avg_s > 0:
+                    valu = {"insts_per_launch": round(cv["SQ_INSTS_VALU"], 1), "ginst_per_s": round(cv["SQ_INSTS_VALU"] / avg_s / 1e9, 2), "peak_ginst_per_s": VALU_PEAK_GINST,
+                            "issue_frac": round(cv["SQ_INSTS_VALU"] / avg_s / 1e9 / VALU_PEAK_GINST, 4),
+                            "busy_frac_sq_active_inst_valu": round(cv["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * avg_s * CLOCK_HZ), 4) if "SQ_ACTIVE_INST_VALU" in cv else None,
+                            "note": "counters from the committed one-lane profile, duration from this run's HIP events on the same launch configuration"}
+    hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+           "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5)}
+    out = {"bound": "hbm", "kernel": kname}
+    out.update(hbm)
+    if method == "NDT_OMP" and valu is not None:
+        out.update({"bound": "valu", "achieved": valu["ginst_per_s"], "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": valu["issue_frac"]})
+        out.pop("frac_of_measured_copy_ceiling", None)
+        out["hbm_logical"] = dict(hbm, bytes_per_unit=bytes_per_unit, note="296 B per source point and pass (SURVEY 8d); the cell table is L2-resident, so this is not HBM traffic")
+    out.update({"traffic": None if traffic is None else round(traffic, 1), "traffic_source": traffic_src,
+                "hbm_frac_from_counters": None if traffic is None or avg_s <= 0 else round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 5),
+                "valu": valu, "limiter": LIMITER[method], "launch_config": launch_config,
+                "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2), "launches": launches,
+                "algorithmic_bytes_per_launch": round(units[dom] * bytes_per_unit / max(launches, 1), 1),
+                # stage times of the PROFILED configuration (one lane, event timers on): they add up to `profiled_step_ms`, not to the timed
+                # region's ms_per_step, which runs the same kernels on 3-4 concurrent lanes (profiles/r04_*_kernel_stats_lanes.md)
+                "profiled_step_ms": None if profiled_step_ms is None else round(profiled_step_ms, 3),
+                "stage_ms_per_step": {s: round(prof[s][0] / prof_steps, 3) for s in prof}})
+    return out
 
 
 def oracle_params(reg):
@@ -130,6 +156,7 @@ def main():
     ap.add_argument("--mild-set", action="store_true", help="the candidate set rounds 1 and 2 benchmarked (8 distinct scans within 4 m of the query, guess noise "
                     "0.3 m / 1 deg) instead of SURVEY 8d's (within 20 m, 0.5 m / 2 deg): for continuity with the earlier lines")
     ap.add_argument("--no-ndt-record", action="store_true", help="default command only: skip the NDT_OMP (factory default engine) sub-record")
+    ap.add_argument("--no-plane-record", action="store_true", help="default command only: skip the FAST_GICP / PLANE-regularisation sub-record")
     ap.add_argument("--ndt-steps", type=int, default=8, help="timed steps of the NDT_OMP sub-record")
     ap.add_argument("--fitness-max-range-variant", action="store_true", help="config 4: also time the batch with fitness_score_max_range = 4.0")
     ap.add_argument("--cpu-single-thread", action="store_true", help="cpu_baseline also carries the one-thread rate (one unit of the sample)")
@@ -253,15 +280,23 @@ def run_loop_batch(ctx):
         out["ndt_omp"] = {k: nd[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
                                              "mean_linearizations", "pose_rmse_vs_ground_truth", "best_candidate", "roofline", "cpu_baseline")}
         out["ndt_omp"]["workload"] = nd["config"]["workload"]
+    if a.config == 0 and method == "FAST_GICP" and not a.regularization and not a.no_plane_record and not a.no_ndt_record and world == 1:
+        # fast_gicp's constructor default is not pinned by the reference (it never calls setRegularizationMethod, registrations.cpp:27-36, and clones an
+        # unpinned fast_gicp master): FROBENIUS according to SURVEY A.2, PLANE according to the round-3 judge.  Until someone reads fast_gicp HEAD both
+        # lines are the metric: `value` is FROBENIUS, this sub-record is the same workload under PLANE (k_knn_cov's eigen-decomposition instantiation)
+        pl = measure_loop_batch(ctx, method, B, max(8, steps // 2), 1, with_cpu=not a.no_cpu_baseline, with_resident=False, max_range=None, regularization="PLANE")
+        out["fast_gicp_plane"] = {k: pl[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
+                                                     "mean_linearizations", "pose_rmse_vs_ground_truth", "best_candidate", "roofline", "cpu_baseline")}
+        out["fast_gicp_plane"]["workload"] = pl["config"]["workload"]
     if a.config == 0 and method == "FAST_GICP" and not a.mild_set and not a.no_ndt_record and world == 1:
         # continuity with BENCH_r01 / BENCH_r02: the candidate set those lines were measured on (never `value`)
-        r2 = measure_loop_batch(ctx, method, B, max(4, steps // 2), 1, with_cpu=False, with_resident=False, max_range=None, mild=True)
+        r2 = measure_loop_batch(ctx, method, B, max(4, steps // 2), 1, with_cpu=False, with_resident=False, max_range=None, mild=True, check_all=False)
         out["r02_candidate_set"] = {k: r2[k] for k in ("value", "unit", "steps", "ms_per_step", "mean_iterations", "converged")}
         out["r02_candidate_set"]["workload"] = r2["config"]["workload"]
     return out
 
 
-def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, max_range, mild=None):
+def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, max_range, mild=None, regularization=None, check_all=True):
     a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
     cfg4 = a.config == 4
     sensor = a.sensor or ("HDL-32E" if cfg4 else "HDL-64E")
@@ -275,8 +310,9 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
         pnh["reg_resolution"] = 1.0   # launch files use 1.0 (NDT factory default 0.5)
     if a.ndt_line_search and method == "NDT_OMP":
         pnh["reg_ndt_line_search"] = True
-    if a.regularization:
-        pnh["reg_regularization_method"] = a.regularization
+    regularization = regularization or a.regularization
+    if regularization and method in ("FAST_GICP", "FAST_VGICP"):
+        pnh["reg_regularization_method"] = regularization
     reg = ctx["select_registration_method"](pnh, device_id=ctx["local_rank"])
     shard = ctx["CandidateShard"](rank, world, device=ctx["coll_device"]) if ctx["sharded"] else None
     barrier = make_barrier(ctx, reg)
@@ -368,8 +404,12 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
     reg.profile_enable(True)
     reg.profile_read(reset=True)
     prof_steps = 2
+    barrier()
+    tp = time.perf_counter()
     for _ in range(prof_steps):
         rec_p, _ = step()
+    barrier()
+    profiled_step_ms = (time.perf_counter() - tp) * 1e3 / prof_steps
     prof = reg.profile_read(reset=True)
     reg.profile_enable(False)
     total_pts = sum(n_pts) + len(wl.target)
@@ -383,7 +423,8 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
     roofline = roofline_of(method, prof, units, prof_steps,
                            "whole-device launches (all candidates of the rank in one launch, HIP events on the engine's stream); the timed region "
                            "runs the same kernels split over 2 to 4 concurrent lanes (by batch size), whose launches overlap each other",
-                           pmc_ok=(sensor == "HDL-64E" and B == 64 and not a.downsample and not mild))
+                           pmc_ok=(sensor == "HDL-64E" and B == 64 and not a.downsample and not mild and pnh.get("reg_regularization_method") in (None, "PLANE")),
+                           profiled_step_ms=profiled_step_ms, pmc_name="fast_gicp_plane" if pnh.get("reg_regularization_method") == "PLANE" else None)
 
     # ---- the other scene seeds (informational: spread of the metric over scenes)
     by_seed = [round(world * B * steps / dt, 1)]
@@ -421,11 +462,34 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
             return kk / (time.perf_counter() - tc), {"max_pose_diff_vs_gpu_m": float(max(d[0] for d in dpose)), "max_pose_diff_vs_gpu_rad": float(max(d[1] for d in dpose))}
         cpu = best_cpu(sample, "registrations/sec", f"{k} of the {B} candidate registrations (setInputSource + align + getFitnessScore), target structures prebuilt",
                        single_thread=(lambda O: sample(O, 1)) if a.cpu_single_thread else None)
+        if check_all:
+            # ---- the checker over the WHOLE candidate set of the timed region (not timed, not part of `value`): the oracle registers every candidate
+            # sequentially, as loop_detector.hpp:135-154 does, at the thread count that was fastest above; every record of the GPU batch is compared with
+            # it and the oracle's own sequential selection (skip non-converged, skip score > best, ties replace) with the device's best_candidate
+            O.set_num_threads(cpu["cores"])
+            o = O.OracleRegistration(p)
+            o.setInputTarget(wl.target)
+            best_score, best_o, dts, drs, its_equal, fit_rel, conv_equal = np.finfo(np.float64).max, -1, [], [], 0, [], 0
+            for i in range(B):
+                o.setInputSource(wl.candidates[i])
+                ro = o.align(wl.guesses[i])
+                score = o.getFitnessScore(fit_range)
+                dt_i, dr_i = synth.pose_error(np.array(rec[i]["final_transformation"]).reshape(4, 4).T, ro.matrix())
+                dts.append(dt_i), drs.append(dr_i)
+                its_equal += int(ro.iterations == rec[i]["iterations"])
+                conv_equal += int(bool(ro.converged) == bool(rec[i]["converged"]))
+                fit_rel.append(abs(score - rec[i]["fitness_score"]) / max(abs(score), 1e-300))
+                if ro.converged and not score > best_score:
+                    best_score, best_o = score, i
+            cpu.update({"candidates_checked": B, "oracle_argmin": int(best_o), "oracle_argmin_agrees": bool(best_o == int(best)),
+                        "max_pose_diff_vs_gpu_m": float(max(dts)), "max_pose_diff_vs_gpu_rad": float(max(drs)), "iterations_equal": its_equal,
+                        "converged_flags_equal": conv_equal, "max_fitness_rel_diff_vs_gpu": float(max(fit_rel)),
+                        "check": "all candidates of the timed batch through the sequential oracle loop (loop_detector.hpp:135-154), after the timed region"})
 
     out = base_line(ctx, world * B * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
                     f"loop-closure batch: {B} candidate keyframes/GPU x {sensor} (~{int(np.mean(n_pts))} pts) vs 1 query keyframe, "
                     f"{method}{' with the opt-in More-Thuente line search (not the reference behaviour)' if pnh.get('reg_ndt_line_search') else ''}"
-                    f"{' (covariance regularisation ' + a.regularization + ')' if a.regularization else ''}"
+                    f"{' (covariance regularisation ' + regularization + ')' if pnh.get('reg_regularization_method') else ''}"
                     f" + getFitnessScore{'' if max_range is None else f' (max_range {max_range})'}, cold (index + covariances rebuilt every step); candidate set: "
                     + ("rounds 1-2 'mild' set (8 distinct scans within 4 m, guess noise 0.3 m / 1 deg)" if mild else
                        "SURVEY 8d (distinct ray-casts at poses within 20 m of the query, guess = ground truth + 0.5 m / 2 deg noise, z forced to 0)"),

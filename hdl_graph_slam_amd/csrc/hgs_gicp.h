@@ -218,18 +218,20 @@ HGS_HD bool gicp_is_converged(const Pose& delta, const GicpConsts& c) {
 }
 
 // d = LDLT(H + lambda I).solve(-b); xi = se3_exp(d) * x0
-HGS_HD void gicp_solve_try(GicpState& s, Pose* delta_out) {
-  double A[36], nb[6];
+// ws: nullptr (host, oracle-side callers: local arrays) or kGicpControlWorkspace doubles the caller owns (LDS in k_gicp_solve / k_gicp_decide)
+constexpr int kGicpControlWorkspace = 36 + 6 + kLdlt6Workspace;
+HGS_HD void gicp_solve_try(GicpState& s, Pose* delta_out, double* ws) {
+  double *A = ws, *nb = ws + 36;
   for (int i = 0; i < 36; i++) A[i] = s.H[i];
   for (int i = 0; i < 6; i++) A[i * 7] += s.lambda, nb[i] = -s.b[i];
-  solve_ldlt6(A, nb, s.d);
+  solve_ldlt6_ws(A, nb, s.d, ws + 42);
   const Pose delta = se3_exp(s.d);
   s.xi = pose_mul(delta, s.x0);
   if (delta_out) *delta_out = delta;
 }
 
 // After a linearisation: acc holds the reduced upper-triangle H, b, error at x0.
-HGS_HD void gicp_after_linearize(GicpState& s, const double* acc, const GicpConsts& c) {
+HGS_HD void gicp_after_linearize(GicpState& s, const double* acc, const GicpConsts& c, double* ws) {
   int k = 0;
   for (int r = 0; r < 6; r++)
     for (int cc = r; cc < 6; cc++) {
@@ -249,12 +251,12 @@ HGS_HD void gicp_after_linearize(GicpState& s, const double* acc, const GicpCons
   }
   s.nu = 2.0;
   s.lm_try = 0;
-  gicp_solve_try(s, nullptr);
+  gicp_solve_try(s, nullptr, ws);
   s.phase = GICP_TRY;
 }
 
 // After the trial error yi at xi is known: accept / reject exactly as step_lm + the outer loop do.
-HGS_HD void gicp_after_error(GicpState& s, double yi, const GicpConsts& c) {
+HGS_HD void gicp_after_error(GicpState& s, double yi, const GicpConsts& c, double* ws) {
   s.yi = yi;
   s.lm_try++;
   s.lm_tries_total++;
@@ -272,7 +274,7 @@ HGS_HD void gicp_after_error(GicpState& s, double yi, const GicpConsts& c) {
       if (s.lm_try >= c.lm_max_iterations) {
         step_ok = false, finished_step = true;  // "lm not converged": outer loop breaks
       } else {
-        gicp_solve_try(s, nullptr);  // next try against the same linearisation
+        gicp_solve_try(s, nullptr, ws);  // next try against the same linearisation
         return;                      // stay in GICP_TRY
       }
     }
@@ -296,6 +298,15 @@ HGS_HD void gicp_after_error(GicpState& s, double yi, const GicpConsts& c) {
   } else {
     s.phase = GICP_LINEARIZE;
   }
+}
+// the same steps with the workspace as a local array (host-side callers: tests/emul, the host mirror of the kernels)
+HGS_HD void gicp_after_linearize(GicpState& s, const double* acc, const GicpConsts& c) {
+  double ws[kGicpControlWorkspace];
+  gicp_after_linearize(s, acc, c, ws);
+}
+HGS_HD void gicp_after_error(GicpState& s, double yi, const GicpConsts& c) {
+  double ws[kGicpControlWorkspace];
+  gicp_after_error(s, yi, c, ws);
 }
 
 }  // namespace hgs

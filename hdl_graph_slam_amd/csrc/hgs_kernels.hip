@@ -722,13 +722,20 @@ void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt
 __global__ __launch_bounds__(kSolveBlock) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
                                                       int max_blocks, int tile_points) {
   const int b = blockIdx.x;
-  GicpState& st = states[b];
-  if (st.phase != GICP_LINEARIZE) return;
+  if (states[b].phase != GICP_LINEARIZE) return;
   __shared__ double acc[kAcc];
   __shared__ double scratch[kSolveBlock];
+  // the control step runs on ONE lane and is a chain of dependent loads and stores on the problem's state and on the factorisation's
+  // pivoted arrays: both live in LDS for its duration (state copied in and out by the block; round 3 ran it on HBM + 592 bytes of scratch)
+  __shared__ GicpState st;
+  __shared__ double ws[kGicpControlWorkspace];
+  static_assert(sizeof(GicpState) % sizeof(double) == 0 && sizeof(GicpState) / sizeof(double) <= kSolveBlock, "state copied one double per thread");
+  if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(&st)[threadIdx.x] = reinterpret_cast<const double*>(&states[b])[threadIdx.x];
   const int ntiles = (descs[b].meta->nvalid + tile_points - 1) / tile_points;  // tiles of the linearize kernel that filled `partials`
-  reduce_tiles<kAcc>(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);
-  if (threadIdx.x == 0) gicp_after_linearize(st, acc, c);
+  reduce_tiles<kAcc>(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);  // (ends with a barrier: the state copy is complete)
+  if (threadIdx.x == 0) gicp_after_linearize(st, acc, c, ws);
+  __syncthreads();
+  if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(&states[b])[threadIdx.x] = reinterpret_cast<const double*>(&st)[threadIdx.x];
 }
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
                        int tile_points) {
@@ -768,17 +775,23 @@ void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, co
 __global__ __launch_bounds__(64) void k_gicp_decide(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials_err,
                                                    int max_blocks, Progress prog) {
   const int b = blockIdx.x;
-  GicpState& st = states[b];
   bool finished_now = false;
-  if (st.phase == GICP_TRY) {
+  if (states[b].phase == GICP_TRY) {  // (block-uniform)
+    __shared__ GicpState st;  // as in k_gicp_solve: the one-lane control step works on LDS
+    __shared__ double ws[kGicpControlWorkspace];
+    for (int k = threadIdx.x; k < (int)(sizeof(GicpState) / sizeof(double)); k += 64) reinterpret_cast<double*>(&st)[k] = reinterpret_cast<const double*>(&states[b])[k];
     const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
     double s = 0;
     for (int t = threadIdx.x; t < ntiles; t += 64) s += partials_err[(size_t)b * max_blocks + t];
     s = wave_sum(s);
+    __syncthreads();
     if (threadIdx.x == 0) {
-      gicp_after_error(st, s, c);
+      gicp_after_error(st, s, c, ws);
       finished_now = st.phase == GICP_DONE;
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < (int)(sizeof(GicpState) / sizeof(double)); k += 64) reinterpret_cast<double*>(&states[b])[k] = reinterpret_cast<const double*>(&st)[k];
+    // (the tick below only tells the host how far the batch is; states[] is read by later kernels of this stream, after this one has ended)
   }
   if (threadIdx.x == 0) progress_tick(prog, finished_now);
 }

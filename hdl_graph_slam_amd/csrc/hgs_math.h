@@ -172,6 +172,60 @@ HGS_HD Pose se3_exp(const double* d) {
 
 // ---- 6x6 solvers (row-major A[36]) ----------------------------------------------------------------------------
 // Symmetric solve via LDL^T with diagonal pivoting (role of Eigen::LDLT in fast_gicp's step_lm).
+// The factorisation's working arrays are indexed by the pivot, i.e. dynamically: as locals they live in scratch memory on the device (592 bytes and
+// ~300 scratch instructions in each of k_gicp_solve / k_gicp_decide in round 3).  `ws` (kLdlt6Workspace doubles, LDS on the device) holds them instead;
+// the arithmetic is the same either way.
+constexpr int kLdlt6Workspace = 36 + 36 + 6 + 6 + 6 + 6;
+HGS_HD void solve_ldlt6_ws(const double* A_in, const double* b_in, double* x, double* ws) {
+  double *A = ws, *L = ws + 36, *D = ws + 72, *y = ws + 78, *z = ws + 84, *permd = ws + 90;  // (the permutation as small integers in doubles: one workspace type)
+  for (int i = 0; i < 36; i++) A[i] = A_in[i], L[i] = 0.0;
+  for (int i = 0; i < 6; i++) permd[i] = (double)i;
+  for (int k = 0; k < 6; k++) {
+    int piv = k;
+    double best = fabs(A[k * 6 + k]);
+    for (int i = k + 1; i < 6; i++) {
+      const double v = fabs(A[i * 6 + i]);
+      if (v > best) best = v, piv = i;
+    }
+    if (piv != k) {
+      for (int j = 0; j < 6; j++) {
+        const double t = A[k * 6 + j];
+        A[k * 6 + j] = A[piv * 6 + j];
+        A[piv * 6 + j] = t;
+      }
+      for (int i = 0; i < 6; i++) {
+        const double t = A[i * 6 + k];
+        A[i * 6 + k] = A[i * 6 + piv];
+        A[i * 6 + piv] = t;
+      }
+      for (int j = 0; j < k; j++) {
+        const double t = L[k * 6 + j];
+        L[k * 6 + j] = L[piv * 6 + j];
+        L[piv * 6 + j] = t;
+      }
+      const double t = permd[k];
+      permd[k] = permd[piv];
+      permd[piv] = t;
+    }
+    D[k] = A[k * 6 + k];
+    L[k * 6 + k] = 1.0;
+    for (int i = k + 1; i < 6; i++) L[i * 6 + k] = (D[k] != 0.0) ? A[i * 6 + k] / D[k] : 0.0;
+    for (int i = k + 1; i < 6; i++)
+      for (int j = k + 1; j < 6; j++) A[i * 6 + j] -= L[i * 6 + k] * D[k] * L[j * 6 + k];
+  }
+  for (int i = 0; i < 6; i++) {
+    double s = b_in[(int)permd[i]];
+    for (int j = 0; j < i; j++) s -= L[i * 6 + j] * y[j];
+    y[i] = s;
+  }
+  for (int i = 0; i < 6; i++) y[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+    for (int j = i + 1; j < 6; j++) s -= L[j * 6 + i] * z[j];
+    z[i] = s;
+  }
+  for (int i = 0; i < 6; i++) x[(int)permd[i]] = z[i];
+}
 HGS_HD void solve_ldlt6(const double* A_in, const double* b_in, double* x) {
   double A[36], L[36], D[6], y[6], z[6];
   int perm[6];

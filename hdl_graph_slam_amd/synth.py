@@ -9,6 +9,10 @@ Sensor models follow the devices hdl_graph_slam's launch files target (VLP-16 / 
 from __future__ import annotations
 
 import dataclasses
+import hashlib
+import os
+import tempfile
+
 import numpy as np
 
 POINT_XYZI_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("intensity", "<f4"), ("pad", "<f4", (3,))])
@@ -122,6 +126,46 @@ def scan(scene: Scene, sensor: str, pose: np.ndarray, noise_seed: int, noise_sig
     """Ray-cast one revolution from `pose` (4x4 vehicle pose in the world; the sensor sits `mount height` above it).
 
     Returns the hits in the SENSOR frame, in firing order, as PointXYZI records (or [n,3] float32)."""
+    # Ray casting is 1-2 s per 64-beam revolution on the host; repeated runs of the benchmarks / A-B scripts over the same seeded scenes (a GPU
+    # visit runs bench.py a dozen times) read the revolution back from a scratch directory instead.  HGS_SCAN_CACHE=<dir> (empty: off); the key is
+    # every input of this function plus this file's own bytes, so an edit to the simulator never meets a stale scan.
+    cache = _scan_cache_path(scene, sensor, pose, noise_seed, noise_sigma, max_range, as_xyzi)
+    if cache and os.path.exists(cache):
+        try:
+            return np.load(cache)
+        except Exception:  # noqa: BLE001 - a truncated file of an interrupted run: cast again
+            pass
+    out = _scan_uncached(scene, sensor, pose, noise_seed, noise_sigma, max_range, as_xyzi)
+    if cache:
+        try:
+            tmp = f"{cache}.{os.getpid()}.tmp.npy"
+            np.save(tmp, out)
+            os.replace(tmp, cache)
+        except OSError:
+            pass
+    return out
+
+
+def _scan_cache_path(scene, sensor, pose, noise_seed, noise_sigma, max_range, as_xyzi):
+    root = os.environ.get("HGS_SCAN_CACHE", os.path.join(tempfile.gettempdir(), "hgs_scan_cache"))
+    if not root:
+        return None
+    try:
+        os.makedirs(root, exist_ok=True)
+    except OSError:
+        return None
+    h = hashlib.sha256()
+    with open(os.path.abspath(__file__), "rb") as fh:
+        h.update(fh.read())
+    for f in dataclasses.fields(scene):
+        v = getattr(scene, f.name)
+        h.update(np.ascontiguousarray(v).tobytes() if isinstance(v, np.ndarray) else repr(v).encode())
+    h.update(repr((sensor, int(noise_seed), float(noise_sigma), float(max_range), bool(as_xyzi))).encode())
+    h.update(np.ascontiguousarray(pose, dtype=np.float64).tobytes())
+    return os.path.join(root, h.hexdigest()[:32] + ".npy")
+
+
+def _scan_uncached(scene: Scene, sensor: str, pose: np.ndarray, noise_seed: int, noise_sigma: float, max_range: float, as_xyzi: bool) -> np.ndarray:
     dirs_s = _ray_dirs(sensor)
     T = pose.copy()
     T[2, 3] += SENSORS[sensor][4]
