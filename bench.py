@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--ndt-steps", type=int, default=8, help="timed steps of the NDT_OMP sub-record")
     ap.add_argument("--fitness-max-range-variant", action="store_true", help="config 4: also time the batch with fitness_score_max_range = 4.0")
     ap.add_argument("--cpu-single-thread", action="store_true", help="cpu_baseline also carries the one-thread rate (one unit of the sample)")
+    ap.add_argument("--no-kitti-records", action="store_true", help="config 3: skip the two sub-records that run the stream behind the KITTI launch file's prefilter")
     ap.add_argument("--oracle-sweeps", type=int, default=12, help="config 3: sweeps the CPU oracle runs through the same caller for the trajectory agreement (0: none)")
     ap.add_argument("--speed", type=float, default=0.0, help="config 3: vehicle speed in m/s (default: 8.0 as SURVEY 8d, plus a 3.0 m/s sub-record)")
     ap.add_argument("--method", default="", choices=["", "FAST_GICP", "FAST_VGICP", "NDT_OMP"])
@@ -642,27 +643,52 @@ def run_odometry(ctx):
     a = ctx["args"]
     speeds = [a.speed] if a.speed > 0 else [8.0, 3.0]
     out = odometry_at_speed(ctx, speeds[0], ctx["n_seeds"], not a.no_cpu_baseline)
+    keys = ("value", "ms_per_step", "steps", "latency_ms", "mean_iterations", "max_iterations", "keyframes", "us_per_iteration_p50", "trajectory_error_vs_ground_truth",
+            "oracle_stream")
     for sp in speeds[1:]:
         o = odometry_at_speed(ctx, sp, 1, False)
-        out[f"at_{sp:g}_mps".replace(".", "_")] = {k: o[k] for k in ("value", "ms_per_step", "steps", "latency_ms", "mean_iterations", "max_iterations", "keyframes",
-                                                                     "trajectory_error_vs_ground_truth", "oracle_stream")}
+        out[f"at_{sp:g}_mps".replace(".", "_")] = {k: o[k] for k in keys}
+    if not a.method and not a.no_kitti_records and ctx["world"] == 1:
+        # the stream as the reference's KITTI launch file runs it (launch/hdl_graph_slam_kitti.launch:22-34,50-59): every sweep through the prefilter
+        # (distance 0.1-100 m, VoxelGrid 0.25 m, radius outlier removal 0.5 m / 2 neighbours) ON THE DEVICE, then (a) the engine SURVEY 8d names for
+        # config 3 (NDT_OMP) and (b) the engine that launch file selects (FAST_GICP, transformation epsilon 0.1, max correspondence distance 2.0)
+        for name, pipeline in (("kitti_prefilter_ndt_omp", "kitti_prefilter"), ("kitti_launch_fast_gicp", "kitti_launch")):
+            o = odometry_at_speed(ctx, speeds[0], 1, not a.no_cpu_baseline, pipeline=pipeline)
+            out[name] = {k: o[k] for k in keys + ("cpu_baseline", "roofline")}
+            out[name]["workload"] = o["config"]["workload"]
+            out[name]["points_after_prefilter"] = o["config"]["points_after_prefilter"]
     return out
 
 
-def odometry_at_speed(ctx, speed, n_seeds, with_cpu):
+def odometry_at_speed(ctx, speed, n_seeds, with_cpu, pipeline="raw"):
     a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
     from hdl_graph_slam_amd.odometry import ScanMatchingOdometry
-    method = a.method or "NDT_OMP"
+    method = a.method or ("FAST_GICP" if pipeline == "kitti_launch" else "NDT_OMP")
     sensor = a.sensor or "HDL-64E"
     steps = a.steps or 60
     pnh = {"registration_method": method, "reg_resolution": 1.0}
+    if pipeline == "kitti_launch":   # launch/hdl_graph_slam_kitti.launch:50-59
+        pnh.update({"reg_transformation_epsilon": 0.1, "reg_maximum_iterations": 64, "reg_max_correspondence_distance": 2.0, "reg_correspondence_randomness": 20})
     kf = dict(keyframe_delta_trans=5.0, keyframe_delta_angle=2.0, keyframe_delta_time=10000.0)
     reg = ctx["select_registration_method"](pnh, device_id=ctx["local_rank"])
     barrier = make_barrier(ctx, reg)
+    prefilter, oracle_prefilter, kept = None, None, []
+    if pipeline != "raw":   # prefiltering_nodelet of the KITTI launch file (:22-34), on the device: raw sweep in (H2D), filtered resident cloud out
+        import ctypes as C
+        pp = L.HgsPrefilterParams()
+        L.lib().hgs_prefilter_params_default(C.byref(pp))
+        pp.use_distance_filter, pp.distance_near_thresh, pp.distance_far_thresh = 1, 0.1, 100.0
+        pp.downsample_method, pp.downsample_resolution = L.HGS_DOWNSAMPLE_VOXELGRID, 0.25
+        pp.outlier_removal_method, pp.radius_radius, pp.radius_min_neighbors = L.HGS_OUTLIER_RADIUS, 0.5, 2
+
+        def prefilter(cloud):
+            d = reg.prefilter(cloud, pp)
+            kept.append(d.size)
+            return d
 
     def run(seed, n_warm, n):
         stream = ctx["workloads"].make_odometry_stream(sensor, seed, n_warm + n + 1, speed=speed, downsample=a.downsample or None)
-        od = ScanMatchingOdometry(reg, **kf)
+        od = ScanMatchingOdometry(reg, downsample=prefilter, **kf)
         est, its = [], []
         for t, c in zip(stream.stamps[:n_warm + 1], stream.scans[:n_warm + 1]):   # the first call only sets the keyframe
             est.append(od.matching(t, c))
@@ -689,12 +715,13 @@ def odometry_at_speed(ctx, speed, n_seeds, with_cpu):
     reg.profile_read(reset=True)
     prof_sweeps, passes = 4, 0
     for c in stream.scans[-prof_sweeps:]:
-        reg.setInputSource(c)
+        reg.setInputSource(prefilter(c) if prefilter else c)
         rp = reg.align(od.prev_trans)
         passes += int(rp.lm_tries if method == "NDT_OMP" else rp.iterations)
     prof = reg.profile_read(reset=True)
     reg.profile_enable(False)
-    units = {"covariance": prof_sweeps * n_pts if method != "NDT_OMP" else 0.0, "linearize": float(passes) * n_pts, "error": 0.0, "fitness": 0.0}
+    n_reg = int(np.mean(kept)) if kept else n_pts   # points per registered cloud (after the prefilter, if any)
+    units = {"covariance": prof_sweeps * n_reg if method != "NDT_OMP" else 0.0, "linearize": float(passes) * n_reg, "error": 0.0, "fitness": 0.0}
     roofline = roofline_of(method, prof, units, prof_sweeps, "one registration per launch (HIP events on the engine's stream)", pmc_ok=False)
 
     by_seed = [round(world * steps / dt, 2)]
@@ -708,10 +735,17 @@ def odometry_at_speed(ctx, speed, n_seeds, with_cpu):
     if rank == 0 and world == 1 and (with_cpu or a.oracle_sweeps > 0):
         O, p = oracle_params(reg)
         k = max(2, min(a.cpu_sample, 4))
+        oracle_pf = None
+        if prefilter:   # the oracle's restatement of the same prefilter (oracle/prefilter.hpp), on the host
+            opf = O.default_prefilter_params()
+            opf.use_distance_filter, opf.distance_near_thresh, opf.distance_far_thresh = 1, 0.1, 100.0
+            opf.downsample_method, opf.downsample_resolution = 1, 0.25
+            opf.outlier_removal_method, opf.radius_radius, opf.radius_min_neighbors = 2, 0.5, 2
+            oracle_pf = lambda c: synth.to_xyzi(O.prefilter(c, opf)[:, :3])  # noqa: E731
         if a.oracle_sweeps > 0:
             O.set_num_threads(min(32, os.cpu_count() or 1))
             n_o = min(a.oracle_sweeps, len(stream.scans) - 1)
-            oo = ScanMatchingOdometry(O.OracleRegistration(p), **kf)
+            oo = ScanMatchingOdometry(O.OracleRegistration(p), downsample=oracle_pf, **kf)
             eo = [oo.matching(t, c) for t, c in zip(stream.stamps[:n_o + 1], stream.scans[:n_o + 1])]
             d = [synth.pose_error(x, y) for x, y in zip(est[:n_o + 1], eo)]
             gt0 = np.linalg.inv(stream.poses[0])
@@ -721,7 +755,7 @@ def odometry_at_speed(ctx, speed, n_seeds, with_cpu):
                              "device_translation_error_at_the_same_sweep_m": round(float(err[n_o][0]), 4), "keyframes_oracle": oo.num_keyframes}
         if with_cpu:
             def sample(O):
-                oc = ScanMatchingOdometry(O.OracleRegistration(p), **kf)
+                oc = ScanMatchingOdometry(O.OracleRegistration(p), downsample=oracle_pf, **kf)
                 oc.matching(stream.stamps[0], stream.scans[0])
                 tc = time.perf_counter()
                 for t, c in zip(stream.stamps[1:k + 1], stream.scans[1:k + 1]):
@@ -733,8 +767,10 @@ def odometry_at_speed(ctx, speed, n_seeds, with_cpu):
     rmse_t = float(np.sqrt(np.mean([e[0] ** 2 for e in err])))
     out = base_line(ctx, world * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
                     f"config 3: {sensor} odometry stream (~{n_pts} pts/sweep, {speed:g} m/s at 10 Hz = {speed / 10:g} m per sweep), {method}, frame-to-keyframe with the KITTI "
-                    f"keyframe rule (5 m / 2 rad), host buffer in -> pose out per sweep: H2D upload INCLUDED in every step",
-                    {"points_per_cloud": n_pts, "method": method, "speed_mps": speed, "parallelism": f"{world} replicas (the path is sequential in time)" if world > 1 else "single GPU"})
+                    f"keyframe rule (5 m / 2 rad), host buffer in -> pose out per sweep: H2D upload INCLUDED in every step"
+                    + ("" if pipeline == "raw" else "; every sweep through the KITTI launch file's prefilter on the device first (distance 0.1-100 m, VoxelGrid 0.25 m, radius "
+                       "outlier removal 0.5 m / 2; hdl_graph_slam_kitti.launch:22-34)" + ("; engine parameters of the same launch file (:50-59)" if pipeline == "kitti_launch" else "")),
+                    {"points_per_cloud": n_pts, "points_after_prefilter": int(np.mean(kept)) if kept else None, "method": method, "speed_mps": speed, "parallelism": f"{world} replicas (the path is sequential in time)" if world > 1 else "single GPU"})
     out.update({"latency_ms": dict(percentiles(per_step), p99=round(float(np.percentile(per_step, 99)), 3)), "step_ms": percentiles(per_step), "timed_region_s": round(dt, 3),
                 "mean_iterations": float(np.mean(its)), "max_iterations": int(max(its)), "keyframes": od.num_keyframes,
                 "us_per_iteration_p50": round(float(np.median(np.array(per_step) / np.maximum(np.array(its), 1))) * 1e3, 1),
