@@ -158,7 +158,12 @@ struct hgs_handle {
   hgs::Comm* comm = nullptr;            // hgs_comm_init: the ranks of a sharded loop-closure batch
   DeviceBuffer comm_send, comm_recv, comm_ids;
   DeviceBuffer ndt_plan;         // per lane: work queue head + tile prefix sums of the running NDT batch
-  int ndt_resident_blocks = 768; // blocks per k_ndt_pass launch: 2 per CU are resident, the third is the tail filler (512 / 640 / 768 / 896 / 1024 measured on the 64-candidate batch: 1276 / 1281 / 1319 / 1319 / 1291 reg/s); HGS_NDT_RESIDENT (A/B runs)
+  // blocks per k_ndt_pass launch (0: by the lane count, below); HGS_NDT_RESIDENT (A/B runs).  Two blocks per CU are resident (the round-4 kernel
+  // holds 57 KB of LDS per block).  One lane: 768 — the third block per CU fills the tail (512 / 768 / 1024: 497 / 473 / 452 us per whole-device pass
+  // but 1024 loses in the batch).  Several concurrent lanes: 512 per launch — the lanes fill each other's tails, and blocks beyond the resident
+  // ones only queue in front of the other lanes' (64-candidate batch, 3 lanes, round 4: 384 / 448 / 512 / 576 / 768 = 2272 / 2284 / 2268 / 2213 /
+  // 2162 registrations/s; profiles/r04_ndt_knobs.log)
+  int ndt_resident_blocks = 0;
   int ndt_chunk = 0;             // largest queue grab in items (0: the default, 8; 1 = one tile per grab); HGS_NDT_CHUNK (A/B runs)
   int ndt_sort = -1;       // NDT source order: -1 Hilbert order if the source has an index, 1 build the index first, 0 input order (HGS_NDT_SORT, A/B runs)
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
@@ -825,7 +830,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
         for (int k = 0; k < L.B; k++) tb[k + 1] = tb[k] + std::max(1, ((int)sources[L.b0 + k]->n_input + kBlock - 1) / kBlock);
         LanePlan& P = plans[li];
         const int total = tb[L.B];
-        P.blocks = std::max(1, std::min(total, h->ndt_resident_blocks));
+        P.blocks = std::max(1, std::min(total, h->ndt_resident_blocks > 0 ? h->ndt_resident_blocks : (lanes.size() > 1 ? 512 : 768)));
         // largest queue grab (the kernel sizes each grab by guided self-scheduling, at most this many items).  Fixed grabs
         // measured on the 16 x 119 k batch with 4 lanes: 1 -> 904, 2 -> 1062, 3 -> 980, 4 -> 936, 8 -> 845 registrations/s
         P.chunk = h->ndt_chunk > 0 ? h->ndt_chunk : 8;
