@@ -1106,6 +1106,31 @@ __device__ __forceinline__ int ndt_pop_cell_lds(unsigned& mask, const int* col /
   mask &= mask - 1u;
   return col[o * kBlock];
 }
+// The angle tables of a problem as k_ndt_pass keeps them in LDS: component-major, and the rows in the order in which the per-cell arithmetic wants
+// them as PAIRS (j rows 0,1 | 2,5 | 3,6 | 4,7: the point-gradient columns 4 and 5 side by side; then the 15 h rows), so that one ds_read_b64 delivers the
+// two factors of a v_pk_mul_f32.  In the [row][component] order of NdtAngles the compiler built the same pairs with ~100 register moves per tile.
+struct NdtAnglesLds {
+  float tab[3][24];  // [component][slot]; slot 23 is padding (zero)
+  float T[12];
+};
+__device__ __forceinline__ int ndt_angle_slot(int row /* 0..7: j, 8..22: h */) {
+  return row >= 8 ? row : (row < 2 ? row : (row == 2 ? 2 : (row == 5 ? 3 : (row == 3 ? 4 : (row == 6 ? 5 : (row == 4 ? 6 : 7))))));
+}
+// ndt_point_derivatives on the LDS layout: per row (a0 x + a1 y) + a2 z, unfused, the scalar form's operations on two rows at a time
+__device__ __forceinline__ void ndt_point_derivatives_lds(const NdtAnglesLds& a, float x, float y, float z, NdtPointDeriv& d) {
+#pragma clang fp contract(off)
+  const ndt_f2 X = {x, x}, Y = {y, y}, Z = {z, z};
+  const ndt_f2* tx = reinterpret_cast<const ndt_f2*>(a.tab[0]);
+  const ndt_f2* ty = reinterpret_cast<const ndt_f2*>(a.tab[1]);
+  const ndt_f2* tz = reinterpret_cast<const ndt_f2*>(a.tab[2]);
+  ndt_f2 r[12];
+#pragma unroll
+  for (int s = 0; s < 12; s++) r[s] = tx[s] * X + ty[s] * Y + tz[s] * Z;
+  d.xj[0] = r[0].x, d.xj[1] = r[0].y, d.xj[2] = r[1].x, d.xj[5] = r[1].y, d.xj[3] = r[2].x, d.xj[6] = r[2].y, d.xj[4] = r[3].x, d.xj[7] = r[3].y;
+#pragma unroll
+  for (int k = 0; k < 15; k++) d.xh[k] = (k & 1) ? r[4 + (k >> 1)].y : r[4 + (k >> 1)].x;
+}
+
 // ---- the three memory stages in front of a tile's arithmetic; k_ndt_pass runs them for tile t + 1 between the pieces of tile t's
 // digit reduction (point -> hash probes -> first cell record are dependent loads: with two waves per SIMD their latencies were exposed)
 struct NdtGridBox {
@@ -1133,7 +1158,7 @@ __device__ __forceinline__ void ndt_front_load(float4& x, int& have, const Cloud
 
 // xt: the point under the problem's current pose; kv: the first probe of every neighbourhood cell, in flight on return
 template <int NOFF>
-__device__ __forceinline__ void ndt_front_issue_probes(const float4& x, int& have, F3& xt, unsigned long long (&kv)[NOFF], const NdtAngles* ap, const NdtTargetView& tgt, const NdtGridBox& g,
+__device__ __forceinline__ void ndt_front_issue_probes(const float4& x, int& have, F3& xt, unsigned long long (&kv)[NOFF], const NdtAnglesLds* ap, const NdtTargetView& tgt, const NdtGridBox& g,
                                                        int search, int sorted) {
   if (!sorted && !finite3(x)) have = 0;
   xt = transform_point_f(ap->T, x.x, x.y, x.z);
@@ -1215,7 +1240,7 @@ __device__ __forceinline__ bool ndt_reduce_sums(const double (&acc)[kAccNdt], un
 }
 
 struct NdtPassShared {
-  NdtAngles ang;
+  NdtAnglesLds ang;
   unsigned long long slots[kAccNdt * 2][64];         // [accumulator * 2 + chunk][lane]: integer chunk sums of the tiles since the last flush (43 KB)
   unsigned long long part[kAccNdt * 2][4];           // flush: a slot's four 16-lane partial sums
   unsigned adds;                                     // wave-tile additions since the last flush (each put one magic constant into every lane of every slot)
@@ -1376,7 +1401,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
           d = descs[cur_b];
           cur_n = sorted ? d.meta->nvalid : d.n_input;
           __syncthreads();
-          for (int k = threadIdx.x; k < (int)(sizeof(NdtAngles) / 4); k += kBlock) reinterpret_cast<float*>(&S.ang)[k] = reinterpret_cast<const float*>(&angles[cur_b])[k];
+          for (int k = threadIdx.x; k < (int)(sizeof(NdtAngles) / 4); k += kBlock) {  // j[8][3] | h[15][3] | T[12] -> NdtAnglesLds
+            const float v = reinterpret_cast<const float*>(&angles[cur_b])[k];
+            if (k < 69) S.ang.tab[k % 3][ndt_angle_slot(k / 3)] = v;
+            else S.ang.T[k - 69] = v;
+          }
+          if (threadIdx.x < 3) S.ang.tab[threadIdx.x][23] = 0.f;
           __syncthreads();
         }
       }
@@ -1393,7 +1423,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
       if (tile * kBlock >= cur_n && !(tile == 0)) continue;  // the host's tile count is an upper bound (non-finite points); tile 0 always runs
       unsigned ang_off = 0;
       HGS_OPAQUE_OFFSET(ang_off);  // re-read the tables from LDS every tile: hoisted out of the loop they would pin 81 VGPRs
-      const NdtAngles* ap = reinterpret_cast<const NdtAngles*>(reinterpret_cast<const char*>(&S.ang) + ang_off);
+      const NdtAnglesLds* ap = reinterpret_cast<const NdtAnglesLds*>(reinterpret_cast<const char*>(&S.ang) + ang_off);
       if (!staged) {  // first tile of a run: the three dependent loads one after the other
         ndt_front_load(fx, fhave, d, sorted, tile * kBlock + (int)threadIdx.x, cur_n);
         ndt_front_issue_probes<NOFF>(fx, fhave, fxt, fkv, ap, tgt, box, c.search, sorted);
@@ -1416,7 +1446,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
         int cur = ndt_pop_cell_lds<NOFF>(vmask, ci_col);
         NdtCellRec rc = tgt.cells[cur >= 0 ? cur : 0];
         NdtPointDeriv pd;
-        ndt_point_derivatives(*ap, fx.x, fx.y, fx.z, pd);
+        ndt_point_derivatives_lds(*ap, fx.x, fx.y, fx.z, pd);
 #pragma unroll 1
         for (int v = 0; v < NOFF; v++) {
           if (__ballot(cur >= 0) == 0ull) break;

@@ -108,8 +108,18 @@ __device__ __forceinline__ double ndt_exp_coeff(double c) {
   return __hiloint2double(hi, lo);
 }
 #define HGS_NDT_EXP_COEFF(c) ndt_exp_coeff(c)
+// One Horner step p * r + c with the coefficient read from its scalar pair: v_fma_f64 (three-address).  Left to itself the compiler picks
+// v_fmac_f64, whose addend is its destination: two v_mov_b32 per step to copy the coefficient there first (20 of ~330 vector instructions per
+// visited cell of k_ndt_pass).  Same IEEE operation, same bits.
+__device__ __forceinline__ double ndt_horner_step(double p, double r, double c) {
+  double out;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(p), "v"(r), "s"(c));
+  return out;
+}
+#define HGS_NDT_HORNER(p, r, c) ndt_horner_step(p, r, c)
 #else
 #define HGS_NDT_EXP_COEFF(c) (c)
+#define HGS_NDT_HORNER(p, r, c) fma(p, r, c)
 #endif
 HGS_HD double ndt_exp(double x) {
   HGS_FP_STRICT
@@ -119,16 +129,16 @@ HGS_HD double ndt_exp(double x) {
   const double kd = rint(x * 0x1.71547652b82fep+0);
   const double r = fma(-kd, 0x1.a39ef35793c76p-33, fma(-kd, 0x1.62e42fee00000p-1, x));
   double p = 0x1.6124613a86d09p-33;
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.1eed8eff8d898p-29));
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.ae64567f544e4p-26));
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.27e4fb7789f5cp-22));
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.71de3a556c734p-19));
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.a01a01a01a01ap-16));
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.a01a01a01a01ap-13));
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.6c16c16c16c17p-10));
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.1111111111111p-7));
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.5555555555555p-5));
-  p = fma(p, r, HGS_NDT_EXP_COEFF(0x1.5555555555555p-3));
+  p = HGS_NDT_HORNER(p, r, 0x1.1eed8eff8d898p-29);
+  p = HGS_NDT_HORNER(p, r, 0x1.ae64567f544e4p-26);
+  p = HGS_NDT_HORNER(p, r, 0x1.27e4fb7789f5cp-22);
+  p = HGS_NDT_HORNER(p, r, 0x1.71de3a556c734p-19);
+  p = HGS_NDT_HORNER(p, r, 0x1.a01a01a01a01ap-16);
+  p = HGS_NDT_HORNER(p, r, 0x1.a01a01a01a01ap-13);
+  p = HGS_NDT_HORNER(p, r, 0x1.6c16c16c16c17p-10);
+  p = HGS_NDT_HORNER(p, r, 0x1.1111111111111p-7);
+  p = HGS_NDT_HORNER(p, r, 0x1.5555555555555p-5);
+  p = HGS_NDT_HORNER(p, r, 0x1.5555555555555p-3);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
