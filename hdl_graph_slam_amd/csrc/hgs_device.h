@@ -95,7 +95,7 @@ constexpr int kTileNN = kBlock * kNW;     // source points per block of k_gicp_l
 void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw, float* intensity /* may be null */);
 void launch_meta_init(hipStream_t s, const CloudDesc* descs, int ncloud);
 void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n);
-void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals);
+void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals, int drop_bits);
 void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int max_slots, const unsigned* sorted_vals);
 void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int max_P);
 void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method,

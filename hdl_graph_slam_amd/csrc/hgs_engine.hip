@@ -139,6 +139,10 @@ struct hgs_handle {
   hipStream_t lane_stream[3] = {};
   hipEvent_t lane_event[4] = {};
   int nn_qpw = 0;  // 0: chosen per launch (nn_queries_per_wave)
+  // levels of the Hilbert curve the index sort compares (HGS_HILBERT_LEVELS, A/B runs; 16 = all 48 bits, rounds 1-3).  64 x 119 k batch, index stage / step:
+  // 16 -> 0.915 / 11.99 ms, 13 -> 0.83 / 11.93, 11 -> 0.75 / 11.91, 10 -> 0.75 / 12.1, 9 -> 0.75 / 12.7 (the walks slow down once a cell of the finest compared
+  // level holds many points): 13 = 1/8192 of the cloud's extent (2.4 cm on a 200 m scan), one radix pass less for a batch and two for a pair
+  int hilbert_levels = 13;
   hipEvent_t comm_event = nullptr;  // hgs_loop_match_batch_sharded: the gathered headers have reached the host
   // measured on the 16 x 120 k-point loop batch: 1 -> 2 -> 4 lanes = 2850 -> 2935 -> 2975 GICP reg/s, 735 -> 772 -> 797 NDT;
   // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default).  Round 2, 64 x 119 k-point batch:
@@ -366,19 +370,22 @@ int ensure_index(hgs_handle* h, const std::vector<hgs_cloud*>& all) {
         HGS_HIP(h, h->sort_keys[i].reserve(total * sizeof(uint64_t)));
         HGS_HIP(h, h->sort_vals[i].reserve(total * sizeof(uint32_t)));
       }
-      launch_hilbert_keys(h->stream, d_descs, nc, max_n, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
+      // The sort compares the top `hilbert_levels` levels of the curve (3 bits each) + the cloud ordinal: points that share a cell of the finest
+      // compared level stay in input order (stable sort), i.e. in firing order — still neighbours.  Fewer compared bits = fewer radix passes.
+      const int drop_bits = 3 * (16 - h->hilbert_levels);
+      launch_hilbert_keys(h->stream, d_descs, nc, max_n, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>(), drop_bits);
       int bits = 48;
       for (int v = nc - 1; v > 0; v >>= 1) bits++;
       size_t tmp_bytes = 0;
       int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
-                                      h->sort_vals[1].as<uint32_t>(), total, 0, bits, h->stream);
+                                      h->sort_vals[1].as<uint32_t>(), total, drop_bits, bits, h->stream);
       if (rc != 0) {
         h->err = "rocprim radix_sort_pairs (size query) failed";
         return HGS_ERR_HIP;
       }
       HGS_HIP(h, h->sort_tmp.reserve(tmp_bytes));
       rc = hgs_sort_pairs_u64_u32(h->sort_tmp.p, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
-                                  h->sort_vals[1].as<uint32_t>(), total, 0, bits, h->stream);
+                                  h->sort_vals[1].as<uint32_t>(), total, drop_bits, bits, h->stream);
       if (rc != 0) {
         h->err = "rocprim radix_sort_pairs failed";
         return HGS_ERR_HIP;
@@ -987,6 +994,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
   if (const char* e = std::getenv("HGS_KNN_REPLAY")) h->knn_replay = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("HGS_NDT_RESIDENT")) h->ndt_resident_blocks = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("HGS_NDT_CHUNK")) h->ndt_chunk = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("HGS_HILBERT_LEVELS")) h->hilbert_levels = std::max(4, std::min(16, std::atoi(e)));
   if (const char* e = std::getenv("HGS_NN_QPW")) h->nn_qpw = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 32 ? 32 : 64);  // A/B: queries per packet of the 1-NN kernels
   if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     g_create_error = "hipSetDevice / hipStreamCreate failed";

@@ -274,7 +274,9 @@ void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
   hipLaunchKernelGGL(k_bbox_count, dim3(gx, ncloud), dim3(kBlock), 0, s, descs);
 }
 
-__global__ __launch_bounds__(kBlock) void k_hilbert_keys(const CloudDesc* descs, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+// drop_bits: low bits of the 48-bit curve position the sort will not look at (3 per level dropped, hgs_engine.hip): a finite point's position is kept
+// below the all-ones value ALSO in the bits that remain, so that no finite point ties with the non-finite ones, which must end up behind nvalid
+__global__ __launch_bounds__(kBlock) void k_hilbert_keys(const CloudDesc* descs, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals, int drop_bits) {
   const CloudDesc d = descs[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= d.n_input) return;
@@ -289,14 +291,15 @@ __global__ __launch_bounds__(kBlock) void k_hilbert_keys(const CloudDesc* descs,
     const unsigned qy = min(65535u, (unsigned)((p.y - mny) * sc));
     const unsigned qz = min(65535u, (unsigned)((p.z - mnz) * sc));
     code = hilbert48(qx, qy, qz);
-    if (code == 0xffffffffffffull) code--;  // reserve all-ones for non-finite points
+    const unsigned long long top = 0xffffffffffffull >> drop_bits << drop_bits;
+    if (code >= top) code = top - 1ull;  // reserve all-ones (in the compared bits) for non-finite points
   }
   keys[d.sort_off + i] = ((unsigned long long)blockIdx.y << 48) | code;
   vals[d.sort_off + i] = (unsigned)i;
 }
-void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals) {
+void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals, int drop_bits) {
   if (max_n <= 0) return;
-  hipLaunchKernelGGL(k_hilbert_keys, dim3((max_n + kBlock - 1) / kBlock, ncloud), dim3(kBlock), 0, s, descs, keys, vals);
+  hipLaunchKernelGGL(k_hilbert_keys, dim3((max_n + kBlock - 1) / kBlock, ncloud), dim3(kBlock), 0, s, descs, keys, vals, drop_bits);
 }
 
 __global__ __launch_bounds__(kBlock) void k_gather_sorted(const CloudDesc* descs, const unsigned* __restrict__ sorted_vals) {
