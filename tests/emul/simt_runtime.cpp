@@ -293,7 +293,9 @@ extern "C" void simt_read_counters(unsigned long long* out2) {
 // ------------------------------------------------------------------------------------------------ hgs_comm.h on the host
 // single-rank stand-in for the RCCL exchange step: the "all-gather" of one rank is a copy
 #include "../../hdl_graph_slam_amd/csrc/hgs_comm.h"
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -365,9 +367,26 @@ int comm_all_gather(Comm* c, const void* send, void* recv, size_t bytes_per_rank
     if (err && cap) snprintf(err, cap, "the communicator has been aborted");
     return 1;
   };
+  // The real collective is enqueued and the engine waits for it with a deadline (comm_wait, HGS_COMM_TIMEOUT_MS); this stand-in completes inside the
+  // call, so the same deadline applies to its rendezvous: a rank whose peers never arrive aborts the group and fails instead of blocking for ever.
+  long limit_ms = 60000;
+  if (const char* e = std::getenv("HGS_COMM_TIMEOUT_MS")) limit_ms = std::atol(e);
+  auto wait_for = [&](auto pred) {
+    if (limit_ms <= 0) {
+      g.cv.wait(lock, pred);
+      return true;
+    }
+    return g.cv.wait_for(lock, std::chrono::milliseconds(limit_ms), pred);
+  };
+  auto timed_out = [&]() {
+    g.aborted = true;
+    g.cv.notify_all();
+    if (err && cap) snprintf(err, cap, "gave up waiting for the peers of the collective; the communicator has been aborted");
+    return 1;
+  };
   if (g.aborted) return aborted();
   // the previous collective's send buffers are released once everybody has left it
-  g.cv.wait(lock, [&] { return g.departed == 0 || g.aborted; });
+  if (!wait_for([&] { return g.departed == 0 || g.aborted; })) return timed_out();
   if (g.aborted) return aborted();
   g.send[c->rank] = send;
   const long gen = g.generation;
@@ -375,7 +394,10 @@ int comm_all_gather(Comm* c, const void* send, void* recv, size_t bytes_per_rank
     g.arrived = 0, g.departed = g.world, g.generation++;
     g.cv.notify_all();
   } else {
-    g.cv.wait(lock, [&] { return g.generation != gen || g.aborted; });
+    if (!wait_for([&] { return g.generation != gen || g.aborted; })) {
+      g.arrived--;
+      return timed_out();
+    }
     if (g.generation == gen) return aborted();
   }
   for (int r = 0; r < g.world; r++) memmove((char*)recv + (size_t)r * bytes_per_rank, g.send[r], bytes_per_rank);

@@ -646,6 +646,31 @@ def test_sharded_batch_rank_that_leaves_between_the_collectives_aborts_the_commu
     assert rc0 == L.HGS_ERR_COMM and rc1 == L.HGS_ERR_INTERNAL
 
 
+def test_sharded_batch_rank_whose_peer_never_enters_gives_up_after_the_deadline(simt_library):
+    """One rank calls the collective, the other never does (a SLAM process that died before the detection): the caller must come back with
+    HGS_ERR_COMM after HGS_COMM_TIMEOUT_MS instead of waiting for ever, and its engine stays usable for unsharded work."""
+    from hdl_graph_slam_amd import _lib as L, workloads
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    import time
+    wl = workloads.make_loop_closure_set("VLP-16", scene_seed=4, n_candidates=2, n_distinct=2, downsample=0.5)
+    uid = RegistrationHIP.comm_unique_id()
+    reg = select_registration_method({"registration_method": "FAST_GICP"}, device_id=0)
+    reg.setInputTarget(wl.target)
+    reg.comm_init(0, 2, uid)   # world size 2, the second rank never joins the collective
+    os.environ["HGS_COMM_TIMEOUT_MS"] = "300"
+    try:
+        t0 = time.time()
+        rec, best, rc = reg.loop_match_batch_sharded([reg.upload(wl.candidates[0])], [0], [wl.guesses[0]], 2, 4.0, return_status=True)
+        waited = time.time() - t0
+    finally:
+        del os.environ["HGS_COMM_TIMEOUT_MS"]
+    assert rc == L.HGS_ERR_COMM and 0.25 < waited < 30.0, (rc, waited)
+    rec1, best1 = reg.loop_match_batch([reg.upload(c) for c in wl.candidates], wl.guesses, 4.0)   # the engine itself is fine
+    assert rec1["converged"].all()
+    reg.close()
+
+
 def test_nn1_with_equidistant_target_points(simt_library):
     """The quad walk's min-only leaves + resolve + keyed-walk fallback on duplicated / regular-grid targets (PC docstring)."""
     PC.check_nn1_with_equidistant_targets(_engine)
