@@ -646,6 +646,32 @@ def test_sharded_batch_rank_that_leaves_between_the_collectives_aborts_the_commu
     assert rc0 == L.HGS_ERR_COMM and rc1 == L.HGS_ERR_INTERNAL
 
 
+def test_ndt_pass_with_one_block_and_long_runs_of_one_problem(simt_library):
+    """k_ndt_pass's LDS lane slots hold at most kNdtFlushTiles tiles of one problem between flushes (their integer sums must stay below 2^56): with ONE
+    resident block a 12 k-point cloud is 48 consecutive tiles of one problem on that block, so the forced mid-run flush runs — and the result is still
+    the oracle's exact-sum result bit for bit (the sums do not depend on how the tiles were grouped)."""
+    tgt, src, T = synth.make_pair("VLP-16", 1, downsample=0.18)
+    assert len(src) > 33 * 256, len(src)
+    p = O.default_params(O.HGS_NDT_OMP)
+    p.resolution, p.neighbor_search = 1.0, O.HGS_DIRECT7
+    o = O.OracleRegistration(p).set_ndt_sum_mode(1)
+    o.setInputTarget(tgt)
+    o.setInputSource(src)
+    guess = T @ synth.pose_matrix([0.05, -0.03, 0.0], [0.0, 0.0, 0.004])
+    ro = o.align(guess)
+    for resident in ("1", "3"):
+        os.environ["HGS_NDT_RESIDENT"] = resident
+        try:
+            e = _engine(p)
+        finally:
+            del os.environ["HGS_NDT_RESIDENT"]
+        e.setInputTarget(tgt)
+        e.setInputSource(src)
+        r = e.align(guess)
+        assert r.iterations == ro.iterations and bytes(r.final_transformation) == bytes(ro.final_transformation), (resident, r.iterations, ro.iterations)
+        e.close()
+
+
 def test_sharded_batch_rank_whose_peer_never_enters_gives_up_after_the_deadline(simt_library):
     """One rank calls the collective, the other never does (a SLAM process that died before the detection): the caller must come back with
     HGS_ERR_COMM after HGS_COMM_TIMEOUT_MS instead of waiting for ever, and its engine stays usable for unsharded work."""
