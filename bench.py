@@ -277,27 +277,27 @@ def run_loop_batch(ctx):
         v = measure_loop_batch(ctx, method, B, max(2, steps // 4), 1, with_cpu=False, with_resident=False, max_range=4.0)
         out["fitness_score_max_range_4"] = {k: v[k] for k in ("value", "ms_per_step", "steps", "converged", "best_candidate", "num_inliers_mean")}
     if a.config == 0 and method == "FAST_GICP" and not a.no_ndt_record and world == 1:
-        nd = measure_loop_batch(ctx, "NDT_OMP", B, a.ndt_steps, 1, with_cpu=not a.no_cpu_baseline, with_resident=False, max_range=None)
-        out["ndt_omp"] = {k: nd[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
+        nd = measure_loop_batch(ctx, "NDT_OMP", B, a.ndt_steps, 1, with_cpu=not a.no_cpu_baseline, with_resident=False, max_range=None, sub_record=True)
+        out["ndt_omp"] = {k: nd[k] for k in ("value", "unit", "steps", "warmup", "warmup_steps_run", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
                                              "mean_linearizations", "pose_rmse_vs_ground_truth", "best_candidate", "roofline", "cpu_baseline")}
         out["ndt_omp"]["workload"] = nd["config"]["workload"]
     if a.config == 0 and method == "FAST_GICP" and not a.regularization and not a.no_plane_record and not a.no_ndt_record and world == 1:
         # fast_gicp's constructor default is not pinned by the reference (it never calls setRegularizationMethod, registrations.cpp:27-36, and clones an
         # unpinned fast_gicp master): FROBENIUS according to SURVEY A.2, PLANE according to the round-3 judge.  Until someone reads fast_gicp HEAD both
         # lines are the metric: `value` is FROBENIUS, this sub-record is the same workload under PLANE (k_knn_cov's eigen-decomposition instantiation)
-        pl = measure_loop_batch(ctx, method, B, max(8, steps // 2), 1, with_cpu=not a.no_cpu_baseline, with_resident=False, max_range=None, regularization="PLANE")
-        out["fast_gicp_plane"] = {k: pl[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
+        pl = measure_loop_batch(ctx, method, B, max(16, steps), 1, with_cpu=not a.no_cpu_baseline, with_resident=False, max_range=None, regularization="PLANE", sub_record=True)
+        out["fast_gicp_plane"] = {k: pl[k] for k in ("value", "unit", "steps", "warmup", "warmup_steps_run", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
                                                      "mean_linearizations", "pose_rmse_vs_ground_truth", "best_candidate", "roofline", "cpu_baseline")}
         out["fast_gicp_plane"]["workload"] = pl["config"]["workload"]
     if a.config == 0 and method == "FAST_GICP" and not a.mild_set and not a.no_ndt_record and world == 1:
         # continuity with BENCH_r01 / BENCH_r02: the candidate set those lines were measured on (never `value`)
-        r2 = measure_loop_batch(ctx, method, B, max(4, steps // 2), 1, with_cpu=False, with_resident=False, max_range=None, mild=True, check_all=False)
+        r2 = measure_loop_batch(ctx, method, B, max(4, steps // 2), 1, with_cpu=False, with_resident=False, max_range=None, mild=True, check_all=False, sub_record=True)
         out["r02_candidate_set"] = {k: r2[k] for k in ("value", "unit", "steps", "ms_per_step", "mean_iterations", "converged")}
         out["r02_candidate_set"]["workload"] = r2["config"]["workload"]
     return out
 
 
-def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, max_range, mild=None, regularization=None, check_all=True):
+def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, max_range, mild=None, regularization=None, check_all=True, sub_record=False):
     a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
     cfg4 = a.config == 4
     sensor = a.sensor or ("HDL-32E" if cfg4 else "HDL-64E")
@@ -378,8 +378,11 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
     wl, d_target, d_cands = load(0)
     n_pts = [len(c) for c in wl.candidates]
     step = make_step(wl, d_target, d_cands)
-    for _ in range(a.warmup):
+    # untimed warm-up: the requested steps, and for a sub-record (measured after another engine's CPU check, with the clocks idle in between) at least 0.1 s of them
+    n_warm, t_warm = 0, time.perf_counter()
+    while n_warm < a.warmup or (sub_record and time.perf_counter() - t_warm < 0.1 and n_warm < 64):
         step()
+        n_warm += 1
     dt, per_step, rec, best = timed(step, steps)
     dt = max_over_ranks(ctx, dt)
 
@@ -499,7 +502,7 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
                     {"candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": method,
                      "distinct_scans": min(set_kwargs.get("n_distinct", 16), B),
                      "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU", "exchange": exchange["kind"]})
-    out.update({"step_ms": percentiles(per_step), "timed_region_s": round(dt, 3),
+    out.update({"step_ms": percentiles(per_step), "timed_region_s": round(dt, 3), "warmup_steps_run": n_warm,
                 "value_by_scene_seed": by_seed, "value_mean_std_over_seeds": [round(float(np.mean(by_seed)), 1), round(float(np.std(by_seed)), 1)],
                 "mean_iterations_by_scene_seed": its_by_seed,
                 "pose_rmse_vs_ground_truth": {"translation_m": round(rmse_t, 5), "rotation_rad": round(rmse_r, 6), "within_0.3m_0.02rad": within, "of": len(et)},
