@@ -276,11 +276,10 @@ def run_loop_batch(ctx):
     if cfg4 and a.fitness_max_range_variant and world == 1:
         v = measure_loop_batch(ctx, method, B, max(2, steps // 4), 1, with_cpu=False, with_resident=False, max_range=4.0)
         out["fitness_score_max_range_4"] = {k: v[k] for k in ("value", "ms_per_step", "steps", "converged", "best_candidate", "num_inliers_mean")}
-    if a.config == 0 and method == "FAST_GICP" and not a.no_ndt_record and world == 1:
-        nd = measure_loop_batch(ctx, "NDT_OMP", B, a.ndt_steps, 1, with_cpu=not a.no_cpu_baseline, with_resident=False, max_range=None, sub_record=True)
-        out["ndt_omp"] = {k: nd[k] for k in ("value", "unit", "steps", "warmup", "warmup_steps_run", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
-                                             "mean_linearizations", "pose_rmse_vs_ground_truth", "best_candidate", "roofline", "cpu_baseline")}
-        out["ndt_omp"]["workload"] = nd["config"]["workload"]
+    # Order of the sub-records: the two FAST_GICP ones first, NDT_OMP last.  Measured (round 4): a FAST_GICP engine that starts after an NDT_OMP record of the same
+    # process runs its batch 8-9 % slower (PLANE 9.1 instead of 8.3 ms per step; every step alike, with or without the CPU legs), an NDT_OMP engine does not care
+    # what ran before it; two engines of any kind one after the other in a bare process do not show it (scripts/probes/second_engine.py).  Not understood yet —
+    # every record is therefore measured in the state a process of its own would give it.
     if a.config == 0 and method == "FAST_GICP" and not a.regularization and not a.no_plane_record and not a.no_ndt_record and world == 1:
         # fast_gicp's constructor default is not pinned by the reference (it never calls setRegularizationMethod, registrations.cpp:27-36, and clones an
         # unpinned fast_gicp master): FROBENIUS according to SURVEY A.2, PLANE according to the round-3 judge.  Until someone reads fast_gicp HEAD both
@@ -294,6 +293,11 @@ def run_loop_batch(ctx):
         r2 = measure_loop_batch(ctx, method, B, max(4, steps // 2), 1, with_cpu=False, with_resident=False, max_range=None, mild=True, check_all=False, sub_record=True)
         out["r02_candidate_set"] = {k: r2[k] for k in ("value", "unit", "steps", "ms_per_step", "mean_iterations", "converged")}
         out["r02_candidate_set"]["workload"] = r2["config"]["workload"]
+    if a.config == 0 and method == "FAST_GICP" and not a.no_ndt_record and world == 1:
+        nd = measure_loop_batch(ctx, "NDT_OMP", B, a.ndt_steps, 1, with_cpu=not a.no_cpu_baseline, with_resident=False, max_range=None, sub_record=True)
+        out["ndt_omp"] = {k: nd[k] for k in ("value", "unit", "steps", "warmup", "warmup_steps_run", "ms_per_step", "step_ms", "timed_region_s", "dtype", "converged", "mean_iterations",
+                                             "mean_linearizations", "pose_rmse_vs_ground_truth", "best_candidate", "roofline", "cpu_baseline")}
+        out["ndt_omp"]["workload"] = nd["config"]["workload"]
     return out
 
 
