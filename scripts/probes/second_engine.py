@@ -6,6 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from hdl_graph_slam_amd import workloads, _lib as L
 from hdl_graph_slam_amd.registrations import select_registration_method
 
+if os.environ.get("PROBE_TORCH"):
+    import torch
+    torch.cuda.set_device(0)
+    torch.cuda.synchronize()
 first = sys.argv[1] if len(sys.argv) > 1 else "none"
 keep = len(sys.argv) > 2 and sys.argv[2] == "keep"
 wl = workloads.make_loop_closure_set("HDL-64E", 0, 64)
