@@ -128,8 +128,8 @@ HGS_HD double ndt_exp(double x) {
   if (x > 90.0) return INFINITY;     // above FLT_MAX
   const double kd = rint(x * 0x1.71547652b82fep+0);
   const double r = fma(-kd, 0x1.a39ef35793c76p-33, fma(-kd, 0x1.62e42fee00000p-1, x));
-  double p = 0x1.6124613a86d09p-33;
-  p = HGS_NDT_HORNER(p, r, 0x1.1eed8eff8d898p-29);
+  // (first step with the leading coefficient as the scalar factor: as a literal it would sit in a vector register pair for the whole kernel)
+  double p = HGS_NDT_HORNER(r, HGS_NDT_EXP_COEFF(0x1.6124613a86d09p-33), 0x1.1eed8eff8d898p-29);
   p = HGS_NDT_HORNER(p, r, 0x1.ae64567f544e4p-26);
   p = HGS_NDT_HORNER(p, r, 0x1.27e4fb7789f5cp-22);
   p = HGS_NDT_HORNER(p, r, 0x1.71de3a556c734p-19);
