@@ -136,8 +136,8 @@ struct hgs_handle {
   hipStream_t stream = nullptr;
   // extra streams of a batch (run_batch): the problems are split into lanes whose launch chains are independent, so the
   // block-per-problem solve / decide kernels of one lane run under the point kernels of the others
-  hipStream_t lane_stream[3] = {};
-  hipEvent_t lane_event[4] = {};
+  hipStream_t lane_stream[7] = {};  // kMaxLanes - 1
+  hipEvent_t lane_event[8] = {};
   int nn_qpw = 0;  // 0: chosen per launch (nn_queries_per_wave)
   // levels of the Hilbert curve the index sort compares (HGS_HILBERT_LEVELS, A/B runs; 16 = all 48 bits, rounds 1-3).  64 x 119 k batch, index stage / step:
   // 16 -> 0.915 / 11.99 ms, 13 -> 0.83 / 11.93, 11 -> 0.75 / 11.91, 10 -> 0.75 / 12.1, 9 -> 0.75 / 12.7 (the walks slow down once a cell of the finest compared
@@ -157,7 +157,7 @@ struct hgs_handle {
   float final_T[16];
 
   DeviceBuffer staging, sort_keys[2], sort_vals[2], sort_tmp, descs, states, angles, partials, partials_err, results, guesses, done, misc;
-  DeviceBuffer lane_partials[3], lane_partials_err[3];
+  DeviceBuffer lane_partials[7], lane_partials_err[7];
   DeviceBuffer ndt_accum;  // NdtAccum per problem of the running NDT batch
   hgs::Comm* comm = nullptr;            // hgs_comm_init: the ranks of a sharded loop-closure batch
   DeviceBuffer comm_send, comm_recv, comm_ids;
@@ -599,7 +599,17 @@ NdtConsts ndt_consts(const hgs_params& p) {
   return c;
 }
 
-constexpr int kMaxLanes = 4;  // one per hardware queue the HIP runtime uses by default
+// The lanes of a batch are HIP streams, and what makes them concurrent is that the runtime puts them on different hardware queues — of which it uses
+// 4 by default.  One engine's four lanes get one each; but in a process that creates engines one after the other (measured: FAST_GICP, then NDT_OMP
+// with its three lanes, then FAST_GICP again) two lanes of the third engine end up on ONE queue and its batch runs 8 % slower (8.96 instead of 8.33 ms per
+// step; scripts/probes/second_engine.py), and so would an odometry engine and a loop-closure engine living in one nodelet manager.  With 8 queues the
+// effect is gone and a single engine is exactly as fast (profiles/r04_lanes_queues.log).  GPU_MAX_HW_QUEUES is read once, when the HIP runtime
+// initialises: this library asks for 8 when it is loaded, unless the variable is already set — effective when nothing has touched HIP before.
+struct HwQueuesDefault {
+  HwQueuesDefault() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+};
+const HwQueuesDefault g_hw_queues_default;
+constexpr int kMaxLanes = 8;  // HGS_BATCH_LANES up to 8 (A/B runs); the default choice stays at 3-4: one per hardware queue the HIP runtime uses by default
 
 // Progress mirror of one lane of a batch: device counters + two ints of host-mapped pinned memory the kernels write into.
 int make_progress(hgs_handle* h, int lane, int B, Progress* out) {
@@ -631,7 +641,7 @@ int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t pa
   // round 3, 64 x 119 k FAST_GICP batch: 1 / 2 / 3 / 4 lanes = 5615 / 5755 / 5787 / 5811 registrations/s (round 2's kernels preferred 2 above 32 problems)
   // NDT (one launch per iteration, work queue inside): 2 / 3 / 4 lanes = 1679 / 1724 / 1652 on the 64-candidate batch (round 2: 1403 / 1384 / 1326)
   const int wanted = h->batch_lanes > 0 ? h->batch_lanes : (h->prm.method == HGS_NDT_OMP && B > 32 ? 3 : 4);
-  const int n = h->profiling ? 1 : std::max(1, std::min(std::min(wanted, kMaxLanes), B));
+  const int n = h->profiling ? 1 : std::max(1, std::min(std::min(wanted, kMaxLanes), B));  // (h_flags / done hold 2 ints per lane: 64 bytes = 8 lanes)
   lanes.assign(n, BatchLane{});
   for (int i = 0, b0 = 0; i < n; i++) {
     BatchLane& L = lanes[i];
@@ -1032,7 +1042,7 @@ int hgs_destroy(hgs_handle* h) try {
                           &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum,    &h->ndt_plan,
                           &h->comm_send, &h->comm_recv,    &h->comm_ids};
   for (DeviceBuffer* b : bufs) b->release();
-  for (int i = 0; i < 3; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
+  for (int i = 0; i < kMaxLanes - 1; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
   for (hipEvent_t ev : h->lane_event)
     if (ev) (void)hipEventDestroy(ev);
   if (h->comm_event) (void)hipEventDestroy(h->comm_event);

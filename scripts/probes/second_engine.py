@@ -46,6 +46,14 @@ def run(pnh, n, label):
     return reg, tgt, cands
 
 held = None
+for f in first.split("+")[:-1]:   # "A+B": engines A, then B (the loop below), then the PLANE engine
+    pnh0 = {"registration_method": "NDT_OMP", "reg_resolution": 1.0} if f == "NDT_OMP" else {"registration_method": "FAST_GICP"}
+    reg0, tgt0, cands0 = run(pnh0, 10, f"engine before ({f})")
+    for c in cands0:
+        c.close()
+    tgt0.close()
+    reg0.close()
+first = first.split("+")[-1]
 if first != "none":
     pnh = {"registration_method": "NDT_OMP", "reg_resolution": 1.0} if first == "NDT_OMP" else {"registration_method": "FAST_GICP"}
     if first == "PLANE":
