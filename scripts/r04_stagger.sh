@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD OF A DROPPED EXPERIMENT: the HGS_STAGGER_COV code path this script measured is not in the tree (it lost: profiles/r04_ab4_staggered_cov.log).
 # Staggered per-lane covariance launches of a cold FAST_GICP batch against the one launch in front of the LM loop (HGS_STAGGER_COV=0)
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of the command: the variants it names were built from round 3's scripts/pending patches, which this visit measured and the round removed)
 # Round 4, first GPU visit: same-box A/B of scripts/pending (round 3's unmeasured exact reductions) plus the LDS lane-slot reduction written
 # this round, the MFMA wave sums of k_gicp_linearize, and the grid-barrier probe that decides the single-registration design.
 set -u
