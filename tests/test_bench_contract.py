@@ -59,6 +59,14 @@ def test_single_rank_line():
     assert nd["value"] > 0 and nd["unit"] == "registrations/sec" and nd["steps"] == 2 and nd["dtype"] == "f32" and "NDT_OMP" in nd["workload"]
     assert ROOFLINE <= set(nd["roofline"]) and nd["roofline"]["kernel"] in ("k_ndt_pass", "k_fitness") and nd["cpu_baseline"]["value"] > 0
     assert "SURVEY 8d" in rec["config"]["workload"] and rec["config"]["distinct_scans"] == 2
+    # ... and FAST_GICP under fast_gicp's other candidate default, the PLANE covariance regularisation (round 4: both lines are the metric)
+    pl = rec["fast_gicp_plane"]
+    assert pl["value"] > 0 and "PLANE" in pl["workload"] and pl["roofline"]["kernel"] in ("k_gicp_linearize", "k_knn_cov", "k_fitness", "k_gicp_error")
+    # every engine's cpu_baseline carries the checker's verdict over the WHOLE timed batch (the oracle's sequential loop) next to the sampled rate
+    for c in (cpu, nd["cpu_baseline"], pl["cpu_baseline"]):
+        assert c["candidates_checked"] == 2 and c["iterations_equal"] == 2 and c["converged_flags_equal"] == 2 and c["oracle_argmin_agrees"] is True
+        assert c["max_pose_diff_vs_gpu_m"] < 1e-3 and c["max_pose_diff_vs_gpu_rad"] < 1e-3 and c["value_over_all_candidates"] > 0
+    assert "profiled_step_ms" in rec["roofline"] and "hbm_frac_from_counters" in rec["roofline"]
 
 
 def test_two_ranks_through_torch_distributed_run():
@@ -89,3 +97,8 @@ def test_other_baseline_configs_emit_the_same_contract(config, extra):
     assert ROOFLINE <= set(rec["roofline"]) and rec["cpu_baseline"]["value"] > 0 and {"p10", "p50", "p90"} <= set(rec["step_ms"])
     if config == 3:
         assert "p99" in rec["latency_ms"] and "H2D" in rec["config"]["workload"]
+        # the stream as launch/hdl_graph_slam_kitti.launch runs it: device prefilter in front of NDT_OMP and of the launch file's FAST_GICP
+        for name, method in (("kitti_prefilter_ndt_omp", "NDT_OMP"), ("kitti_launch_fast_gicp", "FAST_GICP")):
+            k = rec[name]
+            assert k["value"] > 0 and method in k["workload"] and "prefilter" in k["workload"] and 0 < k["points_after_prefilter"] < rec["config"]["points_per_cloud"]
+            assert k["oracle_stream"]["max_translation_diff_vs_device_m"] < 1e-3 and k["cpu_baseline"]["value"] > 0
