@@ -8,34 +8,93 @@
 // and every numerically heavy step runs in the HIP library.  The class is logic-free: it forwards and copies results.
 //
 // PCL facts relied on (PCL 1.8-1.12): setInputSource / setInputTarget are virtual; computeTransformation(output, guess) is the
-// pure virtual called by the non-virtual align(), which has already copied *input_ into `output`; converged_,
+// pure virtual called by the non-virtual align(), which has already run initCompute() and copied *input_ into `output`; converged_,
 // final_transformation_, nr_iterations_ are protected members read by hasConverged() / getFinalTransformation().
-// getFitnessScore() and getSearchMethodTarget() are NON-virtual and keep working on PCL's own CPU kd-tree (tree_), which
-// align() builds in initCompute(); callers that want them on the device use fitnessScoreHIP() / nearestTargetHIP() below
-// (LoopDetector's batched path in INTEGRATION.md does).
+//
+// What an integrated system pays per align() besides the device work, and what this adapter does about each item:
+//   * initCompute() calls tree_->setInputCloud(target_) on every NEW target — with PCL's own tree a KdTreeFLANN build on the CPU
+//     (milliseconds for 13 k points, tens of ms for 119 k) that the device engines never use.  The adapter installs a LazyKdTree
+//     (below) with setSearchMethodTarget(): its setInputCloud() only remembers the cloud, and the FLANN index is built at the first
+//     nearestKSearch / radiusSearch — i.e. only if somebody really calls the NON-virtual getFitnessScore() /
+//     getSearchMethodTarget() through the base pointer.  Semantics unchanged, cost moved to the callers that want it.  (Callers
+//     patched by integration/hdl_graph_slam_hip.patch use fitnessScoreHIP() / nearestTargetHIP() instead and never build it.)
+//   * uploads are deferred to the call that needs them: setInputTarget / setInputSource only keep the shared pointer (as PCL does);
+//     a target that is replaced before it is ever aligned against, or an adapter whose batch path is served by LoopMatcherHIP,
+//     never uploads (nor even creates its engine).
+//   * the aligned cloud: pcl::Registration's contract is that align() fills `output` with T * input.  That is a D2H of the whole
+//     cloud (3.8 MB at 119 k points).  LoopDetector::matching discards it (loop_detector.hpp:134,143); setAlignedCloudOutput(false)
+//     skips the download (output then stays the copy of the input that align() made).  Default: on, the PCL contract.
 //
 // Not compilable against the real PCL in this repository's image (no PCL / ROS); tests/test_adapter_cpp.py compiles it against
-// a minimal stand-in of the pcl::Registration interface (tests/mock_pcl) and runs it on the GPU through the real library.
+// a stand-in of the pcl::Registration / pcl::search::KdTree interfaces (tests/mock_pcl) and runs it on the GPU through the real library.
 //
-// Life cycle: a setter that changes an engine parameter after the engine exists re-creates the engine (recreate()); the
-// adapter's own target / source are uploaded again, but hgs_cloud handles a caller obtained through nativeHandle() belong to
+// Life cycle: a setter that changes an engine parameter after the engine exists drops the engine (recreate()); the next call that needs
+// one creates it and uploads the clouds pcl::Registration holds.  hgs_cloud handles a caller obtained through nativeHandle() belong to
 // the destroyed engine — hgs_destroy orphans them (safe to hgs_cloud_destroy, rejected by every other call), so configure the
 // object fully (the factory does) before caching device clouds.
 #pragma once
 
+#include <atomic>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
+#include <pcl/search/kdtree.h>
 #include <pcl/registration/registration.h>
 
 #include "hgs_registration.h"
 
 namespace hgs_hip {
+
+// pcl::search::KdTree whose index is built at the first query instead of at setInputCloud() (see the header comment).  Thread-safe
+// the way PCL's tree is used: queries are const and may come from several threads; the one-time build is guarded.
+template <typename PointT>
+class LazyKdTree : public pcl::search::KdTree<PointT> {
+  using Base = pcl::search::KdTree<PointT>;
+
+public:
+  using PointCloudConstPtr = typename Base::PointCloudConstPtr;
+  using IndicesConstPtr = typename Base::IndicesConstPtr;
+#if PCL_VERSION_COMPARE(>=, 1, 12, 0)
+  bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override {
+    remember(cloud, indices);
+    return true;
+  }
+#else
+  void setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override { remember(cloud, indices); }
+#endif
+  int nearestKSearch(const PointT& p, int k, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances) const override {
+    ensure_built();
+    return Base::nearestKSearch(p, k, k_indices, k_sqr_distances);
+  }
+  int radiusSearch(const PointT& p, double radius, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances, unsigned int max_nn = 0) const override {
+    ensure_built();
+    return Base::radiusSearch(p, radius, k_indices, k_sqr_distances, max_nn);
+  }
+  bool built() const { return built_.load(std::memory_order_acquire); }
+
+private:
+  void remember(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    this->input_ = cloud;      // what getInputCloud() returns
+    this->indices_ = indices;
+    built_.store(false, std::memory_order_release);
+  }
+  void ensure_built() const {
+    if (built_.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lock(mutex_);
+    if (built_.load(std::memory_order_relaxed)) return;
+    const_cast<LazyKdTree*>(this)->Base::setInputCloud(this->input_, this->indices_);  // the real (FLANN) build, once per target that is queried
+    built_.store(true, std::memory_order_release);
+  }
+  mutable std::mutex mutex_;
+  mutable std::atomic<bool> built_{false};
+};
 
 template <typename PointSource, typename PointTarget>
 class RegistrationHIP : public pcl::Registration<PointSource, PointTarget, float> {
@@ -56,6 +115,8 @@ public:
     this->reg_name_ = method == HGS_NDT_OMP ? "hgs_hip::NDT" : (method == HGS_FAST_VGICP ? "hgs_hip::FastVGICP" : "hgs_hip::FastGICP");
     if (hgs_params_default(method, &params_) != HGS_OK) throw std::invalid_argument("RegistrationHIP: unknown method");
     params_.device_id = device_id;
+    lazy_tree_.reset(new LazyKdTree<PointTarget>());
+    this->setSearchMethodTarget(lazy_tree_);  // initCompute() now "builds" this one: a pointer copy
   }
   ~RegistrationHIP() override { hgs_destroy(handle_); }
   RegistrationHIP(const RegistrationHIP&) = delete;
@@ -80,26 +141,22 @@ public:
   // fast_gicp::FastGICP::setRegularizationMethod (hgs_regularization value); never called by hdl_graph_slam
   void setRegularizationMethod(int hgs_regularization_value) { params_.regularization_method = hgs_regularization_value; recreate(); }
 
-  // ---- pcl::Registration virtuals
+  // extension: false = align() does not download T * input into `output` (callers that discard it: LoopDetector::matching)
+  void setAlignedCloudOutput(bool on) { aligned_output_ = on; }
+  const hgs_params& params() const { return params_; }
+  // true once somebody has queried PCL's CPU tree of the current target through the base pointer (tests, diagnostics)
+  bool cpuTreeBuilt() const { return lazy_tree_->built(); }
+
+  // ---- pcl::Registration virtuals: keep the pointer (fast_gicp: same pointer -> keep the cached structures); the upload is deferred
   void setInputSource(const PointCloudSourceConstPtr& cloud) override {
-    if (cloud == this->input_ && handle_) return;  // fast_gicp: same pointer -> keep the cached structures
+    if (cloud == this->input_) return;
     Base::setInputSource(cloud);
-    const bool fresh = !handle_;  // a handle created by this call has uploaded the clouds pcl::Registration holds, this one included
-    if (hgs_handle* hh = handle()) {
-      if (!fresh) check(hgs_set_source(hh, cloud->points.data(), cloud->points.size(), sizeof(PointSource)), "hgs_set_source");
-    } else {
-      check(HGS_ERR_NO_DEVICE, "hgs_set_source");
-    }
+    uploaded_source_ = nullptr;  // (the identity below is only ever compared with the cloud the base class keeps alive)
   }
   void setInputTarget(const PointCloudTargetConstPtr& cloud) override {
-    if (cloud == this->target_ && handle_) return;
+    if (cloud == this->target_) return;
     Base::setInputTarget(cloud);
-    const bool fresh = !handle_;
-    if (hgs_handle* hh = handle()) {
-      if (!fresh) check(hgs_set_target(hh, cloud->points.data(), cloud->points.size(), sizeof(PointTarget)), "hgs_set_target");
-    } else {
-      check(HGS_ERR_NO_DEVICE, "hgs_set_target");
-    }
+    uploaded_target_ = nullptr;
   }
 
   // ---- device versions of the two non-virtual queries the callers use
@@ -117,7 +174,7 @@ public:
                         sq_dists.data()),
           "hgs_nn_target");
   }
-  hgs_handle* nativeHandle() { return handle(); }
+  hgs_handle* nativeHandle() { return handle(); }  // (engine created and the current clouds uploaded if they were not yet)
   const hgs_result& lastResult() const { return last_; }
 
 protected:
@@ -134,7 +191,7 @@ protected:
     this->converged_ = last_.converged != 0;
     this->nr_iterations_ = last_.iterations;
     // align() copied *input_ into output; overwrite xyz with T * input (other fields are kept)
-    hgs_transform_source(handle(), last_.final_transformation, output.points.data(), sizeof(PointSource));
+    if (aligned_output_) check(hgs_transform_source(handle_, last_.final_transformation, output.points.data(), sizeof(PointSource)), "hgs_transform_source");
   }
 
 private:
@@ -143,33 +200,50 @@ private:
   // ends with hasConverged() == false and the guess as the final transformation — the failure signal the callers test
   // (apps/scan_matching_odometry_nodelet.cpp:214, include/hdl_graph_slam/loop_detector.hpp:147).  Creation is retried on the
   // next call.
-  // A (re)created engine holds no clouds: the ones pcl::Registration already has (set while creation was failing, or before a parameter
-  // change) are uploaded right away — otherwise a keyframe set during one transient failure would be lost for good, because a repeated
-  // setInputTarget with the same pointer returns early and scan_matching_odometry only replaces the keyframe after a successful match.
+  // The clouds pcl::Registration holds are uploaded when they differ from what the engine has (deferred from setInputTarget /
+  // setInputSource; also what makes a cloud set during a transient creation failure, or before a parameter change, reach the new engine:
+  // scan_matching_odometry sets its keyframe ONCE and only replaces it after a successful match).
   hgs_handle* handle() {
-    if (handle_) return handle_;
-    if (hgs_create(&params_, &handle_) != HGS_OK) {
-      PCL_ERROR("[%s] hgs_create failed: %s\n", this->reg_name_.c_str(), hgs_last_error(nullptr));
-      handle_ = nullptr;
-      return nullptr;
+    if (!handle_) {
+      if (hgs_create(&params_, &handle_) != HGS_OK) {
+        PCL_ERROR("[%s] hgs_create failed: %s\n", this->reg_name_.c_str(), hgs_last_error(nullptr));
+        handle_ = nullptr;
+        return nullptr;
+      }
+      uploaded_target_ = nullptr, uploaded_source_ = nullptr;
     }
-    if (this->target_) check(hgs_set_target(handle_, this->target_->points.data(), this->target_->points.size(), sizeof(PointTarget)), "hgs_set_target");
-    if (this->input_) check(hgs_set_source(handle_, this->input_->points.data(), this->input_->points.size(), sizeof(PointSource)), "hgs_set_source");
+    if (this->target_ && this->target_.get() != uploaded_target_) {
+      if (check(hgs_set_target(handle_, this->target_->points.data(), this->target_->points.size(), sizeof(PointTarget)), "hgs_set_target"))
+        uploaded_target_ = this->target_.get();
+    }
+    if (this->input_ && this->input_.get() != uploaded_source_) {
+      if (check(hgs_set_source(handle_, this->input_->points.data(), this->input_->points.size(), sizeof(PointSource)), "hgs_set_source"))
+        uploaded_source_ = this->input_.get();
+    }
     return handle_;
   }
-  void recreate() {  // parameters are fixed at creation: drop the engine; handle() uploads the current clouds into the new one
+  void recreate() {  // parameters are fixed at creation: drop the engine; the next handle() creates one and uploads the current clouds
     if (!handle_) return;
     hgs_destroy(handle_);
     handle_ = nullptr;
-    (void)handle();
+    uploaded_target_ = nullptr, uploaded_source_ = nullptr;
   }
-  void check(int rc, const char* what) {
+  bool check(int rc, const char* what) {
     if (rc != HGS_OK) PCL_ERROR("[%s] %s failed (%d): %s\n", this->reg_name_.c_str(), what, rc, hgs_last_error(handle_));
+    return rc == HGS_OK;
   }
 
   hgs_params params_{};
   hgs_handle* handle_ = nullptr;
   hgs_result last_{};
+  bool aligned_output_ = true;
+  const void* uploaded_target_ = nullptr;  // the clouds the engine currently holds (identity only, never dereferenced)
+  const void* uploaded_source_ = nullptr;
+#if PCL_VERSION_COMPARE(>=, 1, 10, 0)
+  pcl::shared_ptr<LazyKdTree<PointTarget>> lazy_tree_;
+#else
+  boost::shared_ptr<LazyKdTree<PointTarget>> lazy_tree_;
+#endif
 };
 
 }  // namespace hgs_hip

@@ -10,7 +10,9 @@
 // HBM, so there is no per-iteration host decision — the host only polls a done-counter.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -149,7 +151,7 @@ struct hgs_handle {
   // 1 / 2 / 3 / 4 lanes = 3680 / 3999 / 3937 / 3913 GICP reg/s and 1064 / 1403 / 1384 / 1326 NDT — with 32 problems per lane a lane's
   // launches fill the device on their own and two chains are enough to cover each other's solves and tails.
   int knn_replay = -1;  // k_knn_cov gather: -1 default (2), 0 tree walk, 1 leaf-log replay, 2 per-lane leaf lists; HGS_KNN_REPLAY (A/B runs, tests)
-  int batch_lanes = 0;  // 0: by batch size (4 up to 32 problems, 2 above); HGS_BATCH_LANES fixes it (A/B runs)
+  int batch_lanes = 0;  // 0: open_lanes chooses (4; NDT_OMP above 32 problems 3; never more than the process's hardware-queue budget has room for); HGS_BATCH_LANES fixes it (A/B runs)
   std::string err;
   hgs_cloud* target = nullptr;
   hgs_cloud* source = nullptr;
@@ -600,16 +602,22 @@ NdtConsts ndt_consts(const hgs_params& p) {
 }
 
 // The lanes of a batch are HIP streams, and what makes them concurrent is that the runtime puts them on different hardware queues — of which it uses
-// 4 by default.  One engine's four lanes get one each; but in a process that creates engines one after the other (measured: FAST_GICP, then NDT_OMP
-// with its three lanes, then FAST_GICP again) two lanes of the third engine end up on ONE queue and its batch runs 8 % slower (8.96 instead of 8.33 ms per
-// step; scripts/probes/second_engine.py), and so would an odometry engine and a loop-closure engine living in one nodelet manager.  With 8 queues the
-// effect is gone and a single engine is exactly as fast (profiles/r04_lanes_queues.log).  GPU_MAX_HW_QUEUES is read once, when the HIP runtime
-// initialises: this library asks for 8 when it is loaded, unless the variable is already set — effective when nothing has touched HIP before.
-struct HwQueuesDefault {
-  HwQueuesDefault() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-};
-const HwQueuesDefault g_hw_queues_default;
-constexpr int kMaxLanes = 8;  // HGS_BATCH_LANES up to 8 (A/B runs); the default choice stays at 3-4: one per hardware queue the HIP runtime uses by default
+// 4 by default (GPU_MAX_HW_QUEUES, read once when the HIP runtime initialises).  One engine's four lanes get one each; in a process that hosts several
+// engines (the nodelet manager: the odometry engine AND the loop-closure engine) streams beyond the queue count share a queue and a batch runs 8 % slower
+// (measured with three engines on 4 queues, profiles/r04_lanes_queues.log; with 8 queues the effect is gone).  The library does NOT touch the
+// environment (rounds 1-4 called setenv from a static initialiser: a plugin must not change its host process).  Instead every stream an engine
+// creates is counted against the process's queue budget — GPU_MAX_HW_QUEUES if the launcher set it (INTEGRATION.md recommends 8), HIP's default 4
+// otherwise — and a batch opens only as many lanes as the budget still has room for (never fewer than one: the engine's own stream).
+std::atomic<int> g_streams_in_use{0};
+int hw_queue_budget() {
+  static const int budget = [] {
+    const char* e = std::getenv("GPU_MAX_HW_QUEUES");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : 4;
+  }();
+  return budget;
+}
+constexpr int kMaxLanes = 8;  // HGS_BATCH_LANES up to 8 (A/B runs); the default choice stays at 3-4 and is further bounded by the queue budget above
 
 // Progress mirror of one lane of a batch: device counters + two ints of host-mapped pinned memory the kernels write into.
 int make_progress(hgs_handle* h, int lane, int B, Progress* out) {
@@ -641,7 +649,15 @@ int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t pa
   // round 3, 64 x 119 k FAST_GICP batch: 1 / 2 / 3 / 4 lanes = 5615 / 5755 / 5787 / 5811 registrations/s (round 2's kernels preferred 2 above 32 problems)
   // NDT (one launch per iteration, work queue inside): 2 / 3 / 4 lanes = 1679 / 1724 / 1652 on the 64-candidate batch (round 2: 1403 / 1384 / 1326)
   const int wanted = h->batch_lanes > 0 ? h->batch_lanes : (h->prm.method == HGS_NDT_OMP && B > 32 ? 3 : 4);
-  const int n = h->profiling ? 1 : std::max(1, std::min(std::min(wanted, kMaxLanes), B));  // (h_flags / done hold 2 ints per lane: 64 bytes = 8 lanes)
+  int n = h->profiling ? 1 : std::max(1, std::min(std::min(wanted, kMaxLanes), B));  // (h_flags / done hold 2 ints per lane: 64 bytes = 8 lanes)
+  // the process's hardware-queue budget (above): lane streams this engine already owns are free, new ones only while there is room.
+  // HGS_BATCH_LANES (A/B runs) overrides the budget.
+  if (h->batch_lanes <= 0) {
+    int owned = 0;
+    while (owned < kMaxLanes - 1 && h->lane_stream[owned]) owned++;
+    const int room = std::max(0, hw_queue_budget() - g_streams_in_use.load(std::memory_order_relaxed));
+    n = std::min(n, 1 + owned + room);
+  }
   lanes.assign(n, BatchLane{});
   for (int i = 0, b0 = 0; i < n; i++) {
     BatchLane& L = lanes[i];
@@ -653,7 +669,10 @@ int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t pa
       L.partials = h->partials.as<double>(), L.partials_err = h->partials_err.as<double>();
       continue;
     }
-    if (!h->lane_stream[i - 1]) HGS_HIP(h, hipStreamCreateWithFlags(&h->lane_stream[i - 1], hipStreamNonBlocking));
+    if (!h->lane_stream[i - 1]) {
+      HGS_HIP(h, hipStreamCreateWithFlags(&h->lane_stream[i - 1], hipStreamNonBlocking));
+      g_streams_in_use.fetch_add(1, std::memory_order_relaxed);
+    }
     L.stream = h->lane_stream[i - 1];
     HGS_HIP(h, h->lane_partials[i - 1].reserve((size_t)L.B * partial_bytes_per_problem));
     HGS_HIP(h, h->lane_partials_err[i - 1].reserve((size_t)L.B * partial_err_bytes_per_problem));
@@ -838,21 +857,34 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     std::vector<LanePlan> plans(lanes.size());
     {
       const size_t per_lane = align_up(16 + ((size_t)B + 1) * sizeof(int), 256);
+      bool tile_overflow = false;
+      constexpr long long kMaxNdtBlocks = 1 << 16, kMaxNdtChunk = 1 << 10;  // far above anything HGS_NDT_RESIDENT / HGS_NDT_CHUNK are used with
       HGS_HIP(h, h->ndt_plan.reserve(per_lane * lanes.size()));
       std::vector<char> host(per_lane * lanes.size(), 0);
       for (size_t li = 0; li < lanes.size(); li++) {
         const BatchLane& L = lanes[li];
         int* tb = reinterpret_cast<int*>(host.data() + li * per_lane + 16);
         tb[0] = 0;
-        for (int k = 0; k < L.B; k++) tb[k + 1] = tb[k] + std::max(1, ((int)sources[L.b0 + k]->n_input + kBlock - 1) / kBlock);
+        // k_ndt_pass does its item arithmetic in 32-bit ints (queue head + blocks * chunk must fit): bound the lane's tile count here
+        long long tiles64 = 0;
+        for (int k = 0; k < L.B; k++) {
+          tiles64 += std::max<long long>(1, ((long long)sources[L.b0 + k]->n_input + kBlock - 1) / kBlock);
+          tile_overflow = tile_overflow || tiles64 > (long long)INT_MAX - (long long)kMaxNdtBlocks * kMaxNdtChunk;
+          tb[k + 1] = tile_overflow ? 0 : (int)tiles64;
+        }
         LanePlan& P = plans[li];
         const int total = tb[L.B];
-        P.blocks = std::max(1, std::min(total, h->ndt_resident_blocks > 0 ? h->ndt_resident_blocks : (lanes.size() > 1 ? 512 : 768)));
+        if (tile_overflow) continue;
+        P.blocks = std::max(1, std::min(total, h->ndt_resident_blocks > 0 ? std::min(h->ndt_resident_blocks, (int)kMaxNdtBlocks) : (lanes.size() > 1 ? 512 : 768)));
         // largest queue grab (the kernel sizes each grab by guided self-scheduling, at most this many items).  Fixed grabs
         // measured on the 16 x 119 k batch with 4 lanes: 1 -> 904, 2 -> 1062, 3 -> 980, 4 -> 936, 8 -> 845 registrations/s
-        P.chunk = h->ndt_chunk > 0 ? h->ndt_chunk : 8;
+        P.chunk = h->ndt_chunk > 0 ? std::min(h->ndt_chunk, (int)kMaxNdtChunk) : 8;
         P.queues = reinterpret_cast<unsigned long long*>((char*)h->ndt_plan.p + li * per_lane);
         P.tile_base = reinterpret_cast<int*>((char*)h->ndt_plan.p + li * per_lane + 16);
+      }
+      if (tile_overflow) {
+        h->err = "NDT batch too large: the tiles of one lane do not fit 32-bit item arithmetic (more than ~5e11 source points in one call)";
+        return HGS_ERR_INVALID_ARGUMENT;
       }
       HGS_HIP(h, hipMemcpy(h->ndt_plan.p, host.data(), host.size(), hipMemcpyHostToDevice));  // synchronous: `host` is pageable and dies here
     }
@@ -1011,6 +1043,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
     delete h;
     return HGS_ERR_HIP;
   }
+  g_streams_in_use.fetch_add(1, std::memory_order_relaxed);
   *out = h;
   return HGS_OK;
 } catch (...) {
@@ -1047,7 +1080,7 @@ int hgs_destroy(hgs_handle* h) try {
     if (ev) (void)hipEventDestroy(ev);
   if (h->comm_event) (void)hipEventDestroy(h->comm_event);
   for (hipStream_t ls : h->lane_stream)
-    if (ls) (void)hipStreamDestroy(ls);
+    if (ls) (void)hipStreamDestroy(ls), g_streams_in_use.fetch_sub(1, std::memory_order_relaxed);
   for (auto& blk : h->block_pool) (void)hipFree(blk.first);
   h->block_pool.clear();
   h->h_descs.release();
@@ -1057,7 +1090,7 @@ int hgs_destroy(hgs_handle* h) try {
   h->h_flags.release();
   for (auto& ev : h->prof_events) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream) (void)hipStreamDestroy(h->stream), g_streams_in_use.fetch_sub(1, std::memory_order_relaxed);
   delete h;
   return HGS_OK;
 } catch (...) {
@@ -1450,8 +1483,11 @@ template <typename Q>
 int comm_wait(hgs_handle* h, Q&& query, const char* what) {
   const long limit_ms = comm_timeout_ms();
   const auto t0 = std::chrono::steady_clock::now();
+  auto next_check = t0 + std::chrono::milliseconds(1);
+  long sleep_us = 0;  // the exchange itself is microseconds: spin for ~100 us, then sleep with exponential backoff up to 1 ms (a rank waiting out peer skew
+                      // must not burn the core that feeds the other lanes and engines)
   char err[256] = "";
-  for (long spins = 0;; spins++) {
+  for (;;) {
     const hipError_t e = query();
     if (e == hipSuccess) return HGS_OK;
     if (e != hipErrorNotReady) {
@@ -1459,20 +1495,25 @@ int comm_wait(hgs_handle* h, Q&& query, const char* what) {
       hgs::comm_abort(h->comm);
       return HGS_ERR_HIP;
     }
-    if ((spins & 63) == 63) {
+    const auto now = std::chrono::steady_clock::now();
+    if (now >= next_check) {  // time-based: once a millisecond, whatever the polling rate
+      next_check = now + std::chrono::milliseconds(1);
       if (hgs::comm_async_error(h->comm, err, sizeof(err)) != 0) {
         h->err = std::string("hgs_loop_match_batch_sharded: the communicator reported an asynchronous error while waiting for ") + what + ": " + err;
         hgs::comm_abort(h->comm);
         return HGS_ERR_COMM;
       }
-      const long waited = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      const long waited = (long)std::chrono::duration_cast<std::chrono::milliseconds>(now - t0).count();
       if (limit_ms > 0 && waited > limit_ms) {
         h->err = std::string("hgs_loop_match_batch_sharded: gave up after ") + std::to_string(waited) + " ms waiting for " + what +
                  " (a peer has left the collective or never entered it); the communicator has been aborted";
         hgs::comm_abort(h->comm);
         return HGS_ERR_COMM;
       }
-      if (spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    if (now - t0 > std::chrono::microseconds(100)) {
+      sleep_us = sleep_us == 0 ? 10 : std::min(1000l, sleep_us * 2);
+      std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
     }
   }
 }
@@ -1485,15 +1526,20 @@ struct CommAbortGuard {
     if (armed) hgs::comm_abort(comm);
   }
 };
-// test hook (tests/test_simt_kernels_host.py, tests/test_distributed.py; never set in production): HGS_FAULT_AFTER_HEADER = "<kind>:<rank>" makes that
-// rank fail between the two collectives — kind "batch": std::bad_alloc where run_batch runs (handled: the rank sends padding and reports after the
-// exchange); kind "guard": an exception outside every handler (the guard aborts the communicator, the peers get HGS_ERR_COMM)
+// test hook, compiled ONLY into the host-emulation build (tests/emul/simt.py passes -DHGS_TESTING; the shipped library has neither the code nor
+// the string): HGS_FAULT_AFTER_HEADER = "<kind>:<rank>" makes that rank fail between the two collectives — kind "batch": std::bad_alloc where
+// run_batch runs (handled: the rank sends padding and reports after the exchange); kind "guard": an exception outside every handler (the guard
+// aborts the communicator, the peers get HGS_ERR_COMM)
+#ifdef HGS_TESTING
 bool fault_after_header(const char* kind, int rank) {
   const char* e = std::getenv("HGS_FAULT_AFTER_HEADER");
   if (!e) return false;
   const size_t n = std::strlen(kind);
   return std::strncmp(e, kind, n) == 0 && e[n] == ':' && std::atoi(e + n + 1) == rank;
 }
+#else
+constexpr bool fault_after_header(const char*, int) { return false; }
+#endif
 }  // namespace
 extern "C" {
 

@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
   unsigned long long* queue = queues + parity;
   if (blockIdx.x == 0 && threadIdx.x == 0) queues[parity ^ 1] = 0ull;
   // the pass's items (tiles of all problems): a scalar, and the item arithmetic below in 32 bits — 64-bit compares have no scalar form and kept a
-  // VGPR pair alive (and spilled) through the whole pass.  The host bounds the count (launch_ndt_pass) so that head + blocks * chunk fits.
+  // VGPR pair alive (and spilled) through the whole pass.  The host bounds the count (run_batch: HGS_ERR_INVALID_ARGUMENT beyond it) so that head + blocks * chunk fits.
   const int n_items = __builtin_amdgcn_readfirstlane(tile_base[B]);
   // Guided self-scheduling: a grab takes (items left) / (2 * blocks) items, between 1 and `chunk` — long runs of one problem's
   // tiles while there is plenty of work (every change of problem costs a flush: ~170 atomics and a ticket round trip), single
@@ -1371,6 +1371,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_ndt_pass(const CloudDesc* __restr
   F3 fxt = {0.f, 0.f, 0.f};
   int fhave = 0, fci[NOFF];
   __shared__ int ci_lds[NOFF][kBlock];
+  // two blocks per CU (__launch_bounds__(kBlock, 2)) only while the static LDS of a block stays under half of the CU's 160 KB
+  static_assert(sizeof(NdtPassShared) + sizeof(int) * NOFF * kBlock <= 80 * 1024, "k_ndt_pass: static LDS above 80 KB drops residency to one block per CU");
   int* const ci_col = &ci_lds[0][threadIdx.x];
   unsigned long long fkv[NOFF];
   unsigned fvmask = 0;

@@ -127,7 +127,7 @@ def scan(scene: Scene, sensor: str, pose: np.ndarray, noise_seed: int, noise_sig
 
     Returns the hits in the SENSOR frame, in firing order, as PointXYZI records (or [n,3] float32)."""
     # Ray casting is 1-2 s per 64-beam revolution on the host; repeated runs of the benchmarks / A-B scripts over the same seeded scenes (a GPU
-    # visit runs bench.py a dozen times) read the revolution back from a scratch directory instead.  HGS_SCAN_CACHE=<dir> (empty: off); the key is
+    # visit runs bench.py a dozen times) read the revolution back from a per-user scratch directory instead (_scan_cache_root).  HGS_SCAN_CACHE=<dir> (empty: off); the key is
     # every input of this function plus this file's own bytes, so an edit to the simulator never meets a stale scan.
     cache = _scan_cache_path(scene, sensor, pose, noise_seed, noise_sigma, max_range, as_xyzi)
     if cache and os.path.exists(cache):
@@ -146,17 +146,39 @@ def scan(scene: Scene, sensor: str, pose: np.ndarray, noise_seed: int, noise_sig
     return out
 
 
-def _scan_cache_path(scene, sensor, pose, noise_seed, noise_sigma, max_range, as_xyzi):
-    root = os.environ.get("HGS_SCAN_CACHE", os.path.join(tempfile.gettempdir(), "hgs_scan_cache"))
+_SELF_DIGEST = None  # sha256 of this file, computed once per process (the cache key's "simulator version")
+
+
+def _scan_cache_root():
+    """HGS_SCAN_CACHE=<dir> (empty: off).  Default: a PER-USER directory (~/.cache/hgs_scan_cache, mode 0700, owned by this user) — not a shared,
+    predictable path under /tmp, where another user could plant files the benchmarks would load as ray-cast scans."""
+    root = os.environ.get("HGS_SCAN_CACHE")
+    explicit = root is not None
+    if root is None:
+        root = os.path.join(os.path.expanduser("~"), ".cache", "hgs_scan_cache")
     if not root:
         return None
     try:
-        os.makedirs(root, exist_ok=True)
+        os.makedirs(root, mode=0o700, exist_ok=True)
+        if not explicit:
+            st = os.stat(root)
+            if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+                return None
     except OSError:
         return None
+    return root
+
+
+def _scan_cache_path(scene, sensor, pose, noise_seed, noise_sigma, max_range, as_xyzi):
+    global _SELF_DIGEST
+    root = _scan_cache_root()
+    if not root:
+        return None
+    if _SELF_DIGEST is None:
+        with open(os.path.abspath(__file__), "rb") as fh:
+            _SELF_DIGEST = hashlib.sha256(fh.read()).digest()
     h = hashlib.sha256()
-    with open(os.path.abspath(__file__), "rb") as fh:
-        h.update(fh.read())
+    h.update(_SELF_DIGEST)
     for f in dataclasses.fields(scene):
         v = getattr(scene, f.name)
         h.update(np.ascontiguousarray(v).tobytes() if isinstance(v, np.ndarray) else repr(v).encode())

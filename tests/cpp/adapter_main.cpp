@@ -80,6 +80,33 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 16; i++) same = same && Tl.data()[i] == T.data()[i];
       std::printf("recovered converged %d same_pose %d\n", (int)broken->hasConverged(), (int)same);
     }
+    {
+      // The CPU kd-tree of pcl::Registration (tree_): align() -> initCompute() must NOT build it (LazyKdTree); the non-virtual
+      // getFitnessScore() / getSearchMethodTarget()->nearestKSearch() through the BASE pointer must still work — they build it then, once
+      // (apps/scan_matching_odometry_nodelet.cpp:307,316 unpatched), and agree with the device versions.
+      auto& builds = pcl::search::KdTree<PointT>::builds_counter();
+      std::printf("cpu_tree_builds_after_aligns %ld built %d\n", builds.load(), (int)hip->cpuTreeBuilt());
+      const double fit_cpu = registration->getFitnessScore();
+      std::printf("cpu_tree_builds_after_getFitnessScore %ld fitness_cpu %.12g\n", builds.load(), fit_cpu);
+      std::vector<int> idx;
+      std::vector<float> d2;
+      registration->getSearchMethodTarget()->nearestKSearch(aligned.points[0], 1, idx, d2);
+      std::vector<int> idx_dev;
+      std::vector<float> d2_dev;
+      pcl::PointCloud<PointT> one;
+      one.points.push_back(aligned.points[0]);
+      hip->nearestTargetHIP(one, idx_dev, d2_dev);
+      std::printf("nn_cpu %d %.9g nn_hip %d %.9g builds %ld\n", idx[0], d2[0], idx_dev[0], d2_dev[0], builds.load());
+      // a new target (keyframe switch, :246): align again -> still no second build; the aligned cloud is optional
+      auto keyframe2 = std::make_shared<pcl::PointCloud<PointT>>(*filtered);
+      registration->setInputTarget(keyframe2);
+      hip->setAlignedCloudOutput(false);
+      pcl::PointCloud<PointT> untouched;
+      registration->align(untouched, pcl::MockMatrix4f::Identity());
+      bool is_input = untouched.size() == filtered->size();
+      for (size_t i = 0; is_input && i < untouched.size(); i++) is_input = untouched.points[i].x == filtered->points[i].x && untouched.points[i].z == filtered->points[i].z;
+      std::printf("new_target converged %d builds %d output_is_input_copy %d\n", (int)registration->hasConverged(), (int)builds.load(), (int)is_input);
+    }
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 3;

@@ -35,7 +35,7 @@ def build() -> str | None:
     for src in srcs:
         obj = os.path.join(HERE, "_simt_" + os.path.basename(src) + ".o")
         cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-fno-strict-aliasing", "-ffp-contract=off", "-Wno-unknown-attributes",
-               "-Wno-unused-value", "-Wno-pass-failed", "-I", os.path.join(HERE, "simt"), "-c", src, "-o", obj]
+               "-Wno-unused-value", "-Wno-pass-failed", "-DHGS_TESTING", "-I", os.path.join(HERE, "simt"), "-c", src, "-o", obj]
         subprocess.run(cmd, check=True)
         objs.append(obj)
     subprocess.run([cxx, "-shared", "-o", LIB + ".tmp", *objs], check=True)

@@ -1,0 +1,81 @@
+"""TEST INFRASTRUCTURE: applies integration/hdl_graph_slam_hip.patch to a scratch copy of the reference files it touches and compiles
+the patched src/hdl_graph_slam/registrations.cpp + a driver that includes the patched include/hdl_graph_slam/loop_detector.hpp
+(tests/cpp/integration_main.cpp) against the stand-in headers of tests/mock_ros, tests/mock_pcl, tests/mock_eigen.
+
+The reference tree exists only in the build container (/root/reference): the binaries land in integration/_build/ (git-ignored, like every
+built artefact; NOT gpurun-ignored, so they travel to the GPU box the way the .so files do) and the `-m gpu` test runs the prebuilt one.
+The patched scratch copy lives in a temporary directory and is deleted: no reference source enters this repository."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+PATCH = os.path.join(ROOT, "integration", "hdl_graph_slam_hip.patch")
+OUT = os.path.join(ROOT, "integration", "_build")
+PATCHED = ["CMakeLists.txt", "src/hdl_graph_slam/registrations.cpp", "include/hdl_graph_slam/loop_detector.hpp", "apps/scan_matching_odometry_nodelet.cpp"]
+UNTOUCHED = ["include/hdl_graph_slam/registrations.hpp", "include/hdl_graph_slam/keyframe.hpp", "include/hdl_graph_slam/graph_slam.hpp"]
+
+
+def have_reference() -> bool:
+    return all(os.path.exists(os.path.join(REFERENCE, f)) for f in PATCHED + UNTOUCHED)
+
+
+def exe(kind: str) -> str:
+    return os.path.join(OUT, "integration_main" + ("_simt" if kind == "simt" else ""))
+
+
+def _deps(lib):
+    d = [PATCH, lib, os.path.join(ROOT, "tests", "cpp", "integration_main.cpp"), os.path.join(ROOT, "adapters", "registration_hip.hpp"),
+         os.path.join(ROOT, "adapters", "loop_match_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"), os.path.abspath(__file__)]
+    for mock in ("mock_ros", "mock_pcl", "mock_eigen"):
+        for base, _, files in os.walk(os.path.join(ROOT, "tests", mock)):
+            d += [os.path.join(base, f) for f in files]
+    return d
+
+
+def apply_patch(dst: str) -> None:
+    """Copies the files the patch touches (+ the three untouched headers the patched ones include) into dst and applies the patch there."""
+    for f in PATCHED + UNTOUCHED:
+        os.makedirs(os.path.dirname(os.path.join(dst, f)), exist_ok=True)
+        shutil.copy(os.path.join(REFERENCE, f), os.path.join(dst, f))
+    subprocess.run(["git", "apply", "--whitespace=nowarn", PATCH], cwd=dst, check=True)
+
+
+def build(kind: str = "hip") -> str | None:
+    """kind "hip": linked with hdl_graph_slam_amd/lib/libhgs_hip.so (runs on the GPU box); "simt": with tests/emul/libhgs_simt.so (the kernels
+    emulated on the host).  Returns the executable, or None when it cannot be (re)built here and no prebuilt one exists."""
+    if kind == "simt":
+        from emul import simt
+        lib = simt.build()
+        if lib is None:
+            return None
+    else:
+        from hdl_graph_slam_amd import build as hip_build
+        lib = hip_build.build_lib()
+    out = exe(kind)
+    if not have_reference():
+        return out if os.path.exists(out) else None
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in _deps(lib)):
+        return out
+    os.makedirs(OUT, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        apply_patch(tmp)
+        inc = []
+        for d in (os.path.join(ROOT, "tests", "mock_ros"), os.path.join(ROOT, "tests", "mock_pcl"), os.path.join(ROOT, "tests", "mock_eigen"),
+                  os.path.join(tmp, "include"), os.path.join(ROOT, "include"), os.path.join(ROOT, "adapters")):
+            inc += ["-I", d]
+        flags = ["g++", "-std=c++17", "-O1", "-Wall", "-DUSE_HGS_HIP", *inc]
+        subprocess.run([*flags, "-c", os.path.join(tmp, "src", "hdl_graph_slam", "registrations.cpp"), "-o", os.path.join(tmp, "registrations.o")], check=True)
+        subprocess.run([*flags, "-c", os.path.join(ROOT, "tests", "cpp", "integration_main.cpp"), "-o", os.path.join(tmp, "main.o")], check=True)
+        # the factory must also still build WITHOUT the backend (the patch is all #ifdef USE_HGS_HIP)
+        subprocess.run([f for f in flags if f != "-DUSE_HGS_HIP"] + ["-fsyntax-only", os.path.join(tmp, "src", "hdl_graph_slam", "registrations.cpp")], check=True)
+        libdir = os.path.dirname(lib)
+        rpath = "$ORIGIN/" + os.path.relpath(libdir, OUT)
+        link = ["-l:libhgs_simt.so"] if kind == "simt" else ["-lhgs_hip"]
+        subprocess.run(["g++", os.path.join(tmp, "registrations.o"), os.path.join(tmp, "main.o"), "-o", out + ".tmp", "-L", libdir, *link, "-pthread", f"-Wl,-rpath,{rpath}"], check=True)
+        os.replace(out + ".tmp", out)
+    return out

@@ -1,17 +1,26 @@
 // Minimal stand-in for <pcl/point_cloud.h> (TEST ONLY).
 #pragma once
+#include <cstddef>
 #include <memory>
 #include <vector>
 #define PCL_VERSION_CALC(a, b, c) ((a) * 100000 + (b) * 100 + (c))
 #define PCL_VERSION PCL_VERSION_CALC(1, 10, 0)
+#define PCL_VERSION_COMPARE(OP, MAJ, MIN, PATCH) (PCL_VERSION OP PCL_VERSION_CALC(MAJ, MIN, PATCH))
 namespace pcl {
 template <typename T>
 using shared_ptr = std::shared_ptr<T>;
+using IndicesConstPtr = std::shared_ptr<const std::vector<int>>;
 template <typename PointT>
 struct PointCloud {
   using Ptr = std::shared_ptr<PointCloud<PointT>>;
   using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
   std::vector<PointT> points;
   size_t size() const { return points.size(); }
+  bool empty() const { return points.empty(); }
+  void resize(size_t n) { points.resize(n); }
+  const PointT& at(size_t i) const { return points.at(i); }
+  PointT& at(size_t i) { return points.at(i); }
+  const PointT& operator[](size_t i) const { return points[i]; }
+  PointT& operator[](size_t i) { return points[i]; }
 };
 }  // namespace pcl

@@ -1,0 +1,4 @@
+// Minimal stand-in for <pcl/registration/gicp.h> (TEST ONLY).
+#pragma once
+#include <third_party_stub.h>
+HGS_TEST_STUB_ENGINE(pcl, GeneralizedIterativeClosestPoint)

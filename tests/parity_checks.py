@@ -346,3 +346,18 @@ def check_nn1_on_small_trees(make_engine, sizes=(21, 24, 25, 31, 32, 33, 63, 64,
         check_fitness(e, o, synth.pose_matrix([0.1, 0.0, 0.0], [0.0, 0.0, 0.02]), max_ranges=(np.finfo(np.float64).max, 4.0))
         if hasattr(e, "close"):
             e.close()
+
+
+def check_adapter_lazy_tree_lines(out):
+    """Lines 6-9 of tests/cpp/adapter_main.cpp: pcl::Registration's CPU kd-tree behind the adapter (adapters/registration_hip.hpp, LazyKdTree).
+    align() -> initCompute() builds nothing; the non-virtual getFitnessScore() / getSearchMethodTarget() through the base pointer build it once and
+    agree with the device; a new target does not build again; setAlignedCloudOutput(false) leaves align()'s copy of the input in `output`."""
+    assert out[6] == "cpu_tree_builds_after_aligns 0 built 0", out[6]
+    f = out[7].split()
+    assert f[0] == "cpu_tree_builds_after_getFitnessScore" and int(f[1]) == 1
+    fit_hip = float(out[2].split()[1])
+    assert abs(float(f[3]) - fit_hip) <= 1e-6 * max(1.0, abs(fit_hip)), (f[3], fit_hip)   # both exact 1-NN; the float transform differs by rounding only
+    g = out[8].split()
+    assert g[0] == "nn_cpu" and g[3] == "nn_hip" and int(g[7]) == 1
+    assert int(g[1]) == int(g[4]) and abs(float(g[2]) - float(g[5])) <= 1e-6 * max(1e-6, float(g[2]))
+    assert out[9] == "new_target converged 1 builds 1 output_is_input_copy 1", out[9]

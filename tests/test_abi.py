@@ -102,3 +102,17 @@ def test_select_best_is_the_sequential_rule(L):
     rec["converged"] = 1
     rec["fitness_score"] = np.finfo(np.float64).max   # score == DBL_MAX is not > best_score: accepted (loop_detector.hpp:147)
     assert select_best(rec) == 5
+
+
+def test_the_shipped_library_leaves_its_host_process_alone(L):
+    """A plugin loaded into a nodelet manager must not change the process it is loaded into: no setenv / putenv (rounds 1-4 asked for 8 hardware
+    queues from a static initialiser), and the fault-injection hook of the sharded batch exists only in the host-emulation build (-DHGS_TESTING)."""
+    import subprocess
+    so = L.LIB_PATH
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\b(setenv|putenv|unsetenv)\b", undefined), "the library must not modify the environment"
+    blob = open(so, "rb").read()
+    assert b"HGS_FAULT_AFTER_HEADER" not in blob, "test hook compiled into the product"
+    before = dict(os.environ)
+    L.lib()
+    assert dict(os.environ) == before

@@ -19,9 +19,10 @@ def _build():
     from hdl_graph_slam_amd import build as hip_build
     lib = hip_build.build_lib()
     src = os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp")
-    deps = [src, os.path.join(ROOT, "adapters", "registration_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"), lib]
+    deps = [src, os.path.join(ROOT, "adapters", "registration_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"), lib,
+            os.path.join(ROOT, "tests", "mock_pcl", "pcl", "registration", "registration.h"), os.path.join(ROOT, "tests", "mock_pcl", "pcl", "search", "kdtree.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
-        subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "tests", "mock_pcl"), "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+        subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "tests", "mock_pcl"), "-I", os.path.join(ROOT, "tests", "mock_eigen"), "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
                         "-L", os.path.dirname(lib), "-lhgs_hip", f"-Wl,-rpath,{os.path.dirname(lib)}"], check=True)
     return EXE
 
@@ -53,6 +54,8 @@ def test_adapter_matches_python_mirror(tmp_path, method):
     assert abs(float(out[2].split()[1]) - reg.getFitnessScore()) < 1e-9      # printed with 12 significant digits
     assert out[4] == "no_device converged 0 guess_kept 1"              # hgs_create failure: no exception, hasConverged() false, guess kept
     assert out[5] == "recovered converged 1 same_pose 1"                # the engine created later holds the clouds set while creation failed
+    from parity_checks import check_adapter_lazy_tree_lines
+    check_adapter_lazy_tree_lines(out)
     reg.close()
 
 

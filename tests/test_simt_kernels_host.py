@@ -269,9 +269,10 @@ def test_cpp_adapter_end_to_end(simt_library, tmp_path, method):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "tests", "cpp", "adapter_main_simt")
     src_cpp = os.path.join(root, "tests", "cpp", "adapter_main.cpp")
-    deps = [src_cpp, os.path.join(root, "adapters", "registration_hip.hpp"), os.path.join(root, "include", "hgs_registration.h"), simt_library]
+    deps = [src_cpp, os.path.join(root, "adapters", "registration_hip.hpp"), os.path.join(root, "include", "hgs_registration.h"), simt_library,
+            os.path.join(root, "tests", "mock_pcl", "pcl", "registration", "registration.h"), os.path.join(root, "tests", "mock_pcl", "pcl", "search", "kdtree.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
-        subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "tests", "mock_pcl"), "-I", os.path.join(root, "include"), src_cpp, "-o", exe,
+        subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "tests", "mock_pcl"), "-I", os.path.join(root, "tests", "mock_eigen"), "-I", os.path.join(root, "include"), src_cpp, "-o", exe,
                         "-L", os.path.dirname(simt_library), "-l:libhgs_simt.so", f"-Wl,-rpath,{os.path.dirname(simt_library)}"], check=True)
     tgt, src, T = _pair("vlp16")
     tgt.tofile(tmp_path / "t.bin")
@@ -289,6 +290,7 @@ def test_cpp_adapter_end_to_end(simt_library, tmp_path, method):
     assert abs(float(out[2].split()[1]) - e.getFitnessScore()) < 1e-9
     assert out[4] == "no_device converged 0 guess_kept 1"   # an engine that cannot be created does not throw into the caller
     assert out[5] == "recovered converged 1 same_pose 1"                # the engine created later holds the clouds set while creation failed
+    PC.check_adapter_lazy_tree_lines(out)
     if method == 0:
         dt, dr = synth.pose_error(Tc.astype(np.float64), o.align(np.eye(4)).matrix())
         assert dt < 1e-5 and dr < 1e-5
