@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--ndt-steps", type=int, default=8, help="timed steps of the NDT_OMP sub-record")
     ap.add_argument("--fitness-max-range-variant", action="store_true", help="config 4: also time the batch with fitness_score_max_range = 4.0")
     ap.add_argument("--cpu-single-thread", action="store_true", help="cpu_baseline also carries the one-thread rate (one unit of the sample)")
+    ap.add_argument("--no-adapter-record", action="store_true", help="config 3: skip the `adapter_path` sub-record (the stream through the C++ pcl::Registration adapter)")
     ap.add_argument("--no-kitti-records", action="store_true", help="config 3: skip the two sub-records that run the stream behind the KITTI launch file's prefilter")
     ap.add_argument("--oracle-sweeps", type=int, default=12, help="config 3: sweeps the CPU oracle runs through the same caller for the trajectory agreement (0: none)")
     ap.add_argument("--speed", type=float, default=0.0, help="config 3: vehicle speed in m/s (default: 8.0 as SURVEY 8d, plus a 3.0 m/s sub-record)")
@@ -659,6 +660,8 @@ def run_odometry(ctx):
     for sp in speeds[1:]:
         o = odometry_at_speed(ctx, sp, 1, False)
         out[f"at_{sp:g}_mps".replace(".", "_")] = {k: o[k] for k in keys}
+    if ctx["world"] == 1 and not a.no_adapter_record:
+        out["adapter_path"] = adapter_path_record(ctx, speeds[0])
     if not a.method and not a.no_kitti_records and ctx["world"] == 1:
         # the stream as the reference's KITTI launch file runs it (launch/hdl_graph_slam_kitti.launch:22-34,50-59): every sweep through the prefilter
         # (distance 0.1-100 m, VoxelGrid 0.25 m, radius outlier removal 0.5 m / 2 neighbours) ON THE DEVICE, then (a) the engine SURVEY 8d names for
@@ -669,6 +672,53 @@ def run_odometry(ctx):
             out[name]["workload"] = o["config"]["workload"]
             out[name]["points_after_prefilter"] = o["config"]["points_after_prefilter"]
     return out
+
+
+def adapter_path_record(ctx, speed):
+    """What the integrated system would see: the same stream through adapters/registration_hip.hpp — the object the patched factory
+    (integration/hdl_graph_slam_hip.patch) returns — held by a pcl::Registration base pointer and driven like
+    ScanMatchingOdometryNodelet::matching (tests/cpp/adapter_bench.cpp, C++), next to the bare C-ABI loop in the same process.  PCL is not installable
+    here: pcl::Registration is the stand-in of tests/mock_pcl, which does on the host what PCL's align() does (initCompute, output = *input_, data[3] = 1) and
+    whose kd-tree is a real exact kd-tree — `adapter_with_eager_cpu_kdtree` is therefore what rounds 1-4's adapter paid per new target and
+    `pcl_align_alone` what pcl::Registration::align costs with an engine that does nothing (the reference's CPU engines pay that too).
+    Two streams: the raw sweeps config 3 is quoted on, and the sweeps behind a 0.25 m VoxelGrid (what the prefiltering nodelet of
+    launch/hdl_graph_slam_kitti.launch:22-34 hands to the odometry nodelet)."""
+    import subprocess
+    import tempfile
+    a, L, synth = ctx["args"], ctx["L"], ctx["synth"]
+    method = a.method or "NDT_OMP"
+    method_id = {"FAST_GICP": L.HGS_FAST_GICP, "FAST_VGICP": L.HGS_FAST_VGICP, "NDT_OMP": L.HGS_NDT_OMP}[method]
+    lib = ctx["emulated"] or L.LIB_PATH
+    exe = os.path.join(ROOT, "tests", "cpp", "adapter_bench" + ("_simt" if ctx["emulated"] else ""))
+    src = os.path.join(ROOT, "tests", "cpp", "adapter_bench.cpp")
+    deps = [src, os.path.join(ROOT, "adapters", "registration_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"), lib,
+            os.path.join(ROOT, "tests", "mock_pcl", "pcl", "registration", "registration.h"), os.path.join(ROOT, "tests", "mock_pcl", "pcl", "search", "kdtree.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "tests", "mock_pcl"), "-I", os.path.join(ROOT, "tests", "mock_eigen"), "-I", os.path.join(ROOT, "include"),
+                        src, "-o", exe, "-L", os.path.dirname(lib), f"-l:{os.path.basename(lib)}", "-pthread", f"-Wl,-rpath,{os.path.dirname(os.path.abspath(lib))}"], check=True)
+    sensor = a.sensor or "HDL-64E"
+    n = min(a.steps or 60, 60)
+    warm = max(1, a.warmup)
+    stream = ctx["workloads"].make_odometry_stream(sensor, 0, warm + n + 1, speed=speed, downsample=a.downsample or None)
+    rec = {"how": "tests/cpp/adapter_bench.cpp: C++ caller, pcl::Registration base pointer (tests/mock_pcl stand-in of PCL's host-side align()), wall clock around every sweep "
+                  "(setInputSource + fresh output cloud + align + getFinalTransformation, and setInputTarget in the sweep that switches the keyframe); keyframe rule: 5 m",
+           "method": method, "speed_mps": speed}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, scans in (("raw_sweeps", stream.scans), ("behind_voxelgrid_0_25", [synth.voxel_downsample(c, 0.25) for c in stream.scans])):
+            files = []
+            for i, c in enumerate(scans):
+                f = os.path.join(tmp, f"{name}_{i}.bin")
+                np.ascontiguousarray(c).tofile(f)
+                files.append(f)
+            out = subprocess.run([exe, str(method_id), "1.0", str(warm), "5.0", *files], check=True, capture_output=True, text=True).stdout
+            r = json.loads(out)
+            abi, ad = r["c_abi"]["p50_ms"], r["adapter"]["p50_ms"]
+            r["adapter_over_c_abi_p50"] = round(ad / abi, 4) if abi > 0 else None
+            r["adapter_minus_pcl_align_over_c_abi_p50"] = round((ad - r["pcl_align_alone"]["p50_ms"]) / abi, 4) if abi > 0 else None
+            rec[name] = r
+            for f in files:
+                os.remove(f)
+    return rec
 
 
 def odometry_at_speed(ctx, speed, n_seeds, with_cpu, pipeline="raw"):

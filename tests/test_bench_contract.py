@@ -97,6 +97,13 @@ def test_other_baseline_configs_emit_the_same_contract(config, extra):
     assert ROOFLINE <= set(rec["roofline"]) and rec["cpu_baseline"]["value"] > 0 and {"p10", "p50", "p90"} <= set(rec["step_ms"])
     if config == 3:
         assert "p99" in rec["latency_ms"] and "H2D" in rec["config"]["workload"]
+        # the same stream through the C++ pcl::Registration adapter (what the patched factory returns) next to the bare C-ABI, in one C++ process
+        ap = rec["adapter_path"]
+        for stream in ("raw_sweeps", "behind_voxelgrid_0_25"):
+            r = ap[stream]
+            assert r["max_abs_pose_diff_adapter_vs_c_abi"] == 0 and r["adapter"]["sweeps"] == 3 and r["adapter"]["converged"] == r["c_abi"]["converged"]
+            assert r["adapter"]["cpu_kdtree_builds"] == 0 and r["adapter_with_eager_cpu_kdtree"]["cpu_kdtree_builds"] >= 1
+            assert r["adapter_over_c_abi_p50"] > 0 and r["pcl_align_alone"]["p50_ms"] >= 0
         # the stream as launch/hdl_graph_slam_kitti.launch runs it: device prefilter in front of NDT_OMP and of the launch file's FAST_GICP
         for name, method in (("kitti_prefilter_ndt_omp", "NDT_OMP"), ("kitti_launch_fast_gicp", "FAST_GICP")):
             k = rec[name]
