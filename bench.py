@@ -155,6 +155,10 @@ def main():
     ap.add_argument("--distinct", type=int, default=0, help="distinct ray-cast scans behind the candidates (default 16; 8 with --mild-set)")
     ap.add_argument("--mild-set", action="store_true", help="the candidate set rounds 1 and 2 benchmarked (8 distinct scans within 4 m of the query, guess noise "
                     "0.3 m / 1 deg) instead of SURVEY 8d's (within 20 m, 0.5 m / 2 deg): for continuity with the earlier lines")
+    ap.add_argument("--single-process", action="store_true", help="default command / config 4: ONE process drives --gpus engines from host threads (the nodelet manager's "
+                    "shape, MultiDeviceLoopMatcher) instead of one rank per GPU; not to be launched through torch.distributed.run")
+    ap.add_argument("--strong-candidates", type=int, default=512, help="candidates IN TOTAL of the config-4 strong-scaling sub-record (BASELINE config 4: 512)")
+    ap.add_argument("--no-strong-record", action="store_true", help="N > 1, default command: skip the config-4 strong-scaling sub-record (512 candidates in total)")
     ap.add_argument("--no-ndt-record", action="store_true", help="default command only: skip the NDT_OMP (factory default engine) sub-record")
     ap.add_argument("--no-plane-record", action="store_true", help="default command only: skip the FAST_GICP / PLANE-regularisation sub-record")
     ap.add_argument("--ndt-steps", type=int, default=8, help="timed steps of the NDT_OMP sub-record")
@@ -257,6 +261,30 @@ def max_over_ranks(ctx, dt):
     return float(t.item())
 
 
+HGS_EXCHANGE = "hgs_loop_match_batch_sharded (RCCL all-gather on the engine's stream, C-ABI)"
+TORCH_EXCHANGE = "torch.distributed all_gather of the records"
+
+
+def all_ranks_ok(ctx, ok):
+    """MIN over the ranks of a 0/1 flag (every rank takes the same branch afterwards)."""
+    if ctx["dist"] is None:
+        return bool(ok)
+    t = ctx["torch"].tensor([int(ok)], device=ctx["coll_device"], dtype=ctx["torch"].int32)
+    ctx["dist"].all_reduce(t, op=ctx["dist"].ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def gather_floats(ctx, v):
+    """[v of rank 0, v of rank 1, ...] on every rank."""
+    if ctx["dist"] is None:
+        return [round(float(v), 3)]
+    torch = ctx["torch"]
+    t = torch.tensor([float(v)], device=ctx["coll_device"], dtype=torch.float64)
+    out = torch.empty(ctx["world"], device=ctx["coll_device"], dtype=torch.float64)
+    ctx["dist"].all_gather_into_tensor(out, t)
+    return [round(float(x), 3) for x in out.cpu().tolist()]
+
+
 def base_line(ctx, value, unit, steps, dt, dtype, workload, extra_config):
     a = ctx["args"]
     return {"metric": "registrations/sec (64-beam ~120k-pt pair), loop-closure batch" if a.config == 0 else "registrations/sec", "value": round(value, 3), "unit": unit,
@@ -276,7 +304,19 @@ def run_loop_batch(ctx):
     method = a.method or "FAST_GICP"
     B = a.candidates or ((512 + world - 1) // world if cfg4 else 64)
     steps = a.steps or (16 if cfg4 else 64)   # >= 1 s of timed region at the measured 62 / 16 ms per step
+    if a.single_process:
+        return measure_single_process(ctx, method, B, steps)
     out = measure_loop_batch(ctx, method, B, steps, ctx["n_seeds"], with_cpu=not a.no_cpu_baseline, with_resident=True, max_range=None)
+    if a.config == 0 and world > 1 and not a.no_strong_record:
+        # next to the weak line (64 candidates per GPU): BASELINE config 4 — 1 query x 512 HDL-32E candidates IN TOTAL, sharded over the ranks (strong scaling)
+        a.config = 4
+        try:
+            st = measure_loop_batch(ctx, method, (a.strong_candidates + world - 1) // world, max(4, steps // 4), 1, with_cpu=False, with_resident=False, max_range=None, sub_record=True)
+        finally:
+            a.config = 0
+        out["config4_strong_scaling"] = dict({k: st[k] for k in ("value", "unit", "steps", "ms_per_step", "step_ms", "scaling", "converged", "mean_iterations", "best_candidate",
+                                                                  "per_rank_ms_per_step")},
+                                             candidates_total=a.strong_candidates, candidates_per_gpu=(a.strong_candidates + world - 1) // world, workload=st["config"]["workload"], exchange=st["config"]["exchange"])
     if cfg4 and a.fitness_max_range_variant and world == 1:
         v = measure_loop_batch(ctx, method, B, max(2, steps // 4), 1, with_cpu=False, with_resident=False, max_range=4.0)
         out["fitness_score_max_range_4"] = {k: v[k] for k in ("value", "ms_per_step", "steps", "converged", "best_candidate", "num_inliers_mean")}
@@ -304,6 +344,64 @@ def run_loop_batch(ctx):
     return out
 
 
+def measure_single_process(ctx, method, B, steps):
+    """--single-process: what ONE process with several GPUs does (the nodelet manager): one engine per GPU, each driven from its own host thread
+    (hdl_graph_slam_amd.distributed.MultiDeviceLoopMatcher; C++: adapters/loop_match_hip.hpp), candidate k on engine k mod N, no collective — the
+    records are already in this process.  --gpus N engines on devices 0..N-1 (HGS_BENCH_ONE_DEVICE=1: all on device 0, what a 1-GPU box can run);
+    N x `--candidates` candidates per step, cold (index + covariances of the target and of every candidate rebuilt every step)."""
+    a, L, synth = ctx["args"], ctx["L"], ctx["synth"]
+    from hdl_graph_slam_amd.distributed import MultiDeviceLoopMatcher
+    cfg4 = a.config == 4
+    n_eng = max(1, a.gpus)
+    sensor = a.sensor or ("HDL-32E" if cfg4 else "HDL-64E")
+    total = B if cfg4 else B * n_eng   # config 4: 512 in total; the metric's configuration: `--candidates` per GPU
+    pnh = {"registration_method": method}
+    if method in ("NDT_OMP", "FAST_VGICP"):
+        pnh["reg_resolution"] = 1.0
+    devices = [0] * n_eng if (ctx["emulated"] or os.environ.get("HGS_BENCH_ONE_DEVICE")) else list(range(n_eng))
+    m = MultiDeviceLoopMatcher(pnh, devices)
+    set_kwargs = dict(ctx["workloads"].MILD_LOOP_SET) if a.mild_set else {}
+    if a.distinct:
+        set_kwargs["n_distinct"] = a.distinct
+    wl = ctx["workloads"].make_loop_closure_set(sensor, scene_seed=0, n_candidates=total, downsample=a.downsample or None,
+                                                **dict(set_kwargs, n_distinct=min(set_kwargs.get("n_distinct", 16), total)))
+    d_cands = [m.upload(i, c) for i, c in enumerate(wl.candidates)]
+
+    def step():
+        for c in d_cands:
+            c.invalidate()
+        return m.match(wl.target, d_cands, wl.guesses, L.DBL_MAX)
+
+    def sync():
+        for e in m.engines:
+            e.synchronize()
+        if not ctx["emulated"]:
+            ctx["torch"].cuda.synchronize()
+    for _ in range(max(1, a.warmup)):
+        step()
+    per = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts = time.perf_counter()
+        rec, best = step()
+        per.append((time.perf_counter() - ts) * 1e3)
+    sync()
+    dt = time.perf_counter() - t0
+    out = base_line(ctx, total * steps / dt, "registrations/sec", steps, dt, "f32" if method == "NDT_OMP" else "f64",
+                    f"loop-closure batch, ONE process driving {n_eng} engine(s) from host threads (devices {devices}): {total} candidate keyframes x {sensor} "
+                    f"(~{int(np.mean([len(c) for c in wl.candidates]))} pts) vs 1 query keyframe (uploaded to every engine inside the step), {method} + getFitnessScore, cold",
+                    {"candidates_per_gpu": total // n_eng, "candidates_total": total, "method": method, "parallelism": f"single process, {n_eng} engine threads", "exchange": None})
+    out["n_gpus"] = n_eng
+    out["scaling"] = "strong" if cfg4 else "weak"
+    out.update({"step_ms": percentiles(per), "timed_region_s": round(dt, 3), "converged": int(np.sum(rec["converged"])), "mean_iterations": float(np.mean(rec["iterations"])),
+                "best_candidate": int(best), "roofline": None, "cpu_baseline": None})
+    for c in d_cands:
+        c.close()
+    m.close()
+    return out
+
+
 def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, max_range, mild=None, regularization=None, check_all=True, sub_record=False):
     a, rank, world, L, synth = ctx["args"], ctx["rank"], ctx["world"], ctx["L"], ctx["synth"]
     cfg4 = a.config == 4
@@ -327,7 +425,7 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
     # The exchange step of a sharded detection: the library's own entry point (hgs_comm_init + hgs_loop_match_batch_sharded: RCCL
     # all-gather of device-built records on the engine's stream) when every rank could join its communicator; otherwise the same
     # all-gather through torch.distributed (gloo in the emulated CPU runs, or HGS_BENCH_EXCHANGE=torch).
-    exchange = {"kind": None if shard is None else "torch.distributed all_gather of the records"}
+    exchange = {"kind": None if shard is None else TORCH_EXCHANGE}
     if shard is not None and not ctx["emulated"] and str(ctx["coll_device"]).startswith("cuda") and os.environ.get("HGS_BENCH_EXCHANGE", "hgs") != "torch":
         ok = 1
         try:
@@ -336,10 +434,11 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
             ok = 0
             if rank == 0:
                 print(f"[bench] hgs_comm_init failed ({e}); exchanging through torch.distributed", file=sys.stderr)
-        t = ctx["torch"].tensor([ok], device=ctx["coll_device"], dtype=ctx["torch"].int32)
-        ctx["dist"].all_reduce(t, op=ctx["dist"].ReduceOp.MIN)
-        if int(t.item()) == 1:
-            exchange["kind"] = "hgs_loop_match_batch_sharded (RCCL all-gather on the engine's stream, C-ABI)"
+        if all_ranks_ok(ctx, ok):
+            exchange["kind"] = HGS_EXCHANGE
+    if shard is not None and os.environ.get("HGS_BENCH_TEST_EXCHANGE_FAILS") is not None:
+        # test hook (tests/test_bench_contract.py): pretend the library's exchange was set up, so that the trial-and-fall-back logic below runs under gloo
+        exchange["kind"] = HGS_EXCHANGE
 
     def load(seed):
         # every rank holds the query keyframe (replicated target) and its own shard of the N*B candidates
@@ -360,7 +459,7 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
                     c.invalidate()
             reg.setInputTarget(d_target)
             ids = np.arange(rank, world * B, world, dtype=np.int32)   # candidate c lives on rank c mod world
-            if shard is not None and exchange["kind"].startswith("hgs_"):
+            if shard is not None and exchange["kind"] == HGS_EXCHANGE:
                 allrec, best = reg.loop_match_batch_sharded(d_cands, ids, wl.guesses, world * B, fit_range)
                 return allrec[ids], best
             rec, best = reg.loop_match_batch(d_cands, wl.guesses, fit_range)
@@ -385,12 +484,49 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
     wl, d_target, d_cands = load(0)
     n_pts = [len(c) for c in wl.candidates]
     step = make_step(wl, d_target, d_cands)
+    if shard is not None and exchange["kind"] == HGS_EXCHANGE:
+        # The first >= 2-rank execution of the library's RCCL exchange may well be this run: ONE untimed trial step on every rank, with a short
+        # collective deadline, decides.  Any failure or timeout on any rank -> every rank exchanges through torch.distributed instead (the
+        # records and the selection are the same; only the transport differs) and the line says so in config.exchange.
+        ok, why = 1, ""
+        saved = os.environ.get("HGS_COMM_TIMEOUT_MS")
+        os.environ["HGS_COMM_TIMEOUT_MS"] = os.environ.get("HGS_BENCH_TRIAL_TIMEOUT_MS", "5000")
+        try:
+            if os.environ.get("HGS_BENCH_TEST_EXCHANGE_FAILS") == str(rank):
+                raise RuntimeError("injected by HGS_BENCH_TEST_EXCHANGE_FAILS")
+            if os.environ.get("HGS_BENCH_TEST_EXCHANGE_FAILS") is None:
+                step()
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, f"{type(e).__name__}: {e}"
+        finally:
+            if saved is None:
+                os.environ.pop("HGS_COMM_TIMEOUT_MS", None)
+            else:
+                os.environ["HGS_COMM_TIMEOUT_MS"] = saved
+        if not all_ranks_ok(ctx, ok):
+            if why:
+                print(f"[bench] rank {rank}: the trial step through hgs_loop_match_batch_sharded failed ({why}); every rank falls back to torch.distributed", file=sys.stderr)
+            exchange["kind"] = TORCH_EXCHANGE + " (fallback: the untimed trial step of the library's RCCL exchange failed or timed out on some rank)"
+        else:
+            os.environ.setdefault("HGS_COMM_TIMEOUT_MS", "20000")   # the timed steps: a stuck collective costs the driver 20 s, not a minute per wait
     # untimed warm-up: the requested steps, and for a sub-record (measured after another engine's CPU check, with the clocks idle in between) at least 0.1 s of them
     n_warm, t_warm = 0, time.perf_counter()
     while n_warm < a.warmup or (sub_record and time.perf_counter() - t_warm < 0.1 and n_warm < 64):
         step()
         n_warm += 1
-    dt, per_step, rec, best = timed(step, steps)
+    try:
+        dt, per_step, rec, best = timed(step, steps)
+        ok = 1
+    except Exception as e:  # noqa: BLE001 - only the library's exchange can fail here without the whole job being broken: agree on it and re-run
+        if shard is None or exchange["kind"] != HGS_EXCHANGE:
+            raise
+        print(f"[bench] rank {rank}: a timed step through hgs_loop_match_batch_sharded failed ({type(e).__name__}: {e})", file=sys.stderr)
+        ok = 0
+    if shard is not None and exchange["kind"] == HGS_EXCHANGE and not all_ranks_ok(ctx, ok):
+        exchange["kind"] = TORCH_EXCHANGE + " (fallback: a timed step of the library's RCCL exchange failed on some rank; the timed region was re-run)"
+        step()
+        dt, per_step, rec, best = timed(step, steps)
+    dt_rank = dt
     dt = max_over_ranks(ctx, dt)
 
     # ---- informational: the same batch with the candidate keyframes' index + covariances kept resident between detections
@@ -509,6 +645,9 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
                     {"candidates_per_gpu": B, "points_per_cloud": int(np.mean(n_pts)), "method": method,
                      "distinct_scans": min(set_kwargs.get("n_distinct", 16), B),
                      "parallelism": f"candidate-sharded x{world}" if world > 1 else "single GPU", "exchange": exchange["kind"]})
+    if cfg4:
+        out["scaling"] = "strong"   # config 4: 512 candidates in total, whatever the number of ranks
+    out["per_rank_ms_per_step"] = gather_floats(ctx, dt_rank / max(steps, 1) * 1e3)
     out.update({"step_ms": percentiles(per_step), "timed_region_s": round(dt, 3), "warmup_steps_run": n_warm,
                 "value_by_scene_seed": by_seed, "value_mean_std_over_seeds": [round(float(np.mean(by_seed)), 1), round(float(np.std(by_seed)), 1)],
                 "mean_iterations_by_scene_seed": its_by_seed,

@@ -174,6 +174,8 @@ struct hgs_handle {
   int ndt_sort = -1;       // NDT source order: -1 Hilbert order if the source has an index, 1 build the index first, 0 input order (HGS_NDT_SORT, A/B runs)
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_descs, h_results, h_small, h_flags, h_comm;  // h_flags: host-mapped progress mirror (Progress)
+  PinnedBuffer h_xform;            // hgs_transform_source: the aligned cloud on its way down
+  hipEvent_t xform_event[4] = {};
 
   // freed cloud blocks kept for reuse: the odometry path creates and destroys one cloud per sweep, and hipMalloc /
   // hipFree (which synchronises the device) cost more than the upload itself
@@ -1088,6 +1090,9 @@ int hgs_destroy(hgs_handle* h) try {
   h->h_small.release();
   h->h_comm.release();
   h->h_flags.release();
+  h->h_xform.release();
+  for (hipEvent_t ev : h->xform_event)
+    if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : h->prof_events) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   if (h->stream) (void)hipStreamDestroy(h->stream), g_streams_in_use.fetch_sub(1, std::memory_order_relaxed);
@@ -1264,14 +1269,28 @@ int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t
   std::memcpy(h->h_small.p, T, 64);
   HGS_HIP(h, hipMemcpyAsync(dT, h->h_small.p, 64, hipMemcpyHostToDevice, h->stream));
   launch_transform(h->stream, h->source->desc.raw, (int)n, dT, h->misc.as<float4>());
-  std::vector<float> host(n * 4);
-  HGS_HIP(h, hipMemcpyAsync(host.data(), h->misc.p, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
-  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  // Down through a pinned staging buffer the engine keeps (round 4 copied into a fresh pageable std::vector: 1.9 MB of page faults and a staged
+  // pageable D2H per align), in four pieces so that the host scatters piece k into the caller's strided records while piece k + 1 is on the wire.
+  HGS_HIP(h, h->h_xform.reserve(n * sizeof(float4)));
+  const float* host = h->h_xform.as<float>();
+  constexpr int kPieces = 4;
+  if (!h->xform_event[0])
+    for (hipEvent_t& ev : h->xform_event) HGS_HIP(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  size_t bounds[kPieces + 1];
+  for (int k = 0; k <= kPieces; k++) bounds[k] = n * (size_t)k / kPieces;
+  for (int k = 0; k < kPieces; k++) {
+    if (bounds[k + 1] > bounds[k])
+      HGS_HIP(h, hipMemcpyAsync(h->h_xform.as<float4>() + bounds[k], h->misc.as<float4>() + bounds[k], (bounds[k + 1] - bounds[k]) * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    HGS_HIP(h, hipEventRecord(h->xform_event[k], h->stream));
+  }
   char* o = (char*)out_pts;
-  for (size_t i = 0; i < n; i++) {
-    float* f = reinterpret_cast<float*>(o + i * stride_bytes);
-    f[0] = host[4 * i], f[1] = host[4 * i + 1], f[2] = host[4 * i + 2];
-    if (stride_bytes >= 16) f[3] = 1.0f;
+  for (int k = 0; k < kPieces; k++) {
+    HGS_HIP(h, hipEventSynchronize(h->xform_event[k]));
+    for (size_t i = bounds[k]; i < bounds[k + 1]; i++) {
+      float* f = reinterpret_cast<float*>(o + i * stride_bytes);
+      f[0] = host[4 * i], f[1] = host[4 * i + 1], f[2] = host[4 * i + 2];
+      if (stride_bytes >= 16) f[3] = 1.0f;
+    }
   }
   return HGS_OK;
 } catch (...) {

@@ -54,6 +54,22 @@ __device__ __forceinline__ float4 hgs_load_global_xyz(const float4* p) {  // .w 
 // (the 32- / 64-slot lists and the instantiation with the per-point eigen-decomposition keep the compiler's choice: capped at 96 VGPRs the
 // latter spills 536 bytes and its covariance pass takes 5.8 instead of 3.5 ms)
 #define HGS_KNN_OCCUPANCY __attribute__((amdgpu_waves_per_eu((KMAX <= 20 && !REG_GENERAL) ? HGS_KNN_WAVES : 1)))
+// The block-per-problem control kernels (k_gicp_solve: 4 waves, k_gicp_decide: 1 wave) run next to the other lanes' point kernels.  Compiled freely they
+// take 108 / 118 VGPRs: a wave of theirs then fits a SIMD only after TWO of k_gicp_linearize's 72-VGPR waves have left it (7 x 72 = 504 of 512 are
+// taken), and the 30 k-block launch refills every hole with its own next block first — round 4's lanes profile shows k_gicp_solve at 40.7 us on
+// average (13.6 alone, 504 max).  With waves_per_eu(6) they take 80 VGPRs (8 / 100 bytes of scratch in the one-lane LM step) = the hole ONE departing
+// linearize wave leaves; s_setprio puts their one working lane in front of the 6-7 point-kernel waves that share its SIMD's issue slots; reduce_tiles
+// keeps 8 loads in flight instead of 4 (same additions in the same order).  Same-box A/B on the 64 x 119 k batch (profiles/r05_ab_control_kernels.log):
+// 5391 -> 5437 registrations/s FROBENIUS (+0.8 %), PLANE within noise: what the inversion really cost the timed configuration was under 1 %.
+#ifndef HGS_CONTROL_WAVES
+#define HGS_CONTROL_WAVES 6
+#endif
+#ifndef HGS_CONTROL_PRIO
+#define HGS_CONTROL_PRIO 3
+#endif
+#ifndef HGS_REDUCE_UNROLL
+#define HGS_REDUCE_UNROLL 2
+#endif
 #ifndef HGS_FITNESS_WAVES
 #define HGS_FITNESS_WAVES 8
 #endif
@@ -190,6 +206,7 @@ __device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int n
     // four independent partial sums keep four loads in flight per thread (one dependent chain was latency bound)
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int tile = row;
+#pragma unroll HGS_REDUCE_UNROLL
     for (; tile + 3 * ROWS < ntiles; tile += 4 * ROWS) {
       const double a = p[(size_t)tile * N + col], b = p[(size_t)(tile + ROWS) * N + col];
       const double c = p[(size_t)(tile + 2 * ROWS) * N + col], d = p[(size_t)(tile + 3 * ROWS) * N + col];
@@ -722,10 +739,11 @@ void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt
   hipLaunchKernelGGL(k_gicp_linearize, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw);
 }
 
-__global__ __launch_bounds__(kSolveBlock) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
+__global__ __launch_bounds__(kSolveBlock) __attribute__((amdgpu_waves_per_eu(HGS_CONTROL_WAVES))) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
                                                       int max_blocks, int tile_points) {
   const int b = blockIdx.x;
   if (states[b].phase != GICP_LINEARIZE) return;
+  if (HGS_CONTROL_PRIO) __builtin_amdgcn_s_setprio(HGS_CONTROL_PRIO);
   __shared__ double acc[kAcc];
   __shared__ double scratch[kSolveBlock];
   // the control step runs on ONE lane and is a chain of dependent loads and stores on the problem's state and on the factorisation's
@@ -775,10 +793,11 @@ void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, co
   hipLaunchKernelGGL(k_gicp_error, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks);
 }
 
-__global__ __launch_bounds__(64) void k_gicp_decide(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials_err,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_CONTROL_WAVES))) void k_gicp_decide(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials_err,
                                                    int max_blocks, Progress prog) {
   const int b = blockIdx.x;
   bool finished_now = false;
+  if (HGS_CONTROL_PRIO) __builtin_amdgcn_s_setprio(HGS_CONTROL_PRIO);
   if (states[b].phase == GICP_TRY) {  // (block-uniform)
     __shared__ GicpState st;  // as in k_gicp_solve: the one-lane control step works on LDS
     __shared__ double ws[kGicpControlWorkspace];

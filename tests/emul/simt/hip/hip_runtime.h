@@ -19,6 +19,7 @@
 #define HGS_OPAQUE_OFFSET(off) asm volatile("" : "+r"(off))
 #define HGS_WAIT_VMEM_TRACKED() ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define HGS_LANE_ID(dst) ((dst) = (int)(threadIdx.x & 63))
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))

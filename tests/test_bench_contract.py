@@ -21,7 +21,8 @@ def _run(cmd, extra_env=None):
     lib = simt.build()
     if lib is None:
         pytest.skip("clang++ not available")
-    env = dict(os.environ, HGS_BENCH_EMULATED_LIB=lib, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", **(extra_env or {}))
+    env = dict(os.environ, HGS_BENCH_EMULATED_LIB=lib, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    env.update(extra_env or {})
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -109,3 +110,36 @@ def test_other_baseline_configs_emit_the_same_contract(config, extra):
             k = rec[name]
             assert k["value"] > 0 and method in k["workload"] and "prefilter" in k["workload"] and 0 < k["points_after_prefilter"] < rec["config"]["points_per_cloud"]
             assert k["oracle_stream"]["max_translation_diff_vs_device_m"] < 1e-3 and k["cpu_baseline"]["value"] > 0
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_eight_ranks_fall_back_to_the_torch_exchange_when_the_trial_step_fails():
+    """The driver's --gpus 8 launch, emulated: the untimed trial step of the library's RCCL exchange fails on ONE rank (injected) -> the MIN all-reduce makes
+    every rank exchange through torch.distributed; the line says so, carries every rank's step time and the config-4 strong-scaling sub-record."""
+    rec = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--candidates", "1", "--distinct", "1", "--sensor", "VLP-16", "--downsample", "0.6",
+                "--strong-candidates", "8"], extra_env={"HGS_BENCH_TEST_EXCHANGE_FAILS": "5", "OMP_NUM_THREADS": "1"})
+    _check(rec, 8, 1, 1, 1)
+    assert "fallback" in rec["config"]["exchange"] and "torch.distributed" in rec["config"]["exchange"]
+    assert len(rec["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in rec["per_rank_ms_per_step"])
+    st = rec["config4_strong_scaling"]
+    assert st["scaling"] == "strong" and st["candidates_total"] == 8 and st["candidates_per_gpu"] == 1 and st["value"] > 0 and len(st["per_rank_ms_per_step"]) == 8
+    assert "fallback" in st["exchange"]
+
+
+def test_single_process_mode_drives_one_engine_per_gpu_from_threads():
+    """--single-process: the nodelet manager's shape (one process, MultiDeviceLoopMatcher), for the metric's configuration and for config 4."""
+    rec = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--steps", "2", "--warmup", "1", *SMALL])
+    assert rec["n_gpus"] == 2 and rec["config"]["candidates_total"] == 4 and rec["config"]["exchange"] is None and rec["scaling"] == "weak"
+    assert "ONE process" in rec["config"]["workload"] and rec["value"] > 0 and rec["converged"] >= 0
+    rec = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--config", "4", "--steps", "2", "--warmup", "1", "--candidates", "3", "--distinct", "2",
+                "--sensor", "VLP-16", "--downsample", "0.5"])
+    assert rec["scaling"] == "strong" and rec["config"]["candidates_total"] == 3
