@@ -594,8 +594,12 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
         O, p = oracle_params(reg)
         k = min(a.cpu_sample, B)
 
-        def sample(O, kk=k):
+        ndt = method == "NDT_OMP"
+
+        def sample(O, kk=k, sum_mode=0):
             o = O.OracleRegistration(p)
+            if ndt and sum_mode:
+                o.set_ndt_sum_mode(sum_mode)
             o.setInputTarget(wl.target)   # target structures are built once per batch in the reference too
             o.setInputSource(wl.candidates[0])
             o.align(wl.guesses[0])        # warm-up (first-touch, thread pool, target covariances)
@@ -609,6 +613,19 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
             return kk / (time.perf_counter() - tc), {"max_pose_diff_vs_gpu_m": float(max(d[0] for d in dpose)), "max_pose_diff_vs_gpu_rad": float(max(d[1] for d in dpose))}
         cpu = best_cpu(sample, "registrations/sec", f"{k} of the {B} candidate registrations (setInputSource + align + getFitnessScore), target structures prebuilt",
                        single_thread=(lambda O: sample(O, 1)) if a.cpu_single_thread else None)
+        # a "faithful" and an "optimised-CPU" variant where they differ.  NDT_OMP: faithful = ndt_omp's N-long per-point score / gradient / Hessian arrays
+        # added serially afterwards (what upstream does, and the parity reference); optimised = one accumulator set per OpenMP thread (oracle sum mode 2: no
+        # 344-byte-per-point round trip, no serial sum).  FAST_GICP / FAST_VGICP: the port already IS the optimised form — fast_gicp's own per-thread accumulators,
+        # 3x3 covariances / Mahalanobis matrices where upstream carries Matrix4d — so there is one variant.  `value` is the FASTER variant's rate.
+        variants = {"faithful" if ndt else "port": {k_: cpu[k_] for k_ in ("value", "cores", "sample")}}
+        if ndt:
+            opt = best_cpu(lambda O: sample(O, k, 2), "registrations/sec", f"{k} of the {B} candidate registrations, per-thread accumulators instead of N-long arrays + serial sum")
+            variants["optimised"] = {k_: opt[k_] for k_ in ("value", "cores", "sample")}
+            if opt["value"] > cpu["value"]:
+                cpu.update({k_: opt[k_] for k_ in ("value", "cores", "sample")})
+        else:
+            variants["port"]["note"] = "already the optimised form: per-thread 6x6 accumulators as in fast_gicp, 3x3 covariances where upstream stores Matrix4d"
+        cpu["variants"] = variants
         if check_all:
             # ---- the checker over the WHOLE candidate set of the timed region (not timed, not part of `value`): the oracle registers every candidate
             # sequentially, as loop_detector.hpp:135-154 does, at the thread count that was fastest above; every record of the GPU batch is compared with
@@ -629,7 +646,25 @@ def measure_loop_batch(ctx, method, B, steps, n_seeds, with_cpu, with_resident, 
                 fit_rel.append(abs(score - rec[i]["fitness_score"]) / max(abs(score), 1e-300))
                 if ro.converged and not score > best_score:
                     best_score, best_o = score, i
-            cpu.update({"value_over_all_candidates": round(B / (time.perf_counter() - t_all), 4),   # the same loop timed as a whole (includes the comparisons: a few ms)
+            rate_all = B / (time.perf_counter() - t_all)
+            rate_all_by_variant = {"faithful" if ndt else "port": round(rate_all, 4)}
+            if ndt:   # the optimised variant over the WHOLE candidate loop as well (timing only; the comparison above is against the faithful one)
+                O.set_num_threads(variants["optimised"]["cores"])
+                o2 = O.OracleRegistration(p)
+                o2.set_ndt_sum_mode(2)
+                o2.setInputTarget(wl.target)
+                t2 = time.perf_counter()
+                for i in range(B):
+                    o2.setInputSource(wl.candidates[i])
+                    o2.align(wl.guesses[i])
+                    o2.getFitnessScore(fit_range)
+                rate_all_by_variant["optimised"] = round(B / (time.perf_counter() - t2), 4)
+            fastest_all = max(rate_all_by_variant.values())
+            cpu.update({"value_over_all_candidates_by_variant": rate_all_by_variant,
+                        # the figure north_star's ">= 10x" is judged against: this GPU's whole-batch rate over the FASTEST CPU variant's rate on the WHOLE candidate loop
+                        "gpu_over_cpu": {"ratio": round(world * B * steps / dt / fastest_all, 1), "against": "the fastest CPU variant over all candidates of the batch "
+                                         f"({fastest_all:.2f} registrations/s at its best thread count), not the sample"}})
+            cpu.update({"value_over_all_candidates": round(rate_all, 4),   # the same loop timed as a whole (includes the comparisons: a few ms)
                         "candidates_checked": B, "oracle_argmin": int(best_o), "oracle_argmin_agrees": bool(best_o == int(best)),
                         "max_pose_diff_vs_gpu_m": float(max(dts)), "max_pose_diff_vs_gpu_rad": float(max(drs)), "iterations_equal": its_equal,
                         "converged_flags_equal": conv_equal, "max_fitness_rel_diff_vs_gpu": float(max(fit_rel)),

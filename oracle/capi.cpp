@@ -197,9 +197,10 @@ int hgso_gicp_error(hgso_handle* h, const double* T12, double* err) {
 // NDT: voxel table export. Returns number of valid cells; fills up to cap cells:
 // cell_ijk[3*i], mean[3*i], icov6[6*i] (xx,xy,xz,yy,yz,zz), npts[i]; sorted by linear key
 // NDT: how the per-point contributions of a derivative pass are added up: 0 = serially in double (ndt_omp, the default),
-// 1 = order-independent exact accumulation (ndt.hpp ExactSum; what a parallel backend can reproduce bit for bit)
+// 1 = order-independent exact accumulation (ndt.hpp ExactSum; what a parallel backend can reproduce bit for bit),
+// 2 = one accumulator set per OpenMP thread (no N-long arrays, no serial sum): the "optimised-CPU" baseline variant of SURVEY 8d — timing only
 int hgso_ndt_set_sum_mode(hgso_handle* h, int mode) {
-  if (!h->ndt || mode < 0 || mode > 1) return 1;
+  if (!h->ndt || mode < 0 || mode > 2) return 1;
   h->ndt->sum_mode = mode;
   return 0;
 }

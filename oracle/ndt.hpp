@@ -353,7 +353,7 @@ public:
   std::vector<NdtTraceEntry> trace;
   double gauss_d1 = 0, gauss_d2 = 0;
   int derivative_passes = 0;
-  int sum_mode = 0;  // 0: serial double sum over the points (ndt_omp); 1: ExactSum (order-independent; what the device computes)
+  int sum_mode = 0;  // 0: serial double sum over the points (ndt_omp); 1: ExactSum (order-independent; what the device computes); 2: per-thread accumulators ("optimised-CPU" baseline variant)
 
   void set_target(std::shared_ptr<OCloud> t) {
     target = t;
@@ -411,12 +411,21 @@ public:
     float Tf[12];
     iso_to_rowmajor_f(T, Tf);
     const int n = (int)source->pts.size();
-    std::vector<double> scores(n, 0.0);
-    std::vector<V6> gs(n);
-    std::vector<M6> Hs(n);
+    // sum modes 0 / 1 keep ndt_omp's N-long per-point result arrays (344 bytes per point written and read back per pass); mode 2 — the
+    // "optimised-CPU" baseline variant of SURVEY 8d, never the parity reference — adds into one accumulator set per thread instead
+    const bool per_thread = sum_mode == 2;
+    const int nt = per_thread ? omp_get_max_threads() : 0;
+    std::vector<double> scores(per_thread ? nt : n, 0.0);
+    std::vector<V6> gs(per_thread ? nt : n, V6::zero());
+    std::vector<M6> Hs(per_thread ? nt : n, M6::zero());
     const float d1 = (float)gauss_d1, d2 = (float)gauss_d2;
     const int method = prm.neighbor_search;
-#pragma omp parallel for schedule(guided, 8)
+#pragma omp parallel
+    {
+    double t_score = 0;  // (sum mode 2) this thread's totals: private, written once to the shared arrays at the end
+    V6 t_g = V6::zero();
+    M6 t_H = M6::zero();
+#pragma omp for schedule(guided, 8) nowait
     for (int idx = 0; idx < n; idx++) {
       V6 gp = V6::zero();
       M6 Hp = M6::zero();
@@ -479,13 +488,36 @@ public:
             }
         }
       }
-      scores[idx] = sp;
-      gs[idx] = gp;
-      Hs[idx] = Hp;
+      if (per_thread) {
+        t_score += sp;
+        for (int r = 0; r < 6; r++) {
+          t_g.v[r] += gp.v[r];
+          for (int c = 0; c < 6; c++) t_H.m[r][c] += Hp.m[r][c];
+        }
+      } else {
+        scores[idx] = sp;
+        gs[idx] = gp;
+        Hs[idx] = Hp;
+      }
     }
+    if (per_thread) {
+      const int t = omp_get_thread_num();
+      scores[t] = t_score, gs[t] = t_g, Hs[t] = t_H;
+    }
+    }  // omp parallel
     double score = 0;
     g = V6::zero();
     H = M6::zero();
+    if (per_thread) {  // the threads' totals in thread order (the result depends on the schedule in the last bits: a baseline variant, not a reference)
+      for (int t = 0; t < nt; t++) {
+        score += scores[t];
+        for (int r = 0; r < 6; r++) {
+          g.v[r] += gs[t].v[r];
+          for (int c = 0; c < 6; c++) H.m[r][c] += Hs[t].m[r][c];
+        }
+      }
+      return score;
+    }
     if (sum_mode == 1) {
       ExactSum es, eg[6], eH[6][6];
       es.E = -59;

