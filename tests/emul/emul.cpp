@@ -5,6 +5,7 @@
 // the CPU-only build box before the kernels run on an MI355X.  It is never part of the product library and is
 // not a fallback: hdl_graph_slam_amd/ does not reference it.
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -600,8 +601,11 @@ static int g_sim_order = 0;  // 0: majority vote for the nearest wanted child; 1
 template <class Wants, class Leaf>
 static void sim_wave_walk_v1(const BvhView& t, const F3* q, int nl, Wants wants, Leaf visit_leaf, SimStats& st);
 template <class Wants, class Leaf>
+static void sim_wave_walk_wide(const BvhView& t, const F3* q, int nl, Wants wants, Leaf visit_leaf, SimStats& st, int S);
+template <class Wants, class Leaf>
 static void sim_wave_walk(const BvhView& t, const F3* q, int nl, Wants wants, Leaf visit_leaf, SimStats& st) {
   if (g_sim_variant == 1) return sim_wave_walk_v1(t, q, nl, wants, visit_leaf, st);
+  if (g_sim_variant >= 2 && g_sim_variant <= 4) return sim_wave_walk_wide(t, q, nl, wants, visit_leaf, st, g_sim_variant);
   if (t.n <= 0) return;
   int k = 0;
   while ((1 << k) < t.P) k++;
@@ -742,7 +746,93 @@ static void sim_wave_walk_v1(const BvhView& t, const F3* q, int nl, Wants wants,
   }
 }
 
+// variants 2 / 3 / 4: a WIDE step — the 2^S descendants S binary levels below the node are one record, evaluated together (S = 2 is the 4-ary
+// step again, without the quad fetch; S = 3 an 8-ary, S = 4 a 16-ary node).  One dependent fetch per entered node; the unchosen wanted children
+// wait on a stack and are re-tested when popped (their box distance against the lanes' current bounds: one box test, no fetch — the parent's
+// record is still parked).  Counts steps (= dependent fetches), box tests and leaf visits: round 5's "wider node" experiment.
+static long long g_sim_box_tests = 0;
+template <class Wants, class Leaf>
+static void sim_wave_walk_wide(const BvhView& t, const F3* q, int nl, Wants wants, Leaf visit_leaf, SimStats& st, int S) {
+  if (t.n <= 0) return;
+  int k = 0;
+  while ((1 << k) < t.P) k++;
+  if (k == 0) {
+    st.leaves++;
+    visit_leaf(0);
+    return;
+  }
+  struct Pending {
+    unsigned node;
+    int depth;
+  };
+  std::vector<Pending> stack;
+  unsigned node = 1;
+  int bd = 0;
+  for (;;) {
+    const int s = std::min(S, k - bd);
+    const int nc = 1 << s;
+    const unsigned base = node << s;
+    const int cd = bd + s;
+    st.groups++;
+    g_sim_box_tests += nc;
+    std::vector<std::array<float, 64>> d(nc);
+    std::vector<int> votes(nc, 0);
+    std::vector<char> any(nc, 0);
+    for (int l = 0; l < nl; l++) {
+      float pd = INFINITY;
+      int pref = -1;
+      for (int c = 0; c < nc; c++) {
+        d[c][l] = bvh_box_dist2(t.nodes, base + c, q[l]);
+        if (!wants(l, d[c][l])) continue;
+        any[c] = 1;
+        if (pref < 0 || d[c][l] < pd) pd = d[c][l], pref = c;
+      }
+      if (pref >= 0) votes[pref]++;
+    }
+    std::vector<int> order;
+    for (int c = 0; c < nc; c++)
+      if (any[c]) order.push_back(c);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return votes[a] > votes[b]; });
+    bool descended = false;
+    if (!order.empty()) {
+      if (cd == k) {
+        for (int c : order) {
+          bool still = false;
+          for (int l = 0; l < nl; l++) still = still || wants(l, d[c][l]);
+          st.retests++;
+          if (!still) continue;
+          st.leaves++;
+          visit_leaf(((int)(base + c) - t.P) * kLeaf);
+        }
+      } else {
+        for (size_t i = order.size(); i-- > 1;) stack.push_back(Pending{base + (unsigned)order[i], cd});  // best of the rest on top
+        node = base + (unsigned)order[0];
+        bd = cd;
+        descended = true;
+      }
+    }
+    if (descended) continue;
+    for (;;) {
+      if (stack.empty()) return;
+      const Pending p = stack.back();
+      stack.pop_back();
+      bool still = false;
+      g_sim_box_tests++;
+      st.retests++;
+      for (int l = 0; l < nl && !still; l++) still = wants(l, bvh_box_dist2(t.nodes, p.node, q[l]));
+      if (!still) continue;
+      node = p.node, bd = p.depth;
+      break;
+    }
+  }
+}
+
 extern "C" void emul_set_sim_variant(int v) { g_sim_variant = v & 0xff, g_sim_order = v >> 8; }
+extern "C" long long emul_sim_box_tests(int reset) {
+  const long long v = g_sim_box_tests;
+  if (reset) g_sim_box_tests = 0;
+  return v;
+}
 
 extern "C" int emul_walk_stats(EmulHandle* h, const float* T16, float bound2, int use_seed, long long* out5) {
   float Tf[12];
