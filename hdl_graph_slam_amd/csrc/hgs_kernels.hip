@@ -70,6 +70,9 @@ __device__ __forceinline__ float4 hgs_load_global_xyz(const float4* p) {  // .w 
 #ifndef HGS_REDUCE_UNROLL
 #define HGS_REDUCE_UNROLL 2
 #endif
+#ifndef HGS_NDT_FLUSH_ROT
+#define HGS_NDT_FLUSH_ROT 1  // ndt_flush: bank-conflict-free rotation (0: round 4's; A/B)
+#endif
 #ifndef HGS_FITNESS_WAVES
 #define HGS_FITNESS_WAVES 8
 #endif
@@ -1318,8 +1321,13 @@ __device__ __noinline__ void ndt_finish_problem(NdtPassShared& S, NdtAccum& A, N
 __device__ __noinline__ bool ndt_flush(NdtPassShared& S, NdtAccum& A, int tiles, int tiles_total) {
   const int t = (int)threadIdx.x;
   __syncthreads();
-  // 86 slots x 64 lanes -> 86 signed totals: thread (slot, quarter) adds 16 lanes (rotated by the slot so that the 64 threads of a wave read 64
-  // different lanes' words), clears them, and the four quarters meet in S.part
+  // 86 slots x 64 lanes -> 86 signed totals: thread (slot, quarter) adds the 16 lanes of its quarter, clears them, and the four quarters meet in S.part.
+  // The order in which a thread takes its 16 words is rotated so that no wave instruction meets a busy bank (MI355X_MICROARCH.md, LDS): a slot row is
+  // 512 bytes, so the bank of word (s, l) depends on l alone — ds_read_b64 is served in two 32-thread groups with banks (2 l) mod 64, ds_write_b64 in four
+  // 16-thread groups with banks (2 l) mod 32.  With r = (j + 4 qd + (s & 3) + 4 ((s >> 2) & 1)) mod 16 the 16 threads of a write group (4 slots x 4
+  // quarters) take 16 different r, and the 32 threads of a read group 32 different l mod 32.  Round 4 rotated by the slot only: quarters 0 / 2 and 1 / 3
+  // of a slot met on one bank in every read (2-way) and all four quarters in every clearing write (4-way) — 4.1e6 conflict quad-cycles per launch, all of
+  // them here (profiles/r05_ndt_lds_conflicts.md).  Integer sums: the order of the additions changes nothing.
 #pragma unroll
   for (int s0 = 0; s0 < kAccNdt * 2; s0 += kBlock / 4) {
     const int s = s0 + (t >> 2), qd = t & 3;
@@ -1327,7 +1335,11 @@ __device__ __noinline__ bool ndt_flush(NdtPassShared& S, NdtAccum& A, int tiles,
       unsigned long long v = 0;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
+#if HGS_NDT_FLUSH_ROT
+        const int l = qd * 16 + ((j + 4 * qd + (s & 3) + 4 * ((s >> 2) & 1)) & 15);
+#else
         const int l = qd * 16 + ((j + (t >> 2)) & 15);
+#endif
         v += S.slots[s][l], S.slots[s][l] = 0;
       }
       S.part[s][qd] = v;
