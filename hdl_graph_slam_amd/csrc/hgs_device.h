@@ -92,7 +92,7 @@ constexpr int kNW = 1;                    // packets of 64 queries a wave walks 
 constexpr int kTileNN = kBlock * kNW;     // source points per block of k_gicp_linearize / k_fitness
 
 // ---- launchers (hgs_kernels.hip) --------------------------------------------------------------------------
-void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw, float* intensity /* may be null */);
+void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw, float* intensity /* may be null */, CloudMeta* meta_to_reset /* may be null */);
 void launch_meta_init(hipStream_t s, const CloudDesc* descs, int ncloud);
 void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n);
 void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals, int drop_bits);
@@ -124,7 +124,7 @@ void launch_ndt_grid_params(hipStream_t s, CloudDesc desc, float inv_leaf);
 void launch_ndt_cell_keys(hipStream_t s, CloudDesc desc, float inv_leaf, unsigned long long* keys, unsigned* vals);
 void launch_ndt_build_cells(hipStream_t s, CloudDesc desc, const unsigned long long* sorted_keys, const unsigned* sorted_vals, int min_points,
                             int* hash_keys, int* hash_vals, int hash_mask, NdtCellRec* cells);
-void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog);
+void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog, NdtAccum* accum_to_zero /* [B], may be null */);
 void launch_ndt_pack_hash(hipStream_t s, const int* keys, const int* vals, int2* kv, int cap);
 // one Newton iteration of B problems in one launch: `blocks` resident blocks pull runs of consecutive (problem, tile) items —
 // numbered by tile_base[B + 1], the prefix sums of the problems' tile counts — from queues[parity & 1] (zero at the start of the
@@ -196,7 +196,7 @@ void launch_pf_approx_centroids(hipStream_t s, const float4* pts, const unsigned
 void launch_pf_radius_flags(hipStream_t s, CloudDesc d, float r2, int min_neighbors, unsigned* keep);
 void launch_pf_mean_knn_dist(hipStream_t s, CloudDesc d, int mean_k, double* dist);
 void launch_pf_statistical(hipStream_t s, const double* dist, int n, double* stats, double stddev_mul, unsigned* keep);
-void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity);
+void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity, CloudMeta* meta_to_reset);
 
 // stage-level test hooks
 void launch_gicp_debug_state(hipStream_t s, GicpState* st, const double* T12_dev);

@@ -85,6 +85,60 @@ struct PinnedBuffer {
   }
 };
 
+// Small host -> device uploads (cloud descriptors, guesses, work plans) go through a ring of pinned slots, each guarded by an event recorded
+// behind its copy: a slot is rewritten only after the copy that read it has completed, so no caller has to synchronise the stream just to make a
+// staging buffer reusable (rounds 1-4 did, once per index build, once per covariance pass, once per NDT plan: 15-30 us of host latency each on
+// the single-registration path).
+struct PinnedRing {
+  static constexpr int kSlots = 8;
+  PinnedBuffer buf[kSlots];
+  hipEvent_t ev[kSlots] = {};
+  bool pending[kSlots] = {};
+  int next = 0;
+  // a slot of at least `bytes` whose previous upload has completed; *slot identifies it for commit()
+  hipError_t stage(size_t bytes, void** host, int* slot) {
+    const int k = next;
+    next = (next + 1) % kSlots;
+    if (pending[k]) {
+      const hipError_t e = hipEventSynchronize(ev[k]);
+      if (e != hipSuccess) return e;
+      pending[k] = false;
+    }
+    const hipError_t e = buf[k].reserve(bytes);
+    if (e != hipSuccess) return e;
+    *host = buf[k].p, *slot = k;
+    return hipSuccess;
+  }
+  // the copy out of the slot has been enqueued on `stream`
+  hipError_t commit(int slot, hipStream_t stream) {
+    if (!ev[slot]) {
+      const hipError_t e = hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    const hipError_t e = hipEventRecord(ev[slot], stream);
+    if (e == hipSuccess) pending[slot] = true;
+    return e;
+  }
+  // H2D of `bytes` from `src` (any host memory) to `dst` through a slot
+  hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    void* host = nullptr;
+    int slot = 0;
+    hipError_t e = stage(bytes, &host, &slot);
+    if (e != hipSuccess) return e;
+    std::memcpy(host, src, bytes);
+    e = hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    return commit(slot, stream);
+  }
+  void release() {
+    for (int k = 0; k < kSlots; k++) {
+      if (ev[k]) (void)hipEventDestroy(ev[k]);
+      ev[k] = nullptr, pending[k] = false;
+      buf[k].release();
+    }
+  }
+};
+
 int next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -173,7 +227,9 @@ struct hgs_handle {
   int ndt_chunk = 0;             // largest queue grab in items (0: the default, 8; 1 = one tile per grab); HGS_NDT_CHUNK (A/B runs)
   int ndt_sort = -1;       // NDT source order: -1 Hilbert order if the source has an index, 1 build the index first, 0 input order (HGS_NDT_SORT, A/B runs)
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
-  PinnedBuffer h_descs, h_results, h_small, h_flags, h_comm;  // h_flags: host-mapped progress mirror (Progress)
+  PinnedBuffer h_results, h_small, h_flags, h_comm;  // h_flags: host-mapped progress mirror (Progress)
+  PinnedRing up;                   // small uploads (descriptors, guesses, plans)
+  hipEvent_t upload_event = nullptr;  // hgs_cloud_create: the caller's buffer has been read
   PinnedBuffer h_xform;            // hgs_transform_source: the aligned cloud on its way down
   hipEvent_t xform_event[4] = {};
 
@@ -295,7 +351,7 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   c->desc.P = c->P;
   c->desc.sort_off = 0;
   c->desc.pad = 0;
-  (void)hipMemsetAsync(c->desc.corr, 0xff, slots * sizeof(int), h->stream);  // no correspondences yet (-1)
+  c->corr_stale = true;  // no correspondences yet: k_gather_sorted writes -1 when the index is built (every reader of corr has built it first)
   h->live_clouds.push_back(c);
   *out = c;
   return HGS_OK;
@@ -328,9 +384,11 @@ void cloud_free(hgs_cloud* c) {
 // Upload descriptors of a set of clouds (with their sort offsets) into h->descs; returns device pointer.
 int upload_descs(hgs_handle* h, const std::vector<hgs_cloud*>& clouds, bool with_sort_offsets, const CloudDesc** dev, size_t* total_n) {
   const size_t B = clouds.size();
-  HGS_HIP(h, h->h_descs.reserve(B * sizeof(CloudDesc)));
   HGS_HIP(h, h->descs.reserve(B * sizeof(CloudDesc)));
-  CloudDesc* hd = h->h_descs.as<CloudDesc>();
+  void* staged = nullptr;
+  int slot = 0;
+  HGS_HIP(h, h->up.stage(B * sizeof(CloudDesc), &staged, &slot));
+  CloudDesc* hd = static_cast<CloudDesc*>(staged);
   size_t off = 0;
   for (size_t i = 0; i < B; i++) {
     hd[i] = clouds[i]->desc;
@@ -339,6 +397,7 @@ int upload_descs(hgs_handle* h, const std::vector<hgs_cloud*>& clouds, bool with
   }
   if (total_n) *total_n = off;
   HGS_HIP(h, hipMemcpyAsync(h->descs.p, hd, B * sizeof(CloudDesc), hipMemcpyHostToDevice, h->stream));
+  HGS_HIP(h, h->up.commit(slot, h->stream));
   *dev = h->descs.as<CloudDesc>();
   return HGS_OK;
 }
@@ -398,9 +457,7 @@ int ensure_index(hgs_handle* h, const std::vector<hgs_cloud*>& all) {
     launch_gather_sorted(h->stream, d_descs, nc, max_P * kLeaf, h->sort_vals[1].as<unsigned>());
     launch_build_tree(h->stream, d_descs, nc, max_P);
     HGS_HIP(h, hipGetLastError());
-    // descs buffer is reused by later stages: make sure this chunk's kernels were enqueued before it is overwritten
-    // (stream order guarantees that; the pinned staging copy needs the H2D to have completed)
-    HGS_HIP(h, hipStreamSynchronize(h->stream));
+    // (the device-side descs buffer is reused by later stages in stream order; the pinned staging slot is guarded by its event, PinnedRing)
     for (hgs_cloud* c : chunk) c->has_index = true, c->corr_stale = false;
   }
   return HGS_OK;
@@ -430,7 +487,6 @@ int ensure_cov(hgs_handle* h, const std::vector<hgs_cloud*>& all, int k) {
   const int gather = h->knn_replay >= 0 ? h->knn_replay : 2;
   launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, qpw, h->prm.regularization_method, gather);
   HGS_HIP(h, hipGetLastError());
-  HGS_HIP(h, hipStreamSynchronize(h->stream));
   for (hgs_cloud* c : todo) c->has_cov = true, c->cov_k = key;
   return HGS_OK;
 }
@@ -782,7 +838,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   const CloudDesc* d_descs = nullptr;
   HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
   HGS_HIP(h, h->guesses.reserve((size_t)B * 16 * sizeof(float)));
-  HGS_HIP(h, hipMemcpyAsync(h->guesses.p, guesses_host, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HGS_HIP(h, h->up.upload(h->guesses.p, guesses_host, (size_t)B * 16 * sizeof(float), h->stream));  // (the caller's array is pageable: through a pinned slot)
   HGS_HIP(h, h->done.reserve(64));
   HGS_HIP(h, h->results.reserve((size_t)B * sizeof(DevResult)));
   HGS_HIP(h, h->partials.reserve((size_t)B * max_blocks * kAccNdt * sizeof(double)));
@@ -839,8 +895,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     bool sorted = h->ndt_sort != 0;
     for (hgs_cloud* sc : sources) sorted = sorted && sc->has_index;
     HGS_HIP(h, h->ndt_accum.reserve((size_t)B * sizeof(NdtAccum)));
-    HGS_HIP(h, hipMemsetAsync(h->ndt_accum.p, 0, (size_t)B * sizeof(NdtAccum), h->stream));
-    NdtAccum* accum = h->ndt_accum.as<NdtAccum>();
+    NdtAccum* accum = h->ndt_accum.as<NdtAccum>();  // zeroed by k_ndt_init (one dispatch less than a memset in front of it)
     // work plan of every lane: the (problem, tile) items of a pass are numbered by the prefix sums of the problems' tile counts
     // (from n_input: an upper bound of the finite points), and pulled from a queue head in HBM (k_ndt_pass)
     // one derivative pass per iteration as ndt_omp runs; up to 1 + 10 with the More-Thuente search
@@ -862,10 +917,14 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       bool tile_overflow = false;
       constexpr long long kMaxNdtBlocks = 1 << 16, kMaxNdtChunk = 1 << 10;  // far above anything HGS_NDT_RESIDENT / HGS_NDT_CHUNK are used with
       HGS_HIP(h, h->ndt_plan.reserve(per_lane * lanes.size()));
-      std::vector<char> host(per_lane * lanes.size(), 0);
+      void* staged = nullptr;
+      int plan_slot = 0;
+      HGS_HIP(h, h->up.stage(per_lane * lanes.size(), &staged, &plan_slot));
+      std::memset(staged, 0, per_lane * lanes.size());
+      char* const host = static_cast<char*>(staged);
       for (size_t li = 0; li < lanes.size(); li++) {
         const BatchLane& L = lanes[li];
-        int* tb = reinterpret_cast<int*>(host.data() + li * per_lane + 16);
+        int* tb = reinterpret_cast<int*>(host + li * per_lane + 16);
         tb[0] = 0;
         // k_ndt_pass does its item arithmetic in 32-bit ints (queue head + blocks * chunk must fit): bound the lane's tile count here
         long long tiles64 = 0;
@@ -888,9 +947,10 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
         h->err = "NDT batch too large: the tiles of one lane do not fit 32-bit item arithmetic (more than ~5e11 source points in one call)";
         return HGS_ERR_INVALID_ARGUMENT;
       }
-      HGS_HIP(h, hipMemcpy(h->ndt_plan.p, host.data(), host.size(), hipMemcpyHostToDevice));  // synchronous: `host` is pageable and dies here
+      HGS_HIP(h, hipMemcpyAsync(h->ndt_plan.p, host, per_lane * lanes.size(), hipMemcpyHostToDevice, h->stream));  // (round 4: a synchronous hipMemcpy of a pageable vector)
+      HGS_HIP(h, h->up.commit(plan_slot, h->stream));
     }
-    for (BatchLane& L : lanes) launch_ndt_init(L.stream, st + L.b0, ang + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, c, L.B, L.prog);
+    for (BatchLane& L : lanes) launch_ndt_init(L.stream, st + L.b0, ang + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, c, L.B, L.prog, accum + L.b0);
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       StageTimer tm(h, HGS_STAGE_LINEARIZE);
       const LanePlan& P = plans[&L - lanes.data()];
@@ -1085,7 +1145,8 @@ int hgs_destroy(hgs_handle* h) try {
     if (ls) (void)hipStreamDestroy(ls), g_streams_in_use.fetch_sub(1, std::memory_order_relaxed);
   for (auto& blk : h->block_pool) (void)hipFree(blk.first);
   h->block_pool.clear();
-  h->h_descs.release();
+  h->up.release();
+  if (h->upload_event) (void)hipEventDestroy(h->upload_event);
   h->h_results.release();
   h->h_small.release();
   h->h_comm.release();
@@ -1116,26 +1177,25 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
     if (n > 0) {
       hipError_t e = h->staging.reserve(n * stride_bytes);
       if (e == hipSuccess) e = hipMemcpyAsync(h->staging.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream);
+      // the caller may free / reuse `pts` after return: wait for THE COPY (an event right behind it), not for the kernels that follow —
+      // they run while the host goes on to enqueue the registration (round 4 synchronised the stream here: pack + bounding box, ~35 us per sweep)
+      if (e == hipSuccess && !h->upload_event) e = hipEventCreateWithFlags(&h->upload_event, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(h->upload_event, h->stream);
       if (e != hipSuccess) {
         h->err = std::string("upload failed: ") + hipGetErrorString(e);
         cloud_free(c);
         return HGS_ERR_HIP;
       }
-      launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)n, const_cast<float4*>(c->desc.raw), c->intensity);
     }
+    launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)n, const_cast<float4*>(c->desc.raw), c->intensity, c->desc.meta);  // (n == 0: the meta reset alone)
     // nvalid + bounding box of the finite points
     hipError_t e = h->descs.reserve(sizeof(CloudDesc));
-    if (e == hipSuccess) e = h->h_descs.reserve(sizeof(CloudDesc));
+    if (e == hipSuccess) e = h->up.upload(h->descs.p, &c->desc, sizeof(CloudDesc), h->stream);
     if (e == hipSuccess) {
-      *h->h_descs.as<CloudDesc>() = c->desc;
-      e = hipMemcpyAsync(h->descs.p, h->h_descs.p, sizeof(CloudDesc), hipMemcpyHostToDevice, h->stream);
-    }
-    if (e == hipSuccess) {
-      launch_meta_init(h->stream, h->descs.as<CloudDesc>(), 1);
-      launch_bbox_count(h->stream, h->descs.as<CloudDesc>(), 1, (int)n);
+      launch_bbox_count(h->stream, h->descs.as<CloudDesc>(), 1, (int)n);  // (the meta record was reset by the packing kernel)
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the caller may free / reuse `pts` after return
+    if (e == hipSuccess && n > 0) e = hipEventSynchronize(h->upload_event);
     if (e != hipSuccess) {
       h->err = std::string("cloud upload failed: ") + hipGetErrorString(e);
       cloud_free(c);
@@ -1210,10 +1270,7 @@ int hgs_set_target(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   hgs_cloud* c = nullptr;
   HGS_TRY(hgs_cloud_create(h, pts, n, stride_bytes, &c));
-  if (h->own_target) {
-    (void)hipStreamSynchronize(h->stream);
-    cloud_free(h->target);
-  }
+  if (h->own_target) cloud_free(h->target);
   h->target = c;
   h->own_target = true;
   return HGS_OK;
@@ -1226,10 +1283,7 @@ int hgs_set_source(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes
   if (!h) return HGS_ERR_INVALID_ARGUMENT;
   hgs_cloud* c = nullptr;
   HGS_TRY(hgs_cloud_create(h, pts, n, stride_bytes, &c));
-  if (h->own_source) {
-    (void)hipStreamSynchronize(h->stream);
-    cloud_free(h->source);
-  }
+  if (h->own_source) cloud_free(h->source);  // (its block is reused in stream order, or freed by hipFree, which waits by itself)
   h->source = c;
   h->own_source = true;
   return HGS_OK;
@@ -1351,7 +1405,7 @@ int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_by
   int* didx = reinterpret_cast<int*>((char*)h->misc.p + align_up(nq * sizeof(float4), 256));
   float* dd2 = reinterpret_cast<float*>(didx + nq);
   HGS_HIP(h, hipMemcpyAsync(h->staging.p, q_xyz, nq * stride_bytes, hipMemcpyHostToDevice, h->stream));
-  launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)nq, dq, nullptr);
+  launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)nq, dq, nullptr, nullptr);
   launch_nn_query(h->stream, target_view(h->target), dq, (int)nq, didx, dd2);
   HGS_HIP(h, hipMemcpyAsync(idx, didx, nq * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipMemcpyAsync(d2, dd2, nq * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1735,19 +1789,14 @@ int scan_u32(hgs_handle* h, const uint32_t* in, uint32_t* out, size_t n) {
 int cloud_from_device(hgs_handle* h, const float4* src, size_t m, hgs_cloud** out) {
   hgs_cloud* c = nullptr;
   HGS_TRY(cloud_alloc(h, m, &c));
-  launch_pf_to_cloud(h->stream, src, (int)m, const_cast<float4*>(c->desc.raw), c->intensity);
+  launch_pf_to_cloud(h->stream, src, (int)m, const_cast<float4*>(c->desc.raw), c->intensity, c->desc.meta);
   hipError_t e = h->descs.reserve(sizeof(CloudDesc));
-  if (e == hipSuccess) e = h->h_descs.reserve(sizeof(CloudDesc));
+  if (e == hipSuccess) e = h->up.upload(h->descs.p, &c->desc, sizeof(CloudDesc), h->stream);
   if (e == hipSuccess) {
-    *h->h_descs.as<CloudDesc>() = c->desc;
-    e = hipMemcpyAsync(h->descs.p, h->h_descs.p, sizeof(CloudDesc), hipMemcpyHostToDevice, h->stream);
-  }
-  if (e == hipSuccess) {
-    launch_meta_init(h->stream, h->descs.as<CloudDesc>(), 1);
-    launch_bbox_count(h->stream, h->descs.as<CloudDesc>(), 1, (int)m);
+    launch_bbox_count(h->stream, h->descs.as<CloudDesc>(), 1, (int)m);  // (the meta record was reset by k_pf_to_cloud)
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  // (no synchronisation: `src` is a device array of this engine, read in stream order)
   if (e != hipSuccess) {
     h->err = std::string("prefilter: building the resident cloud failed: ") + hipGetErrorString(e);
     cloud_free(c);

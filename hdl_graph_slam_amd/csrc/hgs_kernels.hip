@@ -235,41 +235,55 @@ __device__ __forceinline__ BvhView view_of(const TargetView& t) {
 }
 
 // ------------------------------------------------------------------------------------------------ upload
-__global__ __launch_bounds__(kBlock) void k_pack_aos(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ raw, float* __restrict__ intensity) {
+// (round 5) the packing kernel of a new cloud also resets the cloud's meta record — nvalid and the bounding box k_bbox_count accumulates into with atomics
+// right behind it in the stream: one dispatch less per uploaded sweep than the separate k_meta_init
+__device__ __forceinline__ void meta_reset(CloudMeta* m) {
+  m->nvalid = 0;
+  for (int d = 0; d < 3; d++) m->bbmin[d] = 0xffffffffu, m->bbmax[d] = 0u;
+}
+__global__ __launch_bounds__(kBlock) void k_pack_aos(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ raw, float* __restrict__ intensity, CloudMeta* meta) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (meta && i == 0) meta_reset(meta);
   if (i >= n) return;
   const float* f = reinterpret_cast<const float*>(staging + (size_t)i * stride);
   raw[i] = make_float4(f[0], f[1], f[2], __int_as_float(i));
   if (intensity) intensity[i] = stride >= 20 ? f[4] : 0.f;  // pcl::PointXYZI keeps the intensity at float 4
 }
-void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw, float* intensity) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_pack_aos, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const char*)staging, stride, n, raw, intensity);
+void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw, float* intensity, CloudMeta* meta) {
+  if (n <= 0 && !meta) return;
+  hipLaunchKernelGGL(k_pack_aos, dim3(std::max(1, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, (const char*)staging, stride, n, raw, intensity, meta);
 }
 
 // ------------------------------------------------------------------------------------------------ search index
 __global__ void k_meta_init(const CloudDesc* descs, int ncloud) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncloud) return;
-  CloudMeta* m = descs[c].meta;
-  m->nvalid = 0;
-  for (int d = 0; d < 3; d++) m->bbmin[d] = 0xffffffffu, m->bbmax[d] = 0u;
+  meta_reset(descs[c].meta);
 }
 void launch_meta_init(hipStream_t s, const CloudDesc* descs, int ncloud) {
   hipLaunchKernelGGL(k_meta_init, dim3((ncloud + 63) / 64), dim3(64), 0, s, descs, ncloud);
 }
 
+constexpr int kBboxPerThread = 4;
 __global__ __launch_bounds__(kBlock) void k_bbox_count(const CloudDesc* descs) {
   const CloudDesc d = descs[blockIdx.y];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   int cnt = 0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.n_input; i += gridDim.x * kBlock) {
-    const float4 p = d.raw[i];
-    if (finite3(p)) {
-      cnt++;
-      mn[0] = fminf(mn[0], p.x), mn[1] = fminf(mn[1], p.y), mn[2] = fminf(mn[2], p.z);
-      mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
+  // a thread's kBboxPerThread points are loaded together (round 4 walked them in a dependent loop: 22 us for one 119 k-point sweep — eight L2 round trips)
+  for (int i0 = blockIdx.x * kBlock * kBboxPerThread + threadIdx.x; i0 < d.n_input; i0 += gridDim.x * kBlock * kBboxPerThread) {
+    float4 p[kBboxPerThread];
+#pragma unroll
+    for (int k = 0; k < kBboxPerThread; k++) {
+      const int i = i0 + k * kBlock;
+      p[k] = i < d.n_input ? d.raw[i] : make_float4(NAN, NAN, NAN, 0.f);
     }
+#pragma unroll
+    for (int k = 0; k < kBboxPerThread; k++)
+      if (finite3(p[k])) {
+        cnt++;
+        mn[0] = fminf(mn[0], p[k].x), mn[1] = fminf(mn[1], p[k].y), mn[2] = fminf(mn[2], p[k].z);
+        mx[0] = fmaxf(mx[0], p[k].x), mx[1] = fmaxf(mx[1], p[k].y), mx[2] = fmaxf(mx[2], p[k].z);
+      }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_count(const CloudDesc* descs) {
   }
 }
 void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n) {
-  int gx = (max_n + kBlock * 8 - 1) / (kBlock * 8);
+  int gx = (max_n + kBlock * kBboxPerThread - 1) / (kBlock * kBboxPerThread);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(k_bbox_count, dim3(gx, ncloud), dim3(kBlock), 0, s, descs);
 }
@@ -1051,15 +1065,24 @@ void launch_ndt_build_cells(hipStream_t s, CloudDesc desc, const unsigned long l
 }
 
 // ------------------------------------------------------------------------------------------------ NDT iteration
-__global__ void k_ndt_init(NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0) prog.dev[0] = 0, prog.dev[1] = 0;
-  if (b >= B) return;
-  ndt_state_init(states[b], guesses + 16 * b);
-  ndt_angle_tables(states[b].p, c.upstream_hd1_sign, angles[b]);
+// one 64-thread block per problem: thread 0 sets the state up, all of them zero the problem's digit totals (a separate memset in front of this kernel
+// was one more dispatch on the single-registration path)
+__global__ __launch_bounds__(64) void k_ndt_init(NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog, NdtAccum* accum) {
+  const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0) prog.dev[0] = 0, prog.dev[1] = 0;
+  if (accum) {
+    static_assert(sizeof(NdtAccum) % sizeof(unsigned long long) == 0, "NdtAccum is zeroed word by word");
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(accum + b);
+    for (int k = threadIdx.x; k < (int)(sizeof(NdtAccum) / sizeof(unsigned long long)); k += 64) w[k] = 0ull;
+  }
+  if (threadIdx.x == 0) {
+    ndt_state_init(states[b], guesses + 16 * b);
+    ndt_angle_tables(states[b].p, c.upstream_hd1_sign, angles[b]);
+  }
 }
-void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog) {
-  hipLaunchKernelGGL(k_ndt_init, dim3((B + 63) / 64), dim3(64), 0, s, states, angles, guesses, c, B, prog);
+void launch_ndt_init(hipStream_t s, NdtState* states, NdtAngles* angles, const float* guesses, NdtConsts c, int B, Progress prog, NdtAccum* accum_to_zero) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_ndt_init, dim3(B), dim3(64), 0, s, states, angles, guesses, c, B, prog, accum_to_zero);
 }
 
 // hash_kv[slot] = (key, cell index): one 8-byte load per probe in the derivative kernel
@@ -2183,15 +2206,16 @@ void launch_map_centers(hipStream_t s, const unsigned long long* keys, const uns
 }
 
 // pack a resident float4 {x,y,z,intensity} array into a cloud: raw = {x,y,z,index}, intensity kept beside it
-__global__ __launch_bounds__(kBlock) void k_pf_to_cloud(const float4* __restrict__ in, int n, float4* __restrict__ raw, float* __restrict__ intensity) {
+__global__ __launch_bounds__(kBlock) void k_pf_to_cloud(const float4* __restrict__ in, int n, float4* __restrict__ raw, float* __restrict__ intensity, CloudMeta* meta) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) meta_reset(meta);
   if (i >= n) return;
   const float4 p = in[i];
   raw[i] = make_float4(p.x, p.y, p.z, __int_as_float(i));
   intensity[i] = p.w;
 }
-void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity) {
-  if (n > 0) hipLaunchKernelGGL(k_pf_to_cloud, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, in, n, raw, intensity);
+void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity, CloudMeta* meta) {
+  hipLaunchKernelGGL(k_pf_to_cloud, dim3(std::max(1, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, in, n, raw, intensity, meta);
 }
 
 }  // namespace hgs
