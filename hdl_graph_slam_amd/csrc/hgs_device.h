@@ -92,7 +92,7 @@ constexpr int kNW = 1;                    // packets of 64 queries a wave walks 
 constexpr int kTileNN = kBlock * kNW;     // source points per block of k_gicp_linearize / k_fitness
 
 // ---- launchers (hgs_kernels.hip) --------------------------------------------------------------------------
-void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw, float* intensity /* may be null */, CloudMeta* meta_to_reset /* may be null */);
+void launch_pack_aos(hipStream_t s, const float4* staged /* {x, y, z, intensity} */, int n, float4* raw, float* intensity /* may be null */, CloudMeta* meta_to_reset /* may be null */);
 void launch_meta_init(hipStream_t s, const CloudDesc* descs, int ncloud);
 void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n);
 void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals, int drop_bits);
@@ -177,7 +177,7 @@ void launch_map_centers(hipStream_t s, const unsigned long long* keys, const uns
                         int* count_out);
 
 // prefilter (apps/prefiltering_nodelet.cpp)
-void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out, const float* deskew_w /* -(gyro rate), or null */, double scan_period);
+void launch_pf_load(hipStream_t s, const float4* staged /* {x, y, z, intensity} */, int n, float4* out, const float* deskew_w /* -(gyro rate), or null */, double scan_period);
 void launch_pf_distance_flags(hipStream_t s, const float4* pts, int n, int use_filter, double near_thresh, double far_thresh, unsigned* keep);
 void launch_pf_compact(hipStream_t s, const float4* in, int n, const unsigned* keep, const unsigned* slot, float4* out, int* count);
 void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta);

@@ -194,6 +194,7 @@ struct hgs_handle {
   // block-per-problem solve / decide kernels of one lane run under the point kernels of the others
   hipStream_t lane_stream[7] = {};  // kMaxLanes - 1
   hipEvent_t lane_event[8] = {};
+  int lane_start = 1;                // 1: the host synchronises before it releases the lanes of a batch (open_lanes); HGS_LANE_START=0: not (A/B runs)
   int nn_qpw = 0;  // 0: chosen per launch (nn_queries_per_wave)
   // levels of the Hilbert curve the index sort compares (HGS_HILBERT_LEVELS, A/B runs; 16 = all 48 bits, rounds 1-3).  64 x 119 k batch, index stage / step:
   // 16 -> 0.915 / 11.99 ms, 13 -> 0.83 / 11.93, 11 -> 0.75 / 11.91, 10 -> 0.75 / 12.1, 9 -> 0.75 / 12.7 (the walks slow down once a cell of the finest compared
@@ -229,7 +230,7 @@ struct hgs_handle {
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_results, h_small, h_flags, h_comm;  // h_flags: host-mapped progress mirror (Progress)
   PinnedRing up;                   // small uploads (descriptors, guesses, plans)
-  hipEvent_t upload_event = nullptr;  // hgs_cloud_create: the caller's buffer has been read
+  PinnedRing up_points;            // point uploads: pinned chunks the host packs into (upload_points_packed)
   PinnedBuffer h_xform;            // hgs_transform_source: the aligned cloud on its way down
   hipEvent_t xform_event[4] = {};
 
@@ -294,6 +295,43 @@ struct StageTimer {
 
 int set_device(hgs_handle* h) {
   HGS_HIP(h, hipSetDevice(h->device));
+  return HGS_OK;
+}
+
+// ---- point upload --------------------------------------------------------------------------------------------
+// Host -> device of n strided point records (pcl::PointXYZI: 32 bytes; anything with x, y, z at floats 0..2 and, from 20 bytes on, the intensity
+// at float 4) as packed 16-byte records {x, y, z, intensity} in h->staging.  The HOST packs chunk after chunk into pinned buffers (half the bytes
+// of a PointXYZI go over PCIe, none of them through the runtime's pageable staging path) and every chunk's DMA runs while the next chunk is packed.
+// Round 4 handed the caller's pageable buffer to hipMemcpyAsync: 0.48 ms for one 119 k-point sweep (7.9 GB/s: the runtime copies into its own staging
+// buffers first and does not overlap that with the DMA) — two thirds of a raw-sweep odometry step (profiles/r05_upload.md).
+// The caller's buffer has been read completely when this returns; the device side is ordered on h->stream.
+constexpr size_t kUploadChunkPoints = 16384;  // 256 KB per pinned chunk
+int upload_points_packed(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const float4** dev) {
+  HGS_HIP(h, h->staging.reserve(std::max<size_t>(n, 1) * sizeof(float4)));
+  *dev = h->staging.as<float4>();
+  const bool has_intensity = stride_bytes >= 20;
+  const char* src = static_cast<const char*>(pts);
+  for (size_t i0 = 0; i0 < n; i0 += kUploadChunkPoints) {
+    const size_t m = std::min(kUploadChunkPoints, n - i0);
+    void* staged = nullptr;
+    int slot = 0;
+    HGS_HIP(h, h->up_points.stage(kUploadChunkPoints * sizeof(float4), &staged, &slot));
+    float* dst = static_cast<float*>(staged);
+    const char* s0 = src + i0 * stride_bytes;
+    if (has_intensity) {
+      for (size_t i = 0; i < m; i++) {
+        const float* f = reinterpret_cast<const float*>(s0 + i * stride_bytes);
+        dst[4 * i] = f[0], dst[4 * i + 1] = f[1], dst[4 * i + 2] = f[2], dst[4 * i + 3] = f[4];
+      }
+    } else {
+      for (size_t i = 0; i < m; i++) {
+        const float* f = reinterpret_cast<const float*>(s0 + i * stride_bytes);
+        dst[4 * i] = f[0], dst[4 * i + 1] = f[1], dst[4 * i + 2] = f[2], dst[4 * i + 3] = 0.f;
+      }
+    }
+    HGS_HIP(h, hipMemcpyAsync(h->staging.as<float4>() + i0, staged, m * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    HGS_HIP(h, h->up_points.commit(slot, h->stream));
+  }
   return HGS_OK;
 }
 
@@ -737,6 +775,13 @@ int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t pa
     L.partials = h->lane_partials[i - 1].as<double>(), L.partials_err = h->lane_partials_err[i - 1].as<double>();
   }
   if (n > 1) {
+    // Round 5 removed the host synchronisations behind the index build and the covariance pass (they only protected a pinned staging buffer: PinnedRing).
+    // For a batch with several lanes one synchronisation stays HERE, because it measures faster: with it the host enqueues lane after lane onto an idle
+    // device; without it every lane's first rounds are already queued behind one event when the covariance pass ends and all lanes are released in the
+    // same instant — 5306 instead of 5381 registrations/s FAST_GICP, 7435 / 7574 PLANE, 2307 / 2317 NDT_OMP (same library, HGS_LANE_START=0 / 1,
+    // profiles/r05_lane_start.log).  Releasing lane i + 1 behind lane i's first point kernel instead (a deliberate stagger) is worse than both
+    // (5250 / 7269): the ramp costs three unseeded linearisations.  A single registration (one lane) never gets here.
+    if (h->lane_start != 0) HGS_HIP(h, hipStreamSynchronize(h->stream));
     if (!h->lane_event[0]) HGS_HIP(h, hipEventCreateWithFlags(&h->lane_event[0], hipEventDisableTiming));
     HGS_HIP(h, hipEventRecord(h->lane_event[0], h->stream));
     for (int i = 1; i < n; i++) HGS_HIP(h, hipStreamWaitEvent(lanes[i].stream, h->lane_event[0], 0));
@@ -956,7 +1001,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       const LanePlan& P = plans[&L - lanes.data()];
       launch_ndt_pass(L.stream, d_descs + L.b0, tv, st + L.b0, ang + L.b0, c, accum + L.b0, P.tile_base, P.queues, L.B, (int)(L.round & 1), P.blocks, P.chunk,
                       sorted ? 1 : 0, 0, L.prog);
-    }, finish_lane);
+    }, finish_lane);  // (NDT: one kernel per round, the Newton step inside it — nothing to stagger)
     HGS_TRY(close_lanes(h, lanes));
   }
   HGS_HIP(h, hipGetLastError());
@@ -1094,6 +1139,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
   for (int i = 0; i < 16; i++) h->final_T[i] = (i % 5 == 0) ? 1.f : 0.f;
   for (int i = 0; i < HGS_STAGE_COUNT; i++) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
   if (const char* e = std::getenv("HGS_BATCH_LANES")) h->batch_lanes = std::max(1, std::min(kMaxLanes, std::atoi(e)));  // A/B measurements
+  if (const char* e = std::getenv("HGS_LANE_START")) h->lane_start = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("HGS_NDT_SORT")) h->ndt_sort = std::max(-1, std::min(1, std::atoi(e)));
   if (const char* e = std::getenv("HGS_KNN_REPLAY")) h->knn_replay = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("HGS_NDT_RESIDENT")) h->ndt_resident_blocks = std::max(1, std::atoi(e));
@@ -1146,7 +1192,7 @@ int hgs_destroy(hgs_handle* h) try {
   for (auto& blk : h->block_pool) (void)hipFree(blk.first);
   h->block_pool.clear();
   h->up.release();
-  if (h->upload_event) (void)hipEventDestroy(h->upload_event);
+  h->up_points.release();
   h->h_results.release();
   h->h_small.release();
   h->h_comm.release();
@@ -1174,20 +1220,15 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
   HGS_TRY(cloud_alloc(h, n, &c));
   {
     StageTimer tm(h, HGS_STAGE_UPLOAD);
-    if (n > 0) {
-      hipError_t e = h->staging.reserve(n * stride_bytes);
-      if (e == hipSuccess) e = hipMemcpyAsync(h->staging.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream);
-      // the caller may free / reuse `pts` after return: wait for THE COPY (an event right behind it), not for the kernels that follow —
-      // they run while the host goes on to enqueue the registration (round 4 synchronised the stream here: pack + bounding box, ~35 us per sweep)
-      if (e == hipSuccess && !h->upload_event) e = hipEventCreateWithFlags(&h->upload_event, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventRecord(h->upload_event, h->stream);
-      if (e != hipSuccess) {
-        h->err = std::string("upload failed: ") + hipGetErrorString(e);
+    const float4* staged = nullptr;
+    {
+      const int rc = upload_points_packed(h, pts, n, stride_bytes, &staged);
+      if (rc != HGS_OK) {
         cloud_free(c);
-        return HGS_ERR_HIP;
+        return rc;
       }
     }
-    launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)n, const_cast<float4*>(c->desc.raw), c->intensity, c->desc.meta);  // (n == 0: the meta reset alone)
+    launch_pack_aos(h->stream, staged, (int)n, const_cast<float4*>(c->desc.raw), c->intensity, c->desc.meta);  // (n == 0: the meta reset alone)
     // nvalid + bounding box of the finite points
     hipError_t e = h->descs.reserve(sizeof(CloudDesc));
     if (e == hipSuccess) e = h->up.upload(h->descs.p, &c->desc, sizeof(CloudDesc), h->stream);
@@ -1195,7 +1236,7 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
       launch_bbox_count(h->stream, h->descs.as<CloudDesc>(), 1, (int)n);  // (the meta record was reset by the packing kernel)
       e = hipGetLastError();
     }
-    if (e == hipSuccess && n > 0) e = hipEventSynchronize(h->upload_event);
+    // (no synchronisation: the caller's buffer was read by the host while packing; everything else is ordered on the stream)
     if (e != hipSuccess) {
       h->err = std::string("cloud upload failed: ") + hipGetErrorString(e);
       cloud_free(c);
@@ -1399,13 +1440,13 @@ int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_by
   HGS_TRY(set_device(h));
   std::vector<hgs_cloud*> all{h->target};
   HGS_TRY(ensure_index(h, all));
-  HGS_HIP(h, h->staging.reserve(nq * stride_bytes));
   HGS_HIP(h, h->misc.reserve(nq * (sizeof(float4) + 8) + 512));
   float4* dq = h->misc.as<float4>();
   int* didx = reinterpret_cast<int*>((char*)h->misc.p + align_up(nq * sizeof(float4), 256));
   float* dd2 = reinterpret_cast<float*>(didx + nq);
-  HGS_HIP(h, hipMemcpyAsync(h->staging.p, q_xyz, nq * stride_bytes, hipMemcpyHostToDevice, h->stream));
-  launch_pack_aos(h->stream, h->staging.p, stride_bytes, (int)nq, dq, nullptr, nullptr);
+  const float4* staged = nullptr;
+  HGS_TRY(upload_points_packed(h, q_xyz, nq, stride_bytes, &staged));
+  launch_pack_aos(h->stream, staged, (int)nq, dq, nullptr, nullptr);
   launch_nn_query(h->stream, target_view(h->target), dq, (int)nq, didx, dd2);
   HGS_HIP(h, hipMemcpyAsync(idx, didx, nq * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipMemcpyAsync(d2, dd2, nq * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1840,7 +1881,6 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
   *out = nullptr;
   StageTimer tm(h, HGS_STAGE_PREFILTER);
   const size_t cap = std::max<size_t>(n, 1);
-  HGS_HIP(h, h->staging.reserve(cap * stride_bytes));
   HGS_HIP(h, h->pf_a.reserve(cap * sizeof(float4)));
   HGS_HIP(h, h->pf_b.reserve(cap * sizeof(float4)));
   HGS_HIP(h, h->pf_keep.reserve(cap * sizeof(uint32_t)));
@@ -1853,11 +1893,12 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
   unsigned* d_meta = h->pf_small.as<unsigned>() + 16;      // voxel-grid bbox / grid parameters
   double* d_stats = reinterpret_cast<double*>(h->pf_small.as<char>() + 192);
   if (n > 0) {
-    HGS_HIP(h, hipMemcpyAsync(h->staging.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream));
-    launch_pf_load(h->stream, h->staging.p, stride_bytes, (int)n, cur, deskew_w, scan_period);
+    const float4* staged = nullptr;
+    HGS_TRY(upload_points_packed(h, pts, n, stride_bytes, &staged));
+    launch_pf_load(h->stream, staged, (int)n, cur, deskew_w, scan_period);
   }
   int host_n = (int)n;
-  HGS_HIP(h, hipMemcpyAsync(d_count, &host_n, sizeof(int), hipMemcpyHostToDevice, h->stream));  // (pageable 4-byte copy: staged by the runtime)
+  HGS_HIP(h, h->up.upload(d_count, &host_n, sizeof(int), h->stream));
   if (n > 0 && p->use_distance_filter) {
     launch_pf_distance_flags(h->stream, cur, (int)n, 1, p->distance_near_thresh, p->distance_far_thresh, h->pf_keep.as<unsigned>());
     HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));

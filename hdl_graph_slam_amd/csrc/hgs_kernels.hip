@@ -241,17 +241,18 @@ __device__ __forceinline__ void meta_reset(CloudMeta* m) {
   m->nvalid = 0;
   for (int d = 0; d < 3; d++) m->bbmin[d] = 0xffffffffu, m->bbmax[d] = 0u;
 }
-__global__ __launch_bounds__(kBlock) void k_pack_aos(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ raw, float* __restrict__ intensity, CloudMeta* meta) {
+// `staged`: the points as the host packed them on their way up (hgs_engine.hip, upload_points_packed): 16-byte records {x, y, z, intensity}
+__global__ __launch_bounds__(kBlock) void k_pack_aos(const float4* __restrict__ staged, int n, float4* __restrict__ raw, float* __restrict__ intensity, CloudMeta* meta) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (meta && i == 0) meta_reset(meta);
   if (i >= n) return;
-  const float* f = reinterpret_cast<const float*>(staging + (size_t)i * stride);
-  raw[i] = make_float4(f[0], f[1], f[2], __int_as_float(i));
-  if (intensity) intensity[i] = stride >= 20 ? f[4] : 0.f;  // pcl::PointXYZI keeps the intensity at float 4
+  const float4 p = staged[i];
+  raw[i] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+  if (intensity) intensity[i] = p.w;
 }
-void launch_pack_aos(hipStream_t s, const void* staging, size_t stride, int n, float4* raw, float* intensity, CloudMeta* meta) {
+void launch_pack_aos(hipStream_t s, const float4* staged, int n, float4* raw, float* intensity, CloudMeta* meta) {
   if (n <= 0 && !meta) return;
-  hipLaunchKernelGGL(k_pack_aos, dim3(std::max(1, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, (const char*)staging, stride, n, raw, intensity, meta);
+  hipLaunchKernelGGL(k_pack_aos, dim3(std::max(1, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, staged, n, raw, intensity, meta);
 }
 
 // ------------------------------------------------------------------------------------------------ search index
@@ -1732,18 +1733,17 @@ void launch_vgicp_error(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt
 // of the NDT / VGICP targets with FLOAT centroids accumulated in input order (CentroidPoint semantics).
 // deskew != 0: the deskewing step of cloud_callback (:112, :182-243) on the way in — point i of the sweep rotated back by the
 // first-order rotation of delta_t = scan_period * i / n at the gyro rate w (pf_deskew_point, hgs_math.h).
-__global__ __launch_bounds__(kBlock) void k_pf_load(const char* __restrict__ staging, size_t stride, int n, float4* __restrict__ out, int deskew, float wx, float wy,
-                                                    float wz, double scan_period) {
+__global__ __launch_bounds__(kBlock) void k_pf_load(const float4* __restrict__ staged, int n, float4* __restrict__ out, int deskew, float wx, float wy, float wz, double scan_period) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const float* f = reinterpret_cast<const float*>(staging + (size_t)i * stride);
-  float x = f[0], y = f[1], z = f[2];
+  const float4 p = staged[i];  // {x, y, z, intensity}, packed by the host (upload_points_packed)
+  float x = p.x, y = p.y, z = p.z;
   if (deskew) pf_deskew_point(wx, wy, wz, scan_period, i, n, &x, &y, &z);
-  out[i] = make_float4(x, y, z, stride >= 20 ? f[4] : 0.f);
+  out[i] = make_float4(x, y, z, p.w);
 }
-void launch_pf_load(hipStream_t s, const void* staging, size_t stride, int n, float4* out, const float* deskew_w, double scan_period) {
+void launch_pf_load(hipStream_t s, const float4* staged, int n, float4* out, const float* deskew_w, double scan_period) {
   if (n > 0)
-    hipLaunchKernelGGL(k_pf_load, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (const char*)staging, stride, n, out, deskew_w ? 1 : 0, deskew_w ? deskew_w[0] : 0.f,
+    hipLaunchKernelGGL(k_pf_load, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, staged, n, out, deskew_w ? 1 : 0, deskew_w ? deskew_w[0] : 0.f,
                        deskew_w ? deskew_w[1] : 0.f, deskew_w ? deskew_w[2] : 0.f, scan_period);
 }
 
