@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <climits>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -139,6 +140,96 @@ struct PinnedRing {
   }
 };
 
+// A few helper threads that pack point records next to the calling thread (upload_points_packed).  One core reads a cold 3.8 MB sweep from DRAM at
+// ~8-10 GB/s — 0.45 ms, whether it is this code or the HIP runtime's pageable path doing it — so a large upload is split over kWorkers + 1 threads.
+// The workers only touch host memory (no HIP call); they sleep on a condition variable between uploads and are joined by hgs_destroy.
+struct PackPool {
+  static constexpr int kWorkers = 3;
+  struct Job {
+    const char* src = nullptr;
+    float* dst = nullptr;
+    size_t n = 0, stride = 0, chunk = 0, nchunks = 0;
+    bool has_intensity = false;
+    std::atomic<size_t> next{0};
+    std::atomic<unsigned char>* ready = nullptr;  // [nchunks]
+  };
+  std::vector<std::thread> threads;
+  std::mutex m;
+  std::condition_variable cv;
+  Job* job = nullptr;   // guarded by m
+  unsigned long generation = 0;
+  int active = 0;       // workers inside the current job
+  bool stop = false;
+
+  static void pack_chunk(const Job& j, size_t c) {
+    const size_t i0 = c * j.chunk, m = std::min(j.chunk, j.n - i0);
+    const char* s0 = j.src + i0 * j.stride;
+    float* dst = j.dst + 4 * i0;
+    if (j.has_intensity) {
+      for (size_t i = 0; i < m; i++) {
+        const float* f = reinterpret_cast<const float*>(s0 + i * j.stride);
+        dst[4 * i] = f[0], dst[4 * i + 1] = f[1], dst[4 * i + 2] = f[2], dst[4 * i + 3] = f[4];
+      }
+    } else {
+      for (size_t i = 0; i < m; i++) {
+        const float* f = reinterpret_cast<const float*>(s0 + i * j.stride);
+        dst[4 * i] = f[0], dst[4 * i + 1] = f[1], dst[4 * i + 2] = f[2], dst[4 * i + 3] = 0.f;
+      }
+    }
+    j.ready[c].store(1, std::memory_order_release);
+  }
+  // takes chunks until none is left; false if there was none
+  static bool help(Job& j) {
+    const size_t c = j.next.fetch_add(1, std::memory_order_relaxed);
+    if (c >= j.nchunks) return false;
+    pack_chunk(j, c);
+    return true;
+  }
+  void worker() {
+    unsigned long seen = 0;
+    for (;;) {
+      Job* j = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || (job && generation != seen); });
+        if (stop) return;
+        seen = generation, j = job, active++;
+      }
+      while (help(*j)) {
+      }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        active--;
+      }
+      cv.notify_all();
+    }
+  }
+  void post(Job* j) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      if (threads.empty())
+        for (int i = 0; i < kWorkers; i++) threads.emplace_back([this] { worker(); });
+      job = j, generation++;
+    }
+    cv.notify_all();
+  }
+  // the job's memory may go away after this: no worker is inside it, none will enter it
+  void retire() {
+    std::unique_lock<std::mutex> lk(m);
+    job = nullptr;
+    cv.wait(lk, [&] { return active == 0; });
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv.notify_all();
+    for (std::thread& t : threads) t.join();
+    threads.clear();
+  }
+};
+
 int next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -230,7 +321,11 @@ struct hgs_handle {
   DeviceBuffer pf_a, pf_b, pf_keep, pf_slot, pf_small, pf_dist;  // prefilter work space
   PinnedBuffer h_results, h_small, h_flags, h_comm;  // h_flags: host-mapped progress mirror (Progress)
   PinnedRing up;                   // small uploads (descriptors, guesses, plans)
-  PinnedRing up_points;            // point uploads: pinned chunks the host packs into (upload_points_packed)
+  PinnedRing up_points;            // small point uploads: pinned chunks the host packs into (upload_points_packed)
+  PinnedBuffer up_big;             // large point uploads: one pinned image of the packed cloud, filled by the pack pool
+  hipEvent_t up_big_event = nullptr;  // the last DMA out of up_big
+  bool up_big_pending = false;
+  PackPool pack_pool;
   PinnedBuffer h_xform;            // hgs_transform_source: the aligned cloud on its way down
   hipEvent_t xform_event[4] = {};
 
@@ -305,12 +400,41 @@ int set_device(hgs_handle* h) {
 // Round 4 handed the caller's pageable buffer to hipMemcpyAsync: 0.48 ms for one 119 k-point sweep (7.9 GB/s: the runtime copies into its own staging
 // buffers first and does not overlap that with the DMA) — two thirds of a raw-sweep odometry step (profiles/r05_upload.md).
 // The caller's buffer has been read completely when this returns; the device side is ordered on h->stream.
-constexpr size_t kUploadChunkPoints = 16384;  // 256 KB per pinned chunk
+constexpr size_t kUploadChunkPoints = 16384;     // 256 KB per pinned chunk
+constexpr size_t kUploadParallelPoints = 49152;  // from three chunks on the pack pool helps (below: one thread, the ring of pinned chunks)
 int upload_points_packed(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const float4** dev) {
   HGS_HIP(h, h->staging.reserve(std::max<size_t>(n, 1) * sizeof(float4)));
   *dev = h->staging.as<float4>();
   const bool has_intensity = stride_bytes >= 20;
   const char* src = static_cast<const char*>(pts);
+  if (n >= kUploadParallelPoints) {
+    // large cloud: kWorkers + this thread pack chunks into ONE pinned image; this thread sends chunk c down as soon as it is ready (in order)
+    if (h->up_big_pending) {
+      HGS_HIP(h, hipEventSynchronize(h->up_big_event));  // the previous upload's DMA has left the pinned image (it finished long ago)
+      h->up_big_pending = false;
+    }
+    HGS_HIP(h, h->up_big.reserve(n * sizeof(float4)));
+    const size_t nchunks = (n + kUploadChunkPoints - 1) / kUploadChunkPoints;
+    std::vector<std::atomic<unsigned char>> ready(nchunks);
+    for (auto& r : ready) r.store(0, std::memory_order_relaxed);
+    PackPool::Job job;
+    job.src = src, job.dst = h->up_big.as<float>(), job.n = n, job.stride = stride_bytes, job.chunk = kUploadChunkPoints, job.nchunks = nchunks;
+    job.has_intensity = has_intensity, job.ready = ready.data();
+    h->pack_pool.post(&job);
+    hipError_t err = hipSuccess;
+    for (size_t c = 0; c < nchunks; c++) {
+      while (!ready[c].load(std::memory_order_acquire))
+        if (!PackPool::help(job)) std::this_thread::yield();
+      const size_t i0 = c * kUploadChunkPoints, m = std::min(kUploadChunkPoints, n - i0);
+      if (err == hipSuccess) err = hipMemcpyAsync(h->staging.as<float4>() + i0, h->up_big.as<float4>() + i0, m * sizeof(float4), hipMemcpyHostToDevice, h->stream);
+    }
+    h->pack_pool.retire();  // (`job` and `ready` live on this stack frame)
+    HGS_HIP(h, err);
+    if (!h->up_big_event) HGS_HIP(h, hipEventCreateWithFlags(&h->up_big_event, hipEventDisableTiming));
+    HGS_HIP(h, hipEventRecord(h->up_big_event, h->stream));
+    h->up_big_pending = true;
+    return HGS_OK;
+  }
   for (size_t i0 = 0; i0 < n; i0 += kUploadChunkPoints) {
     const size_t m = std::min(kUploadChunkPoints, n - i0);
     void* staged = nullptr;
@@ -1193,6 +1317,9 @@ int hgs_destroy(hgs_handle* h) try {
   h->block_pool.clear();
   h->up.release();
   h->up_points.release();
+  h->pack_pool.shutdown();
+  h->up_big.release();
+  if (h->up_big_event) (void)hipEventDestroy(h->up_big_event);
   h->h_results.release();
   h->h_small.release();
   h->h_comm.release();

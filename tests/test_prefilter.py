@@ -149,6 +149,42 @@ def test_cloud_download_round_trip():
     reg.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,layout", [(70001, "xyzi"), (200000, "xyzi"), (60000, "xyz12"), (60000, "xyz16"), (16384, "xyzi"), (0, "xyzi")])
+def test_large_upload_round_trip_through_the_pack_pool(n, layout):
+    """Uploads are packed by the host into pinned memory — clouds of >= 49152 points by the engine's helper threads, chunk by chunk, each chunk's DMA
+    under the packing of the next (hgs_engine.hip, upload_points_packed): every layout and size class comes back bit for bit, NaN records included,
+    and repeated uploads reuse the pinned image safely."""
+    from hdl_graph_slam_amd import _lib as L, synth
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    rng = np.random.default_rng(n + len(layout))
+    xyz = rng.normal(0, 20, (n, 3)).astype(np.float32)
+    if n > 10:
+        xyz[rng.integers(0, n, 7)] = np.nan
+    reg = RegistrationHIP(L.default_params(L.HGS_NDT_OMP))
+    for rep in range(3):    # the second and third upload meet the previous one's pinned buffers
+        xyz_r = xyz + np.float32(rep)
+        if layout == "xyzi":
+            cloud = synth.to_xyzi(xyz_r, intensity=rng.random(n).astype(np.float32))
+        elif layout == "xyz12":
+            cloud = np.ascontiguousarray(xyz_r)
+        else:
+            cloud = np.zeros((n, 4), np.float32)
+            cloud[:, :3] = xyz_r
+        d = reg.upload(cloud)
+        got = d.download()
+        assert d.size == n
+        want = synth.xyz_of(cloud) if n else np.zeros((0, 3), np.float32)
+        for k, f in enumerate(("x", "y", "z")):
+            assert np.array_equal(got[f], want[:, k], equal_nan=True), (layout, rep, f)
+        if layout == "xyzi":
+            assert np.array_equal(got["intensity"], cloud["intensity"])
+        else:
+            assert not got["intensity"].any()
+        d.close()
+    reg.close()
+
+
 def _py_approx_voxelgrid(cloud, leaf):
     """pcl::ApproximateVoxelGrid as PCL runs it — a plain sequential loop over the points with the 512-entry history table —
     independent of oracle/prefilter.hpp and of the device's sort-based form."""

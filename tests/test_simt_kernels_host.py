@@ -323,6 +323,11 @@ def test_gpu_suite_prefilter_edges_and_download():
     _gpu_test("test_prefilter", "test_cloud_download_round_trip")()
 
 
+@pytest.mark.parametrize("n,layout", [(70001, "xyzi"), (60000, "xyz12"), (16384, "xyzi"), (0, "xyzi")])
+def test_gpu_suite_large_upload_through_the_pack_pool(n, layout):
+    _gpu_test("test_prefilter", "test_large_upload_round_trip_through_the_pack_pool")(n, layout)
+
+
 @pytest.mark.parametrize("res", [0.5, 0.05])
 def test_gpu_suite_map_cloud(res):
     _gpu_test("test_map_cloud", "test_hip_map_cloud_matches_oracle")(res)      # 0.05 includes the > 2^31-cell map
