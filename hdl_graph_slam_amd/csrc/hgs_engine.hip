@@ -467,11 +467,15 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   c->P = next_pow2((int)((n + kLeaf - 1) / kLeaf));
   if (c->P < 1) c->P = 1;
   const size_t slots = (size_t)c->P * kLeaf;
+  // the per-input-point arrays are sized for n rounded up to 8192 points: consecutive sweeps of one sensor differ by a few hundred returns, and a
+  // block that is a few bytes too small for the next sweep cannot be reused from the pool — the odometry path then paid a hipMalloc and (pool full)
+  // a hipFree, which synchronises the device, on most sweeps: 0.3-0.4 ms of a 0.7 ms raw-sweep step (profiles/r05_upload.md)
+  const size_t n_cap = align_up(std::max<size_t>(n, 1), 8192);
   size_t off = 0;
   const size_t o_meta = off;
   off = align_up(off + sizeof(CloudMeta), 256);
   const size_t o_raw = off;
-  off = align_up(off + std::max<size_t>(n, 1) * sizeof(float4), 256);
+  off = align_up(off + n_cap * sizeof(float4), 256);
   const size_t o_pts = off;
   off = align_up(off + slots * sizeof(float4), 256);
   const size_t o_lpts = off;
@@ -483,7 +487,7 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   const size_t o_corr = off;
   off = align_up(off + slots * sizeof(int), 256);
   const size_t o_int = off;
-  off = align_up(off + std::max<size_t>(n, 1) * sizeof(float), 256);
+  off = align_up(off + n_cap * sizeof(float), 256);
   c->block_bytes = off;
   hipError_t e = hipSuccess;
   for (size_t k = 0; k < h->block_pool.size(); k++) {
@@ -1343,13 +1347,18 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
   if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
+  static const bool trace = std::getenv("HGS_UPLOAD_TRACE") != nullptr;  // host-side phase times of an upload on stderr (diagnostics)
+  const auto t0 = std::chrono::steady_clock::now();
   hgs_cloud* c = nullptr;
   HGS_TRY(cloud_alloc(h, n, &c));
+  const auto t1 = std::chrono::steady_clock::now();
+  auto t2 = t1;
   {
     StageTimer tm(h, HGS_STAGE_UPLOAD);
     const float4* staged = nullptr;
     {
       const int rc = upload_points_packed(h, pts, n, stride_bytes, &staged);
+      t2 = std::chrono::steady_clock::now();
       if (rc != HGS_OK) {
         cloud_free(c);
         return rc;
@@ -1369,6 +1378,11 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
       cloud_free(c);
       return HGS_ERR_HIP;
     }
+  }
+  if (trace) {
+    const auto t3 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    std::fprintf(stderr, "[hgs upload] n %zu: alloc %.1f us, pack + DMA enqueue %.1f us, launches %.1f us\n", n, us(t0, t1), us(t1, t2), us(t2, t3));
   }
   *out = c;
   return HGS_OK;
