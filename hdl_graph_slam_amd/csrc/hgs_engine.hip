@@ -150,6 +150,7 @@ struct PackPool {
     float* dst = nullptr;
     size_t n = 0, stride = 0, chunk = 0, nchunks = 0;
     bool has_intensity = false;
+    bool scatter = false;  // false: pack strided records at src into float4 at dst (upload); true: scatter float4 at src into strided records at dst (hgs_transform_source)
     std::atomic<size_t> next{0};
     std::atomic<unsigned char>* ready = nullptr;  // [nchunks]
   };
@@ -163,6 +164,17 @@ struct PackPool {
 
   static void pack_chunk(const Job& j, size_t c) {
     const size_t i0 = c * j.chunk, m = std::min(j.chunk, j.n - i0);
+    if (j.scatter) {  // x, y, z (and data[3] = 1 when the record has room for it) of the caller's records; everything else in them is left alone
+      const float* s4 = reinterpret_cast<const float*>(j.src) + 4 * i0;
+      char* o = reinterpret_cast<char*>(j.dst) + i0 * j.stride;
+      for (size_t i = 0; i < m; i++) {
+        float* f = reinterpret_cast<float*>(o + i * j.stride);
+        f[0] = s4[4 * i], f[1] = s4[4 * i + 1], f[2] = s4[4 * i + 2];
+        if (j.stride >= 16) f[3] = 1.0f;
+      }
+      j.ready[c].store(1, std::memory_order_release);
+      return;
+    }
     const char* s0 = j.src + i0 * j.stride;
     float* dst = j.dst + 4 * i0;
     if (j.has_intensity) {
@@ -1506,9 +1518,26 @@ int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t
   HGS_HIP(h, hipMemcpyAsync(dT, h->h_small.p, 64, hipMemcpyHostToDevice, h->stream));
   launch_transform(h->stream, h->source->desc.raw, (int)n, dT, h->misc.as<float4>());
   // Down through a pinned staging buffer the engine keeps (round 4 copied into a fresh pageable std::vector: 1.9 MB of page faults and a staged
-  // pageable D2H per align), in four pieces so that the host scatters piece k into the caller's strided records while piece k + 1 is on the wire.
+  // pageable D2H per align).  Small clouds: four pieces, the host scatters piece k into the caller's strided records while piece k + 1 is on the wire.
+  // Large clouds: one copy, then the scatter — a write-allocate pass over the caller's 3.8 MB — spread over the pack pool's threads.
   HGS_HIP(h, h->h_xform.reserve(n * sizeof(float4)));
   const float* host = h->h_xform.as<float>();
+  char* o = (char*)out_pts;
+  if (n >= kUploadParallelPoints) {
+    HGS_HIP(h, hipMemcpyAsync(h->h_xform.p, h->misc.p, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    HGS_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t nchunks = (n + kUploadChunkPoints - 1) / kUploadChunkPoints;
+    std::vector<std::atomic<unsigned char>> ready(nchunks);
+    for (auto& r : ready) r.store(0, std::memory_order_relaxed);
+    PackPool::Job job;
+    job.src = reinterpret_cast<const char*>(host), job.dst = reinterpret_cast<float*>(o), job.n = n, job.stride = stride_bytes, job.chunk = kUploadChunkPoints;
+    job.nchunks = nchunks, job.scatter = true, job.ready = ready.data();
+    h->pack_pool.post(&job);
+    while (PackPool::help(job)) {
+    }
+    h->pack_pool.retire();  // every chunk has been taken, and nobody is inside the job any more: all of them are done
+    return HGS_OK;
+  }
   constexpr int kPieces = 4;
   if (!h->xform_event[0])
     for (hipEvent_t& ev : h->xform_event) HGS_HIP(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1519,7 +1548,6 @@ int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t
       HGS_HIP(h, hipMemcpyAsync(h->h_xform.as<float4>() + bounds[k], h->misc.as<float4>() + bounds[k], (bounds[k + 1] - bounds[k]) * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     HGS_HIP(h, hipEventRecord(h->xform_event[k], h->stream));
   }
-  char* o = (char*)out_pts;
   for (int k = 0; k < kPieces; k++) {
     HGS_HIP(h, hipEventSynchronize(h->xform_event[k]));
     for (size_t i = bounds[k]; i < bounds[k + 1]; i++) {

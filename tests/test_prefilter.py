@@ -182,6 +182,14 @@ def test_large_upload_round_trip_through_the_pack_pool(n, layout):
         else:
             assert not got["intensity"].any()
         d.close()
+    if n > 0:
+        # ... and the way down: hgs_transform_source (align()'s output cloud) of the same size class — one copy + a scatter spread over the same
+        # helper threads for large clouds, four overlapped pieces for small ones — against the float arithmetic of the device's transform
+        reg.setInputSource(cloud)
+        T = synth.pose_matrix([0.5, -0.25, 0.125], [0.0, 0.0, 0.0])   # a pure translation by exactly representable amounts: no rounding to argue about
+        out = reg.transformed_source(T)
+        want = synth.xyz_of(cloud) + np.array([0.5, -0.25, 0.125], np.float32)
+        assert np.array_equal(out[:, :3], want, equal_nan=True) and (out[:, 3] == 1.0).all()
     reg.close()
 
 
