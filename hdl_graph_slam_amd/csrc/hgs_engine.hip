@@ -1767,8 +1767,9 @@ int comm_wait(hgs_handle* h, Q&& query, const char* what) {
   const long limit_ms = comm_timeout_ms();
   const auto t0 = std::chrono::steady_clock::now();
   auto next_check = t0 + std::chrono::milliseconds(1);
-  long sleep_us = 0;  // the exchange itself is microseconds: spin for ~100 us, then sleep with exponential backoff up to 1 ms (a rank waiting out peer skew
-                      // must not burn the core that feeds the other lanes and engines)
+  long sleep_us = 0;  // spin for ~200 us, then sleep with exponential backoff up to 50 us: a rank waiting out peer skew must not burn the core that feeds the
+                      // other lanes and engines, but this wait also sits behind the batch of EVERY sharded detection — a 1 ms cap (the first version of this
+                      // backoff) cost the world-1 bench 2 ms per 12 ms step (profiles/r05_bench_world1_rccl.json before / after)
   char err[256] = "";
   for (;;) {
     const hipError_t e = query();
@@ -1794,8 +1795,8 @@ int comm_wait(hgs_handle* h, Q&& query, const char* what) {
         return HGS_ERR_COMM;
       }
     }
-    if (now - t0 > std::chrono::microseconds(100)) {
-      sleep_us = sleep_us == 0 ? 10 : std::min(1000l, sleep_us * 2);
+    if (now - t0 > std::chrono::microseconds(200)) {
+      sleep_us = sleep_us == 0 ? 5 : std::min(50l, sleep_us * 2);
       std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
     }
   }
