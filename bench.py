@@ -186,10 +186,13 @@ def main():
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     # this process creates up to four engines one after the other: 8 hardware queues keep a later engine's lanes on queues of their own.  The LAUNCHER sets
     # it (here; a launch file in a deployment) — the library itself never touches the environment; it only counts its streams against this budget
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # A rank of a multi-GPU job also hosts torch's NCCL group and the library's own RCCL communicator, whose internal streams take hardware queues
+    # too: with 8 queues two of the engine's lanes then share one and the sharded batch runs 16 % slower (world 1 through the process-group path:
+    # 14.3 ms per step with 8 queues, 11.9-12.0 with 12 / 16 / 24; profiles/r05_world1_queues.log).  16 for those processes, 8 otherwise.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if (world > 1 or os.environ.get("HGS_BENCH_FORCE_DIST")) else "8")
     import torch
     # test hook (tests/test_bench_contract.py, never set by the driver): HGS_BENCH_EMULATED_LIB=<tests/emul/libhgs_simt.so> runs this
     # script against the host emulation of the kernels so that the JSON contract is checked without a GPU; the numbers it

@@ -265,7 +265,7 @@ void launch_meta_init(hipStream_t s, const CloudDesc* descs, int ncloud) {
   hipLaunchKernelGGL(k_meta_init, dim3((ncloud + 63) / 64), dim3(64), 0, s, descs, ncloud);
 }
 
-constexpr int kBboxPerThread = 4;
+constexpr int kBboxPerThread = 8;
 __global__ __launch_bounds__(kBlock) void k_bbox_count(const CloudDesc* descs) {
   const CloudDesc d = descs[blockIdx.y];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -295,11 +295,28 @@ __global__ __launch_bounds__(kBlock) void k_bbox_count(const CloudDesc* descs) {
       mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off, 64));
     }
   }
-  if ((threadIdx.x & 63) == 0 && cnt > 0) {
-    atomicAdd(&d.meta->nvalid, cnt);
-    for (int k = 0; k < 3; k++) {
-      atomicMin(&d.meta->bbmin[k], f2ord(mn[k]));
-      atomicMax(&d.meta->bbmax[k], f2ord(mx[k]));
+  // the four waves of the block meet in LDS and ONE thread sends the block's seven atomics: every block of every cloud's launch hits the same seven
+  // words, and it is their serialisation at the L2, not the loads, that this kernel's time is made of (wave-level atomics: 39 us for a 119 k-point
+  // sweep with 4 points per thread, 22 us with 8; per block and 8 points per thread: profiles/r05_upload.md)
+  __shared__ float s_mn[kBlock / 64][3], s_mx[kBlock / 64][3];
+  __shared__ int s_cnt[kBlock / 64];
+  const int wave = (int)(threadIdx.x >> 6);
+  if ((threadIdx.x & 63) == 0) {
+    s_cnt[wave] = cnt;
+    for (int k = 0; k < 3; k++) s_mn[wave][k] = mn[k], s_mx[wave][k] = mx[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; w++) {
+      cnt += s_cnt[w];
+      for (int k = 0; k < 3; k++) mn[k] = fminf(mn[k], s_mn[w][k]), mx[k] = fmaxf(mx[k], s_mx[w][k]);
+    }
+    if (cnt > 0) {
+      atomicAdd(&d.meta->nvalid, cnt);
+      for (int k = 0; k < 3; k++) {
+        atomicMin(&d.meta->bbmin[k], f2ord(mn[k]));
+        atomicMax(&d.meta->bbmax[k], f2ord(mx[k]));
+      }
     }
   }
 }
