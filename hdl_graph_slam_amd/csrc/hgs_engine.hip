@@ -339,7 +339,6 @@ struct hgs_handle {
   bool up_big_pending = false;
   PackPool pack_pool;
   PinnedBuffer h_xform;            // hgs_transform_source: the aligned cloud on its way down
-  hipEvent_t xform_event[4] = {};
 
   // freed cloud blocks kept for reuse: the odometry path creates and destroys one cloud per sweep, and hipMalloc /
   // hipFree (which synchronises the device) cost more than the upload itself
@@ -1341,8 +1340,6 @@ int hgs_destroy(hgs_handle* h) try {
   h->h_comm.release();
   h->h_flags.release();
   h->h_xform.release();
-  for (hipEvent_t ev : h->xform_event)
-    if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : h->prof_events) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   if (h->stream) (void)hipStreamDestroy(h->stream), g_streams_in_use.fetch_sub(1, std::memory_order_relaxed);
@@ -1518,42 +1515,26 @@ int hgs_transform_source(hgs_handle* h, const float T[16], void* out_pts, size_t
   HGS_HIP(h, hipMemcpyAsync(dT, h->h_small.p, 64, hipMemcpyHostToDevice, h->stream));
   launch_transform(h->stream, h->source->desc.raw, (int)n, dT, h->misc.as<float4>());
   // Down through a pinned staging buffer the engine keeps (round 4 copied into a fresh pageable std::vector: 1.9 MB of page faults and a staged
-  // pageable D2H per align).  Small clouds: four pieces, the host scatters piece k into the caller's strided records while piece k + 1 is on the wire.
-  // Large clouds: one copy, then the scatter — a write-allocate pass over the caller's 3.8 MB — spread over the pack pool's threads.
+  // pageable D2H per align): one copy, then the scatter into the caller's strided records — for a large cloud a write-allocate pass over 3.8 MB, spread
+  // over the pack pool's threads.  (Four overlapped pieces with an event each were tried first: at 13 k points their API calls cost more than they hid.)
   HGS_HIP(h, h->h_xform.reserve(n * sizeof(float4)));
   const float* host = h->h_xform.as<float>();
   char* o = (char*)out_pts;
+  HGS_HIP(h, hipMemcpyAsync(h->h_xform.p, h->misc.p, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipStreamSynchronize(h->stream));
+  const size_t nchunks = (n + kUploadChunkPoints - 1) / kUploadChunkPoints;
+  std::vector<std::atomic<unsigned char>> ready(nchunks);
+  for (auto& r : ready) r.store(0, std::memory_order_relaxed);
+  PackPool::Job job;
+  job.src = reinterpret_cast<const char*>(host), job.dst = reinterpret_cast<float*>(o), job.n = n, job.stride = stride_bytes, job.chunk = kUploadChunkPoints;
+  job.nchunks = nchunks, job.scatter = true, job.ready = ready.data();
   if (n >= kUploadParallelPoints) {
-    HGS_HIP(h, hipMemcpyAsync(h->h_xform.p, h->misc.p, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
-    HGS_HIP(h, hipStreamSynchronize(h->stream));
-    const size_t nchunks = (n + kUploadChunkPoints - 1) / kUploadChunkPoints;
-    std::vector<std::atomic<unsigned char>> ready(nchunks);
-    for (auto& r : ready) r.store(0, std::memory_order_relaxed);
-    PackPool::Job job;
-    job.src = reinterpret_cast<const char*>(host), job.dst = reinterpret_cast<float*>(o), job.n = n, job.stride = stride_bytes, job.chunk = kUploadChunkPoints;
-    job.nchunks = nchunks, job.scatter = true, job.ready = ready.data();
     h->pack_pool.post(&job);
     while (PackPool::help(job)) {
     }
     h->pack_pool.retire();  // every chunk has been taken, and nobody is inside the job any more: all of them are done
-    return HGS_OK;
-  }
-  constexpr int kPieces = 4;
-  if (!h->xform_event[0])
-    for (hipEvent_t& ev : h->xform_event) HGS_HIP(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  size_t bounds[kPieces + 1];
-  for (int k = 0; k <= kPieces; k++) bounds[k] = n * (size_t)k / kPieces;
-  for (int k = 0; k < kPieces; k++) {
-    if (bounds[k + 1] > bounds[k])
-      HGS_HIP(h, hipMemcpyAsync(h->h_xform.as<float4>() + bounds[k], h->misc.as<float4>() + bounds[k], (bounds[k + 1] - bounds[k]) * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
-    HGS_HIP(h, hipEventRecord(h->xform_event[k], h->stream));
-  }
-  for (int k = 0; k < kPieces; k++) {
-    HGS_HIP(h, hipEventSynchronize(h->xform_event[k]));
-    for (size_t i = bounds[k]; i < bounds[k + 1]; i++) {
-      float* f = reinterpret_cast<float*>(o + i * stride_bytes);
-      f[0] = host[4 * i], f[1] = host[4 * i + 1], f[2] = host[4 * i + 2];
-      if (stride_bytes >= 16) f[3] = 1.0f;
+  } else {
+    while (PackPool::help(job)) {  // a small cloud: this thread alone
     }
   }
   return HGS_OK;
