@@ -1749,8 +1749,8 @@ int comm_wait(hgs_handle* h, Q&& query, const char* what) {
   const auto t0 = std::chrono::steady_clock::now();
   auto next_check = t0 + std::chrono::milliseconds(1);
   long sleep_us = 0;  // spin for ~200 us, then sleep with exponential backoff up to 50 us: a rank waiting out peer skew must not burn the core that feeds the
-                      // other lanes and engines, but this wait also sits behind the batch of EVERY sharded detection — a 1 ms cap (the first version of this
-                      // backoff) cost the world-1 bench 2 ms per 12 ms step (profiles/r05_bench_world1_rccl.json before / after)
+                      // other lanes and engines, but this wait also sits behind the batch of EVERY sharded detection, where it overshoots by half its
+                      // last sleep on average — hence 50 us and not the millisecond a pure skew wait could afford
   char err[256] = "";
   for (;;) {
     const hipError_t e = query();
