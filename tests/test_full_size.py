@@ -5,6 +5,8 @@ The oracle still finishes these in seconds on the GPU box's host cores, so each 
 on top of that, through properties that do not depend on the oracle: brute-force nearest neighbours on a sample, invariance
 of the result under a permutation of the points, a fixed point of align (restarting from the answer stays there) and the
 union of two candidate shards being the unsharded batch."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,7 @@ import parity_checks as PC
 from hdl_graph_slam_amd import synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _hip(params):
@@ -257,3 +260,23 @@ def test_metric_candidate_set_every_record_and_the_selection_against_the_sequent
             best_score, best_o = score, i
     assert best == best_o, (best, best_o, rec["fitness_score"][best], best_score)
     reg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("queues,tolerance", [("16", 1.03), (None, 1.08)])
+def test_three_engines_in_one_process_keep_their_batch_rate(queues, tolerance):
+    """The library no longer sets GPU_MAX_HW_QUEUES itself (a plugin must not change its host process): it counts the streams it creates against the
+    process's queue budget and opens only as many lanes as there is room for.  Three engines alive in one process (FAST_GICP, NDT_OMP with its lanes,
+    FAST_GICP): with the launcher's 16 queues the third engine's 64 x 119 k batch runs as fast as the first one's did alone; with HIP's default of 4 it
+    degrades to fewer lanes (a few per cent) — not to two lanes on one queue (8 %, round 4)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    if queues:
+        env["GPU_MAX_HW_QUEUES"] = queues
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probes", "three_engines.py"), "64", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    f = out.stdout.strip().splitlines()[-1].split()
+    alone, third, again = float(f[1]), float(f[3]), float(f[5])
+    assert third <= tolerance * alone and again <= tolerance * alone, out.stdout
