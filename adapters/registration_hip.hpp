@@ -22,8 +22,9 @@
 //     a target that is replaced before it is ever aligned against, or an adapter whose batch path is served by LoopMatcherHIP,
 //     never uploads (nor even creates its engine).
 //   * the aligned cloud: pcl::Registration's contract is that align() fills `output` with T * input.  That is a D2H of the whole
-//     cloud (3.8 MB at 119 k points).  LoopDetector::matching discards it (loop_detector.hpp:134,143); setAlignedCloudOutput(false)
-//     skips the download (output then stays the copy of the input that align() made).  Default: on, the PCL contract.
+//     cloud (3.8 MB at 119 k points).  LoopDetector::matching discards it (loop_detector.hpp:134,143): setAlignedCloudMode(ALIGNED_CLOUD_NONE)
+//     skips it (output then stays the copy of the input that align() made); ALIGNED_CLOUD_HOST transforms that host copy in place instead of
+//     downloading (pcl::transformPointCloud's arithmetic, as the reference's engines do).  Default: the device's result comes down.
 //
 // Not compilable against the real PCL in this repository's image (no PCL / ROS); tests/test_adapter_cpp.py compiles it against
 // a stand-in of the pcl::Registration / pcl::search::KdTree interfaces (tests/mock_pcl) and runs it on the GPU through the real library.
@@ -141,8 +142,19 @@ public:
   // fast_gicp::FastGICP::setRegularizationMethod (hgs_regularization value); never called by hdl_graph_slam
   void setRegularizationMethod(int hgs_regularization_value) { params_.regularization_method = hgs_regularization_value; recreate(); }
 
-  // extension: false = align() does not download T * input into `output` (callers that discard it: LoopDetector::matching)
-  void setAlignedCloudOutput(bool on) { aligned_output_ = on; }
+  // extension: how align() fills `output` (PCL's contract: T * input).
+  //   ALIGNED_CLOUD_DEVICE (default)  the device transforms the resident source and the result comes down (hgs_transform_source)
+  //   ALIGNED_CLOUD_HOST              the adapter transforms align()'s host copy of the input in place, with the float arithmetic of
+  //                                   pcl::transformPointCloud — what fast_gicp / ndt_omp themselves do at the end of computeTransformation; no
+  //                                   device round trip (cheaper for the 10-40 k-point clouds the odometry nodelet handles: DESIGN.md 1.1)
+  //   ALIGNED_CLOUD_NONE              `output` stays the copy of the input that align() made (callers that discard it: LoopDetector::matching)
+  enum AlignedCloudMode { ALIGNED_CLOUD_DEVICE = 0, ALIGNED_CLOUD_HOST = 1, ALIGNED_CLOUD_NONE = 2 };
+  void setAlignedCloudMode(AlignedCloudMode m) { aligned_mode_ = m; }
+  // the rosparam form (reg_hip_aligned_cloud): "device" | "host" | "none"; anything else (and "true") = device, "false" = none
+  void setAlignedCloudMode(const std::string& m) {
+    aligned_mode_ = (m == "host") ? ALIGNED_CLOUD_HOST : ((m == "none" || m == "false") ? ALIGNED_CLOUD_NONE : ALIGNED_CLOUD_DEVICE);
+  }
+  void setAlignedCloudOutput(bool on) { aligned_mode_ = on ? ALIGNED_CLOUD_DEVICE : ALIGNED_CLOUD_NONE; }
   const hgs_params& params() const { return params_; }
   // true once somebody has queried PCL's CPU tree of the current target through the base pointer (tests, diagnostics)
   bool cpuTreeBuilt() const { return lazy_tree_->built(); }
@@ -191,7 +203,17 @@ protected:
     this->converged_ = last_.converged != 0;
     this->nr_iterations_ = last_.iterations;
     // align() copied *input_ into output; overwrite xyz with T * input (other fields are kept)
-    if (aligned_output_) check(hgs_transform_source(handle_, last_.final_transformation, output.points.data(), sizeof(PointSource)), "hgs_transform_source");
+    if (aligned_mode_ == ALIGNED_CLOUD_DEVICE) {
+      check(hgs_transform_source(handle_, last_.final_transformation, output.points.data(), sizeof(PointSource)), "hgs_transform_source");
+    } else if (aligned_mode_ == ALIGNED_CLOUD_HOST) {
+      const float* T = last_.final_transformation;  // column-major
+      for (auto& p : output.points) {
+        const float x = p.x, y = p.y, z = p.z;
+        p.x = T[0] * x + T[4] * y + T[8] * z + T[12];
+        p.y = T[1] * x + T[5] * y + T[9] * z + T[13];
+        p.z = T[2] * x + T[6] * y + T[10] * z + T[14];
+      }
+    }
   }
 
 private:
@@ -236,7 +258,7 @@ private:
   hgs_params params_{};
   hgs_handle* handle_ = nullptr;
   hgs_result last_{};
-  bool aligned_output_ = true;
+  AlignedCloudMode aligned_mode_ = ALIGNED_CLOUD_DEVICE;
   const void* uploaded_target_ = nullptr;  // the clouds the engine currently holds (identity only, never dereferenced)
   const void* uploaded_source_ = nullptr;
 #if PCL_VERSION_COMPARE(>=, 1, 10, 0)

@@ -892,6 +892,7 @@ def adapter_path_record(ctx, speed):
             abi, ad = r["c_abi"]["p50_ms"], r["adapter"]["p50_ms"]
             r["adapter_over_c_abi_p50"] = round(ad / abi, 4) if abi > 0 else None
             r["adapter_minus_pcl_align_over_c_abi_p50"] = round((ad - r["pcl_align_alone"]["p50_ms"]) / abi, 4) if abi > 0 else None
+            r["adapter_aligned_cloud_on_host_over_c_abi_p50"] = round(r["adapter_aligned_cloud_on_host"]["p50_ms"] / abi, 4) if abi > 0 else None
             rec[name] = r
             for f in files:
                 os.remove(f)

@@ -154,10 +154,11 @@ int main(int argc, char** argv) {
     hgs_destroy(h);
   }
   // ---- B-D: through the adapter, held by the base pointer like the nodelet holds it
-  auto adapter_run = [&](bool output, bool eager_tree) {
-    auto hip = std::make_shared<hgs_hip::RegistrationHIP<PointT, PointT>>(method, 0);
+  using Hip = hgs_hip::RegistrationHIP<PointT, PointT>;
+  auto adapter_run = [&](Hip::AlignedCloudMode mode, bool eager_tree) {
+    auto hip = std::make_shared<Hip>(method, 0);
     configure(*hip);
-    hip->setAlignedCloudOutput(output);
+    hip->setAlignedCloudMode(mode);
     pcl::Registration<PointT, PointT>::Ptr registration = hip;
     if (eager_tree) registration->setSearchMethodTarget(std::make_shared<pcl::search::KdTree<PointT>>());  // PCL's default tree: built by initCompute() on every new target
     return drive(scans, warmup, delta_trans, [&](const Cloud::Ptr& c) { registration->setInputTarget(c); },
@@ -169,7 +170,8 @@ int main(int argc, char** argv) {
                    return registration->hasConverged();
                  });
   };
-  const Trace t_adapter = adapter_run(true, false), t_noout = adapter_run(false, false), t_eager = adapter_run(true, true);
+  const Trace t_adapter = adapter_run(Hip::ALIGNED_CLOUD_DEVICE, false), t_host = adapter_run(Hip::ALIGNED_CLOUD_HOST, false), t_noout = adapter_run(Hip::ALIGNED_CLOUD_NONE, false),
+              t_eager = adapter_run(Hip::ALIGNED_CLOUD_DEVICE, true);
   // ---- E: pcl::Registration::align on its own
   Trace t_null;
   {
@@ -192,6 +194,7 @@ int main(int argc, char** argv) {
   std::printf("{\"points_per_sweep\": %zu, \"sweeps_in_stream\": %zu, ", mean_pts, scans.size() - 1);
   print_trace("c_abi", t_abi);
   print_trace("adapter", t_adapter);
+  print_trace("adapter_aligned_cloud_on_host", t_host);
   print_trace("adapter_without_aligned_cloud", t_noout);
   print_trace("adapter_with_eager_cpu_kdtree", t_eager);
   print_trace("pcl_align_alone", t_null);

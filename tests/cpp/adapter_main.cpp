@@ -2,6 +2,8 @@
 //   first frame:  setInputTarget(keyframe)                    apps/scan_matching_odometry_nodelet.cpp:166-174
 //   every frame:  setInputSource(filtered); align(*aligned, guess); hasConverged(); getFinalTransformation()   :176-221
 // Usage: adapter_main <method 0|2> <target.bin> <source.bin>   (raw PointXYZI records); prints the final transform.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -100,6 +102,16 @@ int main(int argc, char** argv) {
       // a new target (keyframe switch, :246): align again -> still no second build; the aligned cloud is optional
       auto keyframe2 = std::make_shared<pcl::PointCloud<PointT>>(*filtered);
       registration->setInputTarget(keyframe2);
+      // the host form of the aligned cloud (pcl::transformPointCloud's arithmetic on align()'s copy of the input) against the device's
+      hip->setAlignedCloudMode("host");
+      pcl::PointCloud<PointT> on_host, on_device;
+      registration->align(on_host, pcl::MockMatrix4f::Identity());
+      hip->setAlignedCloudMode("device");
+      registration->align(on_device, pcl::MockMatrix4f::Identity());
+      float worst = 0.f;
+      for (size_t i = 0; i < on_host.size(); i++)
+        worst = std::max(worst, std::max(std::fabs(on_host.points[i].x - on_device.points[i].x), std::max(std::fabs(on_host.points[i].y - on_device.points[i].y), std::fabs(on_host.points[i].z - on_device.points[i].z))));
+      std::printf("aligned_cloud host_vs_device n %zu max_abs_diff %.3g\n", on_host.size(), (double)worst);
       hip->setAlignedCloudOutput(false);
       pcl::PointCloud<PointT> untouched;
       registration->align(untouched, pcl::MockMatrix4f::Identity());

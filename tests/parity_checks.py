@@ -360,4 +360,6 @@ def check_adapter_lazy_tree_lines(out):
     g = out[8].split()
     assert g[0] == "nn_cpu" and g[3] == "nn_hip" and int(g[7]) == 1
     assert int(g[1]) == int(g[4]) and abs(float(g[2]) - float(g[5])) <= 1e-6 * max(1e-6, float(g[2]))
-    assert out[9] == "new_target converged 1 builds 1 output_is_input_copy 1", out[9]
+    f = out[9].split()   # the aligned cloud computed on the host (pcl::transformPointCloud's unfused float arithmetic) vs the device's fma chain: float rounding apart
+    assert f[0] == "aligned_cloud" and int(f[3]) > 0 and float(f[5]) < 2e-5, out[9]
+    assert out[10] == "new_target converged 1 builds 1 output_is_input_copy 1", out[10]

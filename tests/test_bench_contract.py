@@ -112,6 +112,7 @@ def test_other_baseline_configs_emit_the_same_contract(config, extra):
             assert r["max_abs_pose_diff_adapter_vs_c_abi"] == 0 and r["adapter"]["sweeps"] == 3 and r["adapter"]["converged"] == r["c_abi"]["converged"]
             assert r["adapter"]["cpu_kdtree_builds"] == 0 and r["adapter_with_eager_cpu_kdtree"]["cpu_kdtree_builds"] >= 1
             assert r["adapter_over_c_abi_p50"] > 0 and r["pcl_align_alone"]["p50_ms"] >= 0
+            assert r["adapter_aligned_cloud_on_host"]["sweeps"] == 3 and r["adapter_aligned_cloud_on_host_over_c_abi_p50"] > 0
         # the stream as launch/hdl_graph_slam_kitti.launch runs it: device prefilter in front of NDT_OMP and of the launch file's FAST_GICP
         for name, method in (("kitti_prefilter_ndt_omp", "NDT_OMP"), ("kitti_launch_fast_gicp", "FAST_GICP")):
             k = rec[name]
