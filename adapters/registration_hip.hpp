@@ -148,11 +148,12 @@ public:
   //                                   pcl::transformPointCloud — what fast_gicp / ndt_omp themselves do at the end of computeTransformation; no
   //                                   device round trip (cheaper for the 10-40 k-point clouds the odometry nodelet handles: DESIGN.md 1.1)
   //   ALIGNED_CLOUD_NONE              `output` stays the copy of the input that align() made (callers that discard it: LoopDetector::matching)
-  enum AlignedCloudMode { ALIGNED_CLOUD_DEVICE = 0, ALIGNED_CLOUD_HOST = 1, ALIGNED_CLOUD_NONE = 2 };
+  //   ALIGNED_CLOUD_AUTO              HOST below 49152 points, DEVICE from there on (where the download, spread over the library's pack threads, wins)
+  enum AlignedCloudMode { ALIGNED_CLOUD_DEVICE = 0, ALIGNED_CLOUD_HOST = 1, ALIGNED_CLOUD_NONE = 2, ALIGNED_CLOUD_AUTO = 3 };
   void setAlignedCloudMode(AlignedCloudMode m) { aligned_mode_ = m; }
-  // the rosparam form (reg_hip_aligned_cloud): "device" | "host" | "none"; anything else (and "true") = device, "false" = none
+  // the rosparam form (reg_hip_aligned_cloud): "device" | "host" | "auto" | "none"; anything else (and "true") = device, "false" = none
   void setAlignedCloudMode(const std::string& m) {
-    aligned_mode_ = (m == "host") ? ALIGNED_CLOUD_HOST : ((m == "none" || m == "false") ? ALIGNED_CLOUD_NONE : ALIGNED_CLOUD_DEVICE);
+    aligned_mode_ = (m == "host") ? ALIGNED_CLOUD_HOST : (m == "auto") ? ALIGNED_CLOUD_AUTO : ((m == "none" || m == "false") ? ALIGNED_CLOUD_NONE : ALIGNED_CLOUD_DEVICE);
   }
   void setAlignedCloudOutput(bool on) { aligned_mode_ = on ? ALIGNED_CLOUD_DEVICE : ALIGNED_CLOUD_NONE; }
   const hgs_params& params() const { return params_; }
@@ -203,9 +204,10 @@ protected:
     this->converged_ = last_.converged != 0;
     this->nr_iterations_ = last_.iterations;
     // align() copied *input_ into output; overwrite xyz with T * input (other fields are kept)
-    if (aligned_mode_ == ALIGNED_CLOUD_DEVICE) {
+    const AlignedCloudMode mode = aligned_mode_ != ALIGNED_CLOUD_AUTO ? aligned_mode_ : (output.points.size() < 49152 ? ALIGNED_CLOUD_HOST : ALIGNED_CLOUD_DEVICE);
+    if (mode == ALIGNED_CLOUD_DEVICE) {
       check(hgs_transform_source(handle_, last_.final_transformation, output.points.data(), sizeof(PointSource)), "hgs_transform_source");
-    } else if (aligned_mode_ == ALIGNED_CLOUD_HOST) {
+    } else if (mode == ALIGNED_CLOUD_HOST) {
       const float* T = last_.final_transformation;  // column-major
       for (auto& p : output.points) {
         const float x = p.x, y = p.y, z = p.z;
