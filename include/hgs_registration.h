@@ -123,10 +123,15 @@ const char* hgs_last_error(const hgs_handle* h); /* h may be NULL: error of the 
 int hgs_abi_version(void);
 
 /* ---- clouds resident on the device -------------------------------------------------------------------- */
-/* Upload + pack a host cloud (H2D on the handle's stream).  The cloud caches its search structure and
+/* Upload a host cloud: records of `stride_bytes` with x, y, z at floats 0..2 and, from 20 bytes on, the intensity at float 4
+ * (pcl::PointXYZI: 32).  `pts` may be pageable memory and may be freed or overwritten as soon as the call returns: the host packs the
+ * records into pinned chunks while it reads them and the DMA + device-side packing run behind it on the handle's stream (no
+ * synchronisation; an error of those shows up at the next call that waits).  The cloud caches its search structure and
  * covariances once an engine has computed them, like fast_gicp keeps them per input pointer.  A cloud belongs to the
  * handle that created it (its memory is recycled in that handle's stream order): using it with another handle is
- * rejected with HGS_ERR_INVALID_ARGUMENT. */
+ * rejected with HGS_ERR_INVALID_ARGUMENT.  The library does not change the process environment; the number of hardware
+ * queues the HIP runtime spreads streams over (GPU_MAX_HW_QUEUES, read once at HIP's initialisation) is the launcher's to set:
+ * INTEGRATION.md. */
 int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, hgs_cloud** out);
 int hgs_cloud_destroy(hgs_cloud* c);
 size_t hgs_cloud_size(const hgs_cloud* c);
