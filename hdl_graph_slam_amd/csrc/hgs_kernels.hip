@@ -1795,12 +1795,20 @@ void launch_pf_compact(hipStream_t s, const float4* in, int n, const unsigned* k
 __global__ __launch_bounds__(kBlock) void k_pf_bbox(const float4* __restrict__ pts, const int* __restrict__ count, unsigned* __restrict__ meta) {
   const int n = *count;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float4 p = pts[i];
-    if (finite3(p)) {
-      mn[0] = fminf(mn[0], p.x), mn[1] = fminf(mn[1], p.y), mn[2] = fminf(mn[2], p.z);
-      mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
+  // as in k_bbox_count: a thread's points loaded together, ONE set of atomics per block (their serialisation on the six words was this kernel's time)
+  for (int i0 = blockIdx.x * kBlock * kBboxPerThread + threadIdx.x; i0 < n; i0 += gridDim.x * kBlock * kBboxPerThread) {
+    float4 p[kBboxPerThread];
+#pragma unroll
+    for (int k = 0; k < kBboxPerThread; k++) {
+      const int i = i0 + k * kBlock;
+      p[k] = i < n ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
     }
+#pragma unroll
+    for (int k = 0; k < kBboxPerThread; k++)
+      if (finite3(p[k])) {
+        mn[0] = fminf(mn[0], p[k].x), mn[1] = fminf(mn[1], p[k].y), mn[2] = fminf(mn[2], p[k].z);
+        mx[0] = fmaxf(mx[0], p[k].x), mx[1] = fmaxf(mx[1], p[k].y), mx[2] = fmaxf(mx[2], p[k].z);
+      }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
@@ -1809,11 +1817,20 @@ __global__ __launch_bounds__(kBlock) void k_pf_bbox(const float4* __restrict__ p
       mn[k] = fminf(mn[k], __shfl_down(mn[k], off, 64));
       mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off, 64));
     }
-  if ((threadIdx.x & 63) == 0 && mn[0] <= mx[0])
-    for (int k = 0; k < 3; k++) {
-      atomicMin(&meta[k], f2ord(mn[k]));
-      atomicMax(&meta[3 + k], f2ord(mx[k]));
-    }
+  __shared__ float s_mn[kBlock / 64][3], s_mx[kBlock / 64][3];
+  const int wave = (int)(threadIdx.x >> 6);
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; k++) s_mn[wave][k] = mn[k], s_mx[wave][k] = mx[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; w++)
+      for (int k = 0; k < 3; k++) mn[k] = fminf(mn[k], s_mn[w][k]), mx[k] = fmaxf(mx[k], s_mx[w][k]);
+    if (mn[0] <= mx[0])
+      for (int k = 0; k < 3; k++) {
+        atomicMin(&meta[k], f2ord(mn[k]));
+        atomicMax(&meta[3 + k], f2ord(mx[k]));
+      }
+  }
 }
 // meta: [0..2] bbmin, [3..5] bbmax (ordered uints) -> [6..8] min_b, [9..11] div_mul, [12] error (index overflow)
 __global__ void k_pf_grid(unsigned* meta, float inv_leaf) {
@@ -1875,7 +1892,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_voxel_centroids(const float4* __r
   out[slot[i]] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
 }
 void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta) {
-  int gx = (cap + kBlock * 8 - 1) / (kBlock * 8);
+  int gx = (cap + kBlock * kBboxPerThread - 1) / (kBlock * kBboxPerThread);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(k_pf_bbox, dim3(gx), dim3(kBlock), 0, s, pts, count, meta);
 }
