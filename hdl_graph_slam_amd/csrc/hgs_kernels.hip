@@ -1883,29 +1883,10 @@ __global__ __launch_bounds__(kBlock) void k_pf_voxel_centroids(const float4* __r
   const unsigned long long key = keys[i];
   float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
   int n = 0;
-  // The voxel's points in sequence order (pcl::VoxelGrid's CentroidPoint adds them one by one: the float sums must follow that order), but fetched
-  // kBatch at a time: keys, indices and points of a batch are independent loads issued together, then the valid prefix is added in order.  One point
-  // per trip (round 4) made every point three dependent round trips; a voxel next to the sensor holds hundreds of points (68 us on average, 250 us worst
-  // for a 119 k-point sweep; now profiles/r05_upload.md).
-  constexpr int kBatch = 8;
-  for (int j0 = i;; j0 += kBatch) {
-    unsigned long long kk[kBatch];
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) kk[b] = j0 + b < cap ? keys[j0 + b] : ~key;
-    int m = 0;
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) m += (m == b && kk[b] == key) ? 1 : 0;  // length of the same-voxel prefix
-    unsigned vv[kBatch];
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) vv[b] = b < m ? vals[j0 + b] : 0u;
-    float4 pp[kBatch];
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) pp[b] = b < m ? pts[vv[b]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int b = 0; b < kBatch; b++)
-      if (b < m) sx += pp[b].x, sy += pp[b].y, sz += pp[b].z, si += pp[b].w;
-    n += m;
-    if (m < kBatch) break;
+  for (int j = i; j < cap && keys[j] == key; j++) {
+    const float4 p = pts[vals[j]];
+    sx += p.x, sy += p.y, sz += p.z, si += p.w;
+    n++;
   }
   const float fn = (float)n;
   out[slot[i]] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
