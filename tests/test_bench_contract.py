@@ -86,8 +86,10 @@ def test_two_ranks_through_torch_distributed_run():
     port = s.getsockname()[1]
     s.close()
     rec = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *SMALL, "--method", "NDT_OMP", "--ndt-line-search"])
+                os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *SMALL, "--method", "NDT_OMP", "--ndt-line-search", "--strong-candidates", "4"])
     _check(rec, 2, 2, 1, 2)
+    st = rec["config4_strong_scaling"]     # BASELINE config 4 next to the weak line (512 candidates in total on the device; 4 here)
+    assert st["scaling"] == "strong" and st["candidates_total"] == 4 and st["candidates_per_gpu"] == 2 and len(st["per_rank_ms_per_step"]) == 2
     assert "More-Thuente" in rec["config"]["workload"] and rec["mean_linearizations"] >= rec["mean_iterations"] + 1
     assert rec["cpu_baseline"] is None and "x2" in rec["config"]["parallelism"]
 
