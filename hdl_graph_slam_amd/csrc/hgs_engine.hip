@@ -140,9 +140,10 @@ struct PinnedRing {
   }
 };
 
-// A few helper threads that pack point records next to the calling thread (upload_points_packed).  One core reads a cold 3.8 MB sweep from DRAM at
-// ~8-10 GB/s — 0.45 ms, whether it is this code or the HIP runtime's pageable path doing it — so a large upload is split over kWorkers + 1 threads.
-// The workers only touch host memory (no HIP call); they sleep on a condition variable between uploads and are joined by hgs_destroy.
+// A few helper threads that pack point records next to the calling thread (upload_points_packed).  One core packs a cold 119 k-point sweep (3.8 MB
+// read, 1.9 MB written) in 150 us; kWorkers + 1 threads in 59 us (same box, scripts/probes/upload_probe.py: hgs_set_source 0.164 -> 0.075 ms of a
+// 0.39 ms odometry step).  The workers only touch host memory (no HIP call); they sleep on a condition variable between uploads and are joined by
+// hgs_destroy.
 struct PackPool {
   static constexpr int kWorkers = 3;
   struct Job {
@@ -408,11 +409,13 @@ int set_device(hgs_handle* h) {
 // Host -> device of n strided point records (pcl::PointXYZI: 32 bytes; anything with x, y, z at floats 0..2 and, from 20 bytes on, the intensity
 // at float 4) as packed 16-byte records {x, y, z, intensity} in h->staging.  The HOST packs chunk after chunk into pinned buffers (half the bytes
 // of a PointXYZI go over PCIe, none of them through the runtime's pageable staging path) and every chunk's DMA runs while the next chunk is packed.
-// Round 4 handed the caller's pageable buffer to hipMemcpyAsync: 0.48 ms for one 119 k-point sweep (7.9 GB/s: the runtime copies into its own staging
-// buffers first and does not overlap that with the DMA) — two thirds of a raw-sweep odometry step (profiles/r05_upload.md).
+// Round 4 handed the caller's pageable buffer to hipMemcpyAsync and synchronised behind the kernels that followed (profiles/r05_upload.md).
 // The caller's buffer has been read completely when this returns; the device side is ordered on h->stream.
 constexpr size_t kUploadChunkPoints = 16384;     // 256 KB per pinned chunk
-constexpr size_t kUploadParallelPoints = 49152;  // from three chunks on the pack pool helps (below: one thread, the ring of pinned chunks)
+#ifndef HGS_UPLOAD_PARALLEL_POINTS
+#define HGS_UPLOAD_PARALLEL_POINTS 49152  // (A/B knob: a huge value keeps every upload on the calling thread)
+#endif
+constexpr size_t kUploadParallelPoints = HGS_UPLOAD_PARALLEL_POINTS;  // from three chunks on the pack pool helps (below: one thread, the ring of pinned chunks)
 int upload_points_packed(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, const float4** dev) {
   HGS_HIP(h, h->staging.reserve(std::max<size_t>(n, 1) * sizeof(float4)));
   *dev = h->staging.as<float4>();
