@@ -209,7 +209,9 @@ __device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int n
     // four independent partial sums keep four loads in flight per thread (one dependent chain was latency bound)
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int tile = row;
-#pragma unroll HGS_REDUCE_UNROLL
+#if HGS_REDUCE_UNROLL == 2  // (a macro as the pragma's operand does not survive a separate preprocessing step: hipcc --save-temps)
+#pragma unroll 2
+#endif
     for (; tile + 3 * ROWS < ntiles; tile += 4 * ROWS) {
       const double a = p[(size_t)tile * N + col], b = p[(size_t)(tile + ROWS) * N + col];
       const double c = p[(size_t)(tile + 2 * ROWS) * N + col], d = p[(size_t)(tile + 3 * ROWS) * N + col];
