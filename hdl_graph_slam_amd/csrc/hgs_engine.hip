@@ -1601,9 +1601,13 @@ int hgs_nn_target(hgs_handle* h, const float* q_xyz, size_t nq, size_t stride_by
   HGS_TRY(upload_points_packed(h, q_xyz, nq, stride_bytes, &staged));
   launch_pack_aos(h->stream, staged, (int)nq, dq, nullptr, nullptr);
   launch_nn_query(h->stream, target_view(h->target), dq, (int)nq, didx, dd2);
-  HGS_HIP(h, hipMemcpyAsync(idx, didx, nq * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HGS_HIP(h, hipMemcpyAsync(d2, dd2, nq * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  // the two result arrays come down in ONE copy into pinned memory (they are adjacent on the device: didx[nq] | dd2[nq]) and are handed to the
+  // caller's (pageable) arrays from there
+  HGS_HIP(h, h->h_xform.reserve(nq * 8));
+  HGS_HIP(h, hipMemcpyAsync(h->h_xform.p, didx, nq * 8, hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
+  std::memcpy(idx, h->h_xform.p, nq * sizeof(int));
+  std::memcpy(d2, static_cast<const char*>(h->h_xform.p) + nq * sizeof(int), nq * sizeof(float));
   return HGS_OK;
 } catch (...) {
   return status_of_current_exception(h);
@@ -2198,9 +2202,11 @@ extern "C" int hgs_cloud_download(hgs_cloud* c, void* out_pts, size_t stride_byt
   HGS_TRY(set_device(h));
   const size_t n = c->n_input;
   if (n == 0) return HGS_OK;
-  std::vector<float> xyzw(n * 4), inten(n);
-  HGS_HIP(h, hipMemcpyAsync(xyzw.data(), c->desc.raw, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
-  HGS_HIP(h, hipMemcpyAsync(inten.data(), c->intensity, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, h->h_xform.reserve(n * (sizeof(float4) + sizeof(float))));  // pinned (round 4: two fresh pageable vectors per call)
+  const float* xyzw = h->h_xform.as<float>();
+  const float* inten = xyzw + 4 * n;
+  HGS_HIP(h, hipMemcpyAsync(h->h_xform.p, c->desc.raw, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+  HGS_HIP(h, hipMemcpyAsync(h->h_xform.as<float>() + 4 * n, c->intensity, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
   char* o = (char*)out_pts;
   for (size_t i = 0; i < n; i++) {
