@@ -20,5 +20,5 @@ def brief(x):
     return {k: x.get(k) for k in ("value", "ms_per_step", "mean_iterations", "converged", "best_candidate")} | {"cpu": {k: c.get(k) for k in ("value", "cores", "variants", "value_over_all_candidates_by_variant", "gpu_over_cpu", "candidates_checked", "oracle_argmin_agrees", "max_pose_diff_vs_gpu_m", "iterations_equal")} if c else None, "roof": {k: x["roofline"].get(k) for k in ("bound", "kernel", "achieved", "frac", "avg_launch_us", "hbm_frac_from_counters", "profiled_step_ms", "stage_ms_per_step")}}
 print("FAST_GICP", brief(r)); print("PLANE", brief(r["fast_gicp_plane"])); print("NDT", brief(r["ndt_omp"])); print("r02 set", r["r02_candidate_set"])
 PY
-[ -z "${SKIP_PROFILE:-}" ] && bash scripts/r05_profile.sh
-[ -z "${SKIP_CONFIGS:-}" ] && bash scripts/r05_configs.sh
+if [ -z "${SKIP_PROFILE:-}" ]; then bash scripts/r05_profile.sh; fi
+if [ -z "${SKIP_CONFIGS:-}" ]; then bash scripts/r05_configs.sh; fi
