@@ -4,7 +4,11 @@
 #include <memory>
 #include <vector>
 #define PCL_VERSION_CALC(a, b, c) ((a) * 100000 + (b) * 100 + (c))
+#ifdef HGS_MOCK_PCL_1_12   // the other side of the adapter's PCL_VERSION_COMPARE branches: search::KdTree::setInputCloud returns bool from 1.12 on
+#define PCL_VERSION PCL_VERSION_CALC(1, 12, 1)
+#else
 #define PCL_VERSION PCL_VERSION_CALC(1, 10, 0)
+#endif
 #define PCL_VERSION_COMPARE(OP, MAJ, MIN, PATCH) (PCL_VERSION OP PCL_VERSION_CALC(MAJ, MIN, PATCH))
 namespace pcl {
 template <typename T>

@@ -21,7 +21,15 @@ public:
   using Ptr = std::shared_ptr<KdTree<PointT>>;
   using ConstPtr = std::shared_ptr<const KdTree<PointT>>;
   virtual ~KdTree() = default;
-  virtual void setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) {
+#ifdef HGS_MOCK_PCL_1_12
+  virtual bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) {
+    build_index(cloud, indices);
+    return true;
+  }
+#else
+  virtual void setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) { build_index(cloud, indices); }
+#endif
+  void build_index(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices) {
     input_ = cloud;
     indices_ = indices;
     order_.resize(cloud ? cloud->size() : 0);

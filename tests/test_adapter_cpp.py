@@ -31,6 +31,14 @@ def test_adapter_compiles_and_links():
     assert os.path.exists(_build())
 
 
+def test_adapter_compiles_against_the_pcl_1_12_signatures():
+    """pcl::search::KdTree::setInputCloud returns bool from PCL 1.12 on (void before): the adapter's LazyKdTree overrides it under
+    PCL_VERSION_COMPARE — the stand-in switches signature and version with -DHGS_MOCK_PCL_1_12 so that the other branch is compiled too."""
+    src = os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror=overloaded-virtual", "-fsyntax-only", "-DHGS_MOCK_PCL_1_12", "-I", os.path.join(ROOT, "tests", "mock_pcl"),
+                    "-I", os.path.join(ROOT, "tests", "mock_eigen"), "-I", os.path.join(ROOT, "include"), src], check=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", [0, 2])
 def test_adapter_matches_python_mirror(tmp_path, method):
