@@ -1136,6 +1136,13 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       }
       HGS_HIP(h, hipMemcpyAsync(h->ndt_plan.p, host, per_lane * lanes.size(), hipMemcpyHostToDevice, h->stream));  // (round 4: a synchronous hipMemcpy of a pageable vector)
       HGS_HIP(h, h->up.commit(plan_slot, h->stream));
+      // open_lanes() released lanes 1.. behind an event recorded BEFORE this copy: order them behind the plan as well, or a lane's first
+      // k_ndt_init / k_ndt_pass could read the previous batch's tile_base / queue heads (round-5 advisor finding; tests/test_hip_parity.py
+      // ::test_ndt_batches_of_different_shape_back_to_back poisons the plan between batches)
+      if (lanes.size() > 1) {
+        HGS_HIP(h, hipEventRecord(h->lane_event[0], h->stream));
+        for (size_t i = 1; i < lanes.size(); i++) HGS_HIP(h, hipStreamWaitEvent(lanes[i].stream, h->lane_event[0], 0));
+      }
     }
     for (BatchLane& L : lanes) launch_ndt_init(L.stream, st + L.b0, ang + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, c, L.B, L.prog, accum + L.b0);
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {

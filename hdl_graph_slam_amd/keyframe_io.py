@@ -38,8 +38,10 @@ def _fmt(v: float) -> str:
     return f"{v:.6g}"   # Eigen's operator<< default: 6 significant digits (keyframe.cpp:30,33)
 
 
-def _matrix_text(M: np.ndarray) -> str:
-    cells = [[_fmt(float(x)) for x in row] for row in np.asarray(M, np.float64).reshape(4, 4)]
+def _matrix_text(M: np.ndarray, shape=(4, 4)) -> str:
+    """Eigen's operator<< (default IOFormat): every coefficient right-aligned to the width of the widest one, " " between columns, "\\n"
+    between rows.  Pinned against the reference's own KeyFrame::save run here (tests/test_reference_code_pins.py)."""
+    cells = [[_fmt(float(x)) for x in row] for row in np.asarray(M, np.float64).reshape(shape)]
     width = max(len(c) for row in cells for c in row)
     return "\n".join(" ".join(c.rjust(width) for c in row) for row in cells)
 
@@ -108,8 +110,13 @@ def save_keyframe(directory: str, kf: KeyFrameRecord) -> None:
              f"accum_distance {_fmt(kf.accum_distance)}"]
     for name in ("floor_coeffs", "utm_coord", "acceleration", "orientation"):
         v = getattr(kf, name)
-        if v is not None:
-            lines.append(name + " " + " ".join(_fmt(float(x)) for x in np.asarray(v).ravel()))
+        if v is None:
+            continue
+        v = np.asarray(v, np.float64).ravel()
+        if name == "orientation":       # four scalars streamed one by one (keyframe.cpp:49)
+            lines.append(name + " " + " ".join(_fmt(float(x)) for x in v))
+        else:                           # `->transpose()` of an Eigen vector: a 1 x N matrix, column-aligned like the 4x4s (keyframe.cpp:37-46)
+            lines.append(name + " " + _matrix_text(v, (1, len(v))))
     if kf.node_id >= 0:
         lines.append(f"id {kf.node_id}")
     with open(os.path.join(directory, "data"), "w") as fh:
