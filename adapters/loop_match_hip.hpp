@@ -9,6 +9,12 @@
 // Only the C-ABI of include/hgs_registration.h and the standard library are used (no PCL types): the caller passes point
 // arrays with a stride, e.g. cloud->points.data(), cloud->size(), sizeof(pcl::PointXYZI).
 //
+// Memory: a resident keyframe costs hgs_cloud_device_bytes() — about 100 bytes per point (12 MB for a 119 k-point HDL-64E sweep, 6 MB for a 60 k
+// HDL-32E one: points, Hilbert-sorted copy, leaf copy, box tree, covariances, correspondence seeds).  hdl_graph_slam never removes a keyframe from its
+// graph, so the resident set is BOUNDED here: setCapacity(bytes per engine, keyframes per engine) — default 16 GiB / unlimited count of the 288 GB —
+// and after every match() the least recently matched keyframes beyond the budget are released (a keyframe that becomes a candidate again is simply
+// uploaded again: the host copy is the graph's KeyFrame::cloud).  The candidates of the running batch are never evicted under it.
+//
 //   hgs_hip::LoopMatcherHIP matcher(params, {0, 1, 2, 3});
 //   std::vector<hgs_hip::LoopMatcherHIP::Candidate> cands;          // {keyframe id, points, n, stride, guess[16]}
 //   ...
@@ -17,6 +23,7 @@
 // Exercised end to end by tests/cpp/loop_match_main.cpp (tests/test_simt_kernels_host.py) on the host emulation of the kernels.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -51,7 +58,7 @@ public:
         release();
         throw std::runtime_error("LoopMatcherHIP: hgs_create failed: " + msg);
       }
-      engines_.push_back(Engine{h, {}});
+      engines_.push_back(Engine{h, {}, 0, 0});
     }
   }
   ~LoopMatcherHIP() { release(); }
@@ -64,13 +71,30 @@ public:
     for (const Engine& e : engines_) n += e.clouds.size();
     return n;
   }
+  // device bytes held by the resident keyframes of all engines (hgs_cloud_device_bytes, refreshed after every match)
+  size_t resident_bytes() const {
+    size_t n = 0;
+    for (const Engine& e : engines_) n += e.bytes;
+    return n;
+  }
+  size_t evictions() const {
+    size_t n = 0;
+    for (const Engine& e : engines_) n += e.evictions;
+    return n;
+  }
+  // Budget PER ENGINE (= per GPU); 0 = unlimited.  Takes effect at the end of the next match().
+  void setCapacity(size_t max_bytes_per_engine, size_t max_keyframes_per_engine = 0) { max_bytes_ = max_bytes_per_engine, max_keyframes_ = max_keyframes_per_engine; }
   // a keyframe was removed from the graph / its cloud changed
   void forget(long keyframe_id) {
     Engine& e = owner(keyframe_id);
     auto it = e.clouds.find(keyframe_id);
     if (it == e.clouds.end()) return;
-    hgs_cloud_destroy(it->second);
-    e.clouds.erase(it);
+    drop(e, it);
+  }
+  // every resident keyframe (e.g. the graph was replaced by load_service: apps/hdl_graph_slam_nodelet.cpp:932-974 reuses node ids)
+  void forget_all() {
+    for (Engine& e : engines_)
+      while (!e.clouds.empty()) drop(e, e.clouds.begin());
   }
 
   // Registers every candidate against the new keyframe; records[i] is filled for candidates[i].  Returns the index the
@@ -81,6 +105,7 @@ public:
   int match(const void* target_points, size_t target_n, size_t target_stride, const std::vector<Candidate>& candidates, double max_range,
             std::vector<hgs_result>* records) {
     const size_t N = engines_.size();
+    const uint64_t tick = ++tick_;
     std::vector<std::vector<size_t>> mine(N);
     for (size_t i = 0; i < candidates.size(); i++) mine[owner_index(candidates[i].keyframe_id)].push_back(i);
     records->assign(candidates.size(), hgs_result{});
@@ -103,9 +128,10 @@ public:
           if (it == eng.clouds.end()) {
             hgs_cloud* cl = nullptr;
             check(eng, hgs_cloud_create(eng.h, c.points, c.n, c.stride_bytes, &cl));
-            it = eng.clouds.emplace(c.keyframe_id, cl).first;
+            it = eng.clouds.emplace(c.keyframe_id, Resident{cl, 0, 0}).first;
           }
-          clouds.push_back(it->second);
+          it->second.last_used = tick;
+          clouds.push_back(it->second.cloud);
           guesses.insert(guesses.end(), c.guess, c.guess + 16);
         }
         std::vector<hgs_result> out(clouds.size());
@@ -118,6 +144,11 @@ public:
       } catch (const std::exception& ex) {
         errors[e] = ex.what();
       }
+      try {
+        enforce_capacity(engines_[e], tick);  // (also after a failure: a failed hgs_cloud_create is most likely an exhausted device)
+      } catch (const std::exception& ex) {
+        if (errors[e].empty()) errors[e] = ex.what();
+      }
     };
     if (N == 1) {
       work(0);
@@ -126,22 +157,66 @@ public:
       for (size_t e = 0; e < N; e++) threads.emplace_back(work, e);
       for (std::thread& t : threads) t.join();
     }
-    for (size_t e = 0; e < N; e++)
-      if (!errors[e].empty()) last_error_ += "engine " + std::to_string(e) + ": " + errors[e] + "; ";
+    failed_engines_ = 0, used_engines_ = 0;
+    for (size_t e = 0; e < N; e++) {
+      if (!mine[e].empty()) used_engines_++;
+      if (!errors[e].empty()) last_error_ += "engine " + std::to_string(e) + ": " + errors[e] + "; ", failed_engines_++;
+    }
     int32_t best = -1;
     if (!candidates.empty() && hgs_select_best(records->data(), records->size(), &best) != HGS_OK) last_error_ += "hgs_select_best failed; ", best = -1;
     return best;
   }
   // empty after a clean match(); otherwise which engine failed and why (its candidates were left not converged)
   const std::string& last_error() const { return last_error_; }
+  // engines of the last match() that had candidates / that failed: a caller that must not lose candidates silently (LoopDetector::matching)
+  // falls back to its sequential loop when failed_engines() > 0
+  size_t used_engines() const { return used_engines_; }
+  size_t failed_engines() const { return failed_engines_; }
 
 private:
+  struct Resident {
+    hgs_cloud* cloud;
+    uint64_t last_used;   // match() counter of the last batch this keyframe took part in
+    size_t bytes;         // hgs_cloud_device_bytes at the end of that batch (index / covariances are built inside it)
+  };
   struct Engine {
     hgs_handle* h;
-    std::unordered_map<long, hgs_cloud*> clouds;
+    std::unordered_map<long, Resident> clouds;
+    size_t bytes = 0;
+    size_t evictions = 0;  // (per engine: the engines of a match() run on their own threads)
   };
   std::vector<Engine> engines_;
   std::string last_error_;
+  size_t max_bytes_ = (size_t)16 << 30, max_keyframes_ = 0, used_engines_ = 0, failed_engines_ = 0;
+  uint64_t tick_ = 0;
+
+  void drop(Engine& e, std::unordered_map<long, Resident>::iterator it) {
+    e.bytes -= std::min(e.bytes, it->second.bytes);
+    hgs_cloud_destroy(it->second.cloud);
+    e.clouds.erase(it);
+  }
+  // Called by the engine's own worker thread at the end of a batch: refresh the sizes of the keyframes the batch touched, then release the least
+  // recently matched ones until the engine is within its budget.  Keyframes of the current batch (last_used == tick) go last and only if the
+  // batch alone exceeds the budget.
+  void enforce_capacity(Engine& e, uint64_t tick) {
+    for (auto& kv : e.clouds) {
+      if (kv.second.last_used != tick) continue;
+      const size_t b = hgs_cloud_device_bytes(kv.second.cloud);
+      e.bytes = e.bytes - std::min(e.bytes, kv.second.bytes) + b;
+      kv.second.bytes = b;
+    }
+    auto over = [&]() { return (max_bytes_ && e.bytes > max_bytes_) || (max_keyframes_ && e.clouds.size() > max_keyframes_); };
+    if (!over()) return;
+    std::vector<std::pair<uint64_t, long>> order;
+    order.reserve(e.clouds.size());
+    for (const auto& kv : e.clouds) order.emplace_back(kv.second.last_used, kv.first);
+    std::sort(order.begin(), order.end());
+    for (const auto& o : order) {
+      if (!over()) break;
+      drop(e, e.clouds.find(o.second));
+      e.evictions++;
+    }
+  }
 
   size_t owner_index(long keyframe_id) const { return (size_t)((keyframe_id % (long)engines_.size() + (long)engines_.size()) % (long)engines_.size()); }
   Engine& owner(long keyframe_id) { return engines_[owner_index(keyframe_id)]; }
@@ -150,8 +225,9 @@ private:
   }
   void release() {
     for (Engine& e : engines_) {
-      for (auto& kv : e.clouds) hgs_cloud_destroy(kv.second);
+      for (auto& kv : e.clouds) hgs_cloud_destroy(kv.second.cloud);
       e.clouds.clear();
+      e.bytes = 0;
       hgs_destroy(e.h);
     }
     engines_.clear();

@@ -24,7 +24,7 @@
 //   * the aligned cloud: pcl::Registration's contract is that align() fills `output` with T * input.  That is a D2H of the whole
 //     cloud (3.8 MB at 119 k points).  LoopDetector::matching discards it (loop_detector.hpp:134,143): setAlignedCloudMode(ALIGNED_CLOUD_NONE)
 //     skips it (output then stays the copy of the input that align() made); ALIGNED_CLOUD_HOST transforms that host copy in place instead of
-//     downloading (pcl::transformPointCloud's arithmetic, as the reference's engines do).  Default: the device's result comes down.
+//     downloading (pcl::transformPointCloud's arithmetic, as the reference's engines do).  Default: ALIGNED_CLOUD_AUTO (host below 49152 points).
 //
 // Not compilable against the real PCL in this repository's image (no PCL / ROS); tests/test_adapter_cpp.py compiles it against
 // a stand-in of the pcl::Registration / pcl::search::KdTree interfaces (tests/mock_pcl) and runs it on the GPU through the real library.
@@ -143,17 +143,17 @@ public:
   void setRegularizationMethod(int hgs_regularization_value) { params_.regularization_method = hgs_regularization_value; recreate(); }
 
   // extension: how align() fills `output` (PCL's contract: T * input).
-  //   ALIGNED_CLOUD_DEVICE (default)  the device transforms the resident source and the result comes down (hgs_transform_source)
+  //   ALIGNED_CLOUD_DEVICE            the device transforms the resident source and the result comes down (hgs_transform_source)
   //   ALIGNED_CLOUD_HOST              the adapter transforms align()'s host copy of the input in place, with the float arithmetic of
   //                                   pcl::transformPointCloud — what fast_gicp / ndt_omp themselves do at the end of computeTransformation; no
   //                                   device round trip (cheaper for the 10-40 k-point clouds the odometry nodelet handles: DESIGN.md 1.1)
   //   ALIGNED_CLOUD_NONE              `output` stays the copy of the input that align() made (callers that discard it: LoopDetector::matching)
-  //   ALIGNED_CLOUD_AUTO              HOST below 49152 points, DEVICE from there on (where the download, spread over the library's pack threads, wins)
+  //   ALIGNED_CLOUD_AUTO (default)    HOST below 49152 points, DEVICE from there on (where the download, spread over the library's pack threads, wins)
   enum AlignedCloudMode { ALIGNED_CLOUD_DEVICE = 0, ALIGNED_CLOUD_HOST = 1, ALIGNED_CLOUD_NONE = 2, ALIGNED_CLOUD_AUTO = 3 };
   void setAlignedCloudMode(AlignedCloudMode m) { aligned_mode_ = m; }
-  // the rosparam form (reg_hip_aligned_cloud): "device" | "host" | "auto" | "none"; anything else (and "true") = device, "false" = none
+  // the rosparam form (reg_hip_aligned_cloud): "auto" | "device" | "host" | "none"; "true" = device, "false" = none, anything else = auto
   void setAlignedCloudMode(const std::string& m) {
-    aligned_mode_ = (m == "host") ? ALIGNED_CLOUD_HOST : (m == "auto") ? ALIGNED_CLOUD_AUTO : ((m == "none" || m == "false") ? ALIGNED_CLOUD_NONE : ALIGNED_CLOUD_DEVICE);
+    aligned_mode_ = (m == "host") ? ALIGNED_CLOUD_HOST : (m == "device" || m == "true") ? ALIGNED_CLOUD_DEVICE : ((m == "none" || m == "false") ? ALIGNED_CLOUD_NONE : ALIGNED_CLOUD_AUTO);
   }
   void setAlignedCloudOutput(bool on) { aligned_mode_ = on ? ALIGNED_CLOUD_DEVICE : ALIGNED_CLOUD_NONE; }
   const hgs_params& params() const { return params_; }
@@ -176,14 +176,18 @@ public:
   // getFitnessScore(max_range): apps/scan_matching_odometry_nodelet.cpp:307, include/hdl_graph_slam/loop_detector.hpp:146
   double fitnessScoreHIP(double max_range = std::numeric_limits<double>::max()) {
     double score = std::numeric_limits<double>::max();
-    check(hgs_fitness(handle(), this->final_transformation_.data(), max_range, &score, nullptr), "hgs_fitness");
+    hgs_handle* h = handle();
+    if (h && !uploadsCurrent()) return score;  // (logged by handle(): the engine holds older clouds than pcl::Registration does)
+    check(hgs_fitness(h, this->final_transformation_.data(), max_range, &score, nullptr), "hgs_fitness");
     return score;
   }
   // getSearchMethodTarget()->nearestKSearch(pt, 1, ...) over a whole cloud: apps/scan_matching_odometry_nodelet.cpp:314-321
   void nearestTargetHIP(const pcl::PointCloud<PointSource>& queries, std::vector<int>& indices, std::vector<float>& sq_dists) {
-    indices.resize(queries.size());
-    sq_dists.resize(queries.size());
-    check(hgs_nn_target(handle(), reinterpret_cast<const float*>(queries.points.data()), queries.size(), sizeof(PointSource), indices.data(),
+    indices.assign(queries.size(), -1);
+    sq_dists.assign(queries.size(), std::numeric_limits<float>::max());
+    hgs_handle* h = handle();
+    if (h && !uploadsCurrent()) return;  // no neighbour found: index -1 (the patched status path counts no inlier)
+    check(hgs_nn_target(h, reinterpret_cast<const float*>(queries.points.data()), queries.size(), sizeof(PointSource), indices.data(),
                         sq_dists.data()),
           "hgs_nn_target");
   }
@@ -193,9 +197,11 @@ public:
 protected:
   void computeTransformation(PointCloudSource& output, const Matrix4& guess) override {
     this->converged_ = false;
-    const int rc = hgs_align(handle(), guess.data(), &last_);
+    hgs_handle* h = handle();
+    // a cloud that could not be uploaded must not be replaced silently by the one the engine still holds from the previous sweep / keyframe
+    const int rc = (h && !uploadsCurrent()) ? (int)HGS_ERR_HIP : hgs_align(h, guess.data(), &last_);
     if (rc != HGS_OK) {  // failure is signalled the way the callers expect: hasConverged() == false, pose unchanged
-      PCL_ERROR("[%s] %s\n", this->reg_name_.c_str(), hgs_last_error(handle_));
+      PCL_ERROR("[%s] %s\n", this->reg_name_.c_str(), (h && !uploadsCurrent()) ? "the current clouds are not on the device (upload failed)" : hgs_last_error(handle_));
       this->final_transformation_ = guess;
       return;
     }
@@ -246,6 +252,10 @@ private:
     }
     return handle_;
   }
+  // true when the engine holds exactly the clouds pcl::Registration holds (handle() uploads what differs; a failed upload leaves them different)
+  bool uploadsCurrent() const {
+    return (!this->target_ || this->target_.get() == uploaded_target_) && (!this->input_ || this->input_.get() == uploaded_source_);
+  }
   void recreate() {  // parameters are fixed at creation: drop the engine; the next handle() creates one and uploads the current clouds
     if (!handle_) return;
     hgs_destroy(handle_);
@@ -260,7 +270,7 @@ private:
   hgs_params params_{};
   hgs_handle* handle_ = nullptr;
   hgs_result last_{};
-  AlignedCloudMode aligned_mode_ = ALIGNED_CLOUD_DEVICE;
+  AlignedCloudMode aligned_mode_ = ALIGNED_CLOUD_AUTO;
   const void* uploaded_target_ = nullptr;  // the clouds the engine currently holds (identity only, never dereferenced)
   const void* uploaded_source_ = nullptr;
 #if PCL_VERSION_COMPARE(>=, 1, 10, 0)

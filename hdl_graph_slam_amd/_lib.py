@@ -71,7 +71,7 @@ assert RESULT_DTYPE.itemsize == C.sizeof(HgsResult)
 # every symbol include/hgs_registration.h declares
 EXPORTS = [
     "hgs_params_default", "hgs_create", "hgs_destroy", "hgs_last_error", "hgs_abi_version",
-    "hgs_cloud_create", "hgs_cloud_destroy", "hgs_cloud_size", "hgs_cloud_invalidate",
+    "hgs_cloud_create", "hgs_cloud_destroy", "hgs_cloud_size", "hgs_cloud_device_bytes", "hgs_cloud_invalidate",
     "hgs_set_target", "hgs_set_target_cloud", "hgs_set_source", "hgs_set_source_cloud",
     "hgs_align", "hgs_transform_source", "hgs_fitness", "hgs_nn_target",
     "hgs_loop_match_batch", "hgs_select_best", "hgs_calc_fitness_score",
@@ -102,6 +102,8 @@ def lib():
     L.hgs_cloud_destroy.argtypes = [vp]
     L.hgs_cloud_size.argtypes = [vp]
     L.hgs_cloud_size.restype = sz
+    L.hgs_cloud_device_bytes.argtypes = [vp]
+    L.hgs_cloud_device_bytes.restype = sz
     L.hgs_cloud_invalidate.argtypes = [vp]
     L.hgs_set_target.argtypes = [vp, vp, sz, sz]
     L.hgs_set_source.argtypes = [vp, vp, sz, sz]

@@ -269,6 +269,7 @@ struct hgs_cloud {
   double ndt_resolution = 0;
   int ndt_min_points = 0;
   void* ndt_block = nullptr;
+  size_t ndt_block_bytes = 0;
   int* ndt_hash_keys = nullptr;
   int* ndt_hash_vals = nullptr;
   NdtCellRec* ndt_cells = nullptr;
@@ -279,6 +280,7 @@ struct hgs_cloud {
   double vg_resolution = 0;
   int vg_cov_k = 0;
   void* vg_block = nullptr;
+  size_t vg_block_bytes = 0;
   int* vg_hash_keys = nullptr;
   int* vg_hash_vals = nullptr;
   NdtCellRec* vg_cells = nullptr;
@@ -686,6 +688,7 @@ int ensure_ndt_target(hgs_handle* h, hgs_cloud* c) {
     const size_t o_cells = o_kv + align_up((size_t)cap * 8, 256);
     const size_t bytes = o_cells + (size_t)max_cells * sizeof(NdtCellRec);
     HGS_HIP(h, hipMalloc(&c->ndt_block, bytes));
+    c->ndt_block_bytes = bytes;
     c->ndt_hash_keys = (int*)((char*)c->ndt_block + o_keys);
     c->ndt_hash_vals = (int*)((char*)c->ndt_block + o_vals);
     c->ndt_hash_kv = (int2*)((char*)c->ndt_block + o_kv);
@@ -742,6 +745,7 @@ int ensure_vgicp_target(hgs_handle* h, hgs_cloud* c) {
     const size_t o_keys = 0, o_vals = align_up((size_t)cap * 4, 256), o_cells = o_vals + align_up((size_t)cap * 4, 256);
     const size_t bytes = o_cells + (size_t)max_cells * sizeof(NdtCellRec);
     HGS_HIP(h, hipMalloc(&c->vg_block, bytes));
+    c->vg_block_bytes = bytes;
     c->vg_hash_keys = (int*)((char*)c->vg_block + o_keys);
     c->vg_hash_vals = (int*)((char*)c->vg_block + o_vals);
     c->vg_cells = (NdtCellRec*)((char*)c->vg_block + o_cells);
@@ -846,7 +850,10 @@ NdtConsts ndt_consts(const hgs_params& p) {
 // environment (rounds 1-4 called setenv from a static initialiser: a plugin must not change its host process).  Instead every stream an engine
 // creates is counted against the process's queue budget — GPU_MAX_HW_QUEUES if the launcher set it (INTEGRATION.md recommends 8), HIP's default 4
 // otherwise — and a batch opens only as many lanes as the budget still has room for (never fewer than one: the engine's own stream).
-std::atomic<int> g_streams_in_use{0};
+// (the budget is per DEVICE: in the one-process-several-GPUs shape — LoopMatcherHIP, bench.py --single-process — every GPU has its own queues)
+constexpr int kMaxCountedDevices = 64;
+std::atomic<int> g_streams_in_use[kMaxCountedDevices] = {};
+std::atomic<int>& streams_in_use(int device) { return g_streams_in_use[(unsigned)device % kMaxCountedDevices]; }
 int hw_queue_budget() {
   static const int budget = [] {
     const char* e = std::getenv("GPU_MAX_HW_QUEUES");
@@ -893,7 +900,7 @@ int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t pa
   if (h->batch_lanes <= 0) {
     int owned = 0;
     while (owned < kMaxLanes - 1 && h->lane_stream[owned]) owned++;
-    const int room = std::max(0, hw_queue_budget() - g_streams_in_use.load(std::memory_order_relaxed));
+    const int room = std::max(0, hw_queue_budget() - streams_in_use(h->device).load(std::memory_order_relaxed));
     n = std::min(n, 1 + owned + room);
   }
   lanes.assign(n, BatchLane{});
@@ -909,7 +916,7 @@ int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t pa
     }
     if (!h->lane_stream[i - 1]) {
       HGS_HIP(h, hipStreamCreateWithFlags(&h->lane_stream[i - 1], hipStreamNonBlocking));
-      g_streams_in_use.fetch_add(1, std::memory_order_relaxed);
+      streams_in_use(h->device).fetch_add(1, std::memory_order_relaxed);
     }
     L.stream = h->lane_stream[i - 1];
     HGS_HIP(h, h->lane_partials[i - 1].reserve((size_t)L.B * partial_bytes_per_problem));
@@ -1300,7 +1307,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
     delete h;
     return HGS_ERR_HIP;
   }
-  g_streams_in_use.fetch_add(1, std::memory_order_relaxed);
+  streams_in_use(h->device).fetch_add(1, std::memory_order_relaxed);
   *out = h;
   return HGS_OK;
 } catch (...) {
@@ -1337,7 +1344,7 @@ int hgs_destroy(hgs_handle* h) try {
     if (ev) (void)hipEventDestroy(ev);
   if (h->comm_event) (void)hipEventDestroy(h->comm_event);
   for (hipStream_t ls : h->lane_stream)
-    if (ls) (void)hipStreamDestroy(ls), g_streams_in_use.fetch_sub(1, std::memory_order_relaxed);
+    if (ls) (void)hipStreamDestroy(ls), streams_in_use(h->device).fetch_sub(1, std::memory_order_relaxed);
   for (auto& blk : h->block_pool) (void)hipFree(blk.first);
   h->block_pool.clear();
   h->up.release();
@@ -1352,7 +1359,7 @@ int hgs_destroy(hgs_handle* h) try {
   h->h_xform.release();
   for (auto& ev : h->prof_events) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
-  if (h->stream) (void)hipStreamDestroy(h->stream), g_streams_in_use.fetch_sub(1, std::memory_order_relaxed);
+  if (h->stream) (void)hipStreamDestroy(h->stream), streams_in_use(h->device).fetch_sub(1, std::memory_order_relaxed);
   delete h;
   return HGS_OK;
 } catch (...) {
@@ -1428,6 +1435,11 @@ int hgs_cloud_destroy(hgs_cloud* c) try {
 }
 
 size_t hgs_cloud_size(const hgs_cloud* c) { return c ? c->n_input : 0; }
+
+size_t hgs_cloud_device_bytes(const hgs_cloud* c) {
+  if (!c || !c->owner) return 0;
+  return (c->block ? c->block_bytes : 0) + (c->ndt_block ? c->ndt_block_bytes : 0) + (c->vg_block ? c->vg_block_bytes : 0);
+}
 
 int hgs_cloud_invalidate(hgs_cloud* c) try {
   std::unique_lock<std::recursive_mutex> api_lock__;

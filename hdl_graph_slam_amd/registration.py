@@ -43,6 +43,11 @@ class DeviceCloud:
         self._reg._check(L.lib().hgs_cloud_download(self._h, out.ctypes.data_as(C.c_void_p), out.dtype.itemsize))
         return out
 
+    @property
+    def device_bytes(self) -> int:
+        """hgs_cloud_device_bytes: what this keyframe costs while it stays resident (points, index, covariances, voxel tables)."""
+        return int(L.lib().hgs_cloud_device_bytes(self._h))
+
     def invalidate(self):
         L.lib().hgs_cloud_invalidate(self._h)
 

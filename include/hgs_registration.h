@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 4
+#define HGS_ABI_VERSION 5
 
 enum hgs_status {
   HGS_OK = 0,
@@ -135,6 +135,10 @@ int hgs_abi_version(void);
 int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_bytes, hgs_cloud** out);
 int hgs_cloud_destroy(hgs_cloud* c);
 size_t hgs_cloud_size(const hgs_cloud* c);
+/* Device memory the cloud currently holds, in bytes: points, search index, covariances, correspondence seeds and — once it has served as an NDT /
+ * VGICP target — its voxel tables.  What a cache of resident keyframes (adapters/loop_match_hip.hpp; the reference keeps every KeyFrame::cloud for the
+ * life of the graph, include/hdl_graph_slam/keyframe.hpp:44) budgets against.  0 for NULL or an orphaned cloud. */
+size_t hgs_cloud_device_bytes(const hgs_cloud* c);
 /* Drop cached search structure / covariances (forces the cold path again; used by benchmarks). */
 int hgs_cloud_invalidate(hgs_cloud* c);
 

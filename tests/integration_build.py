@@ -16,8 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFERENCE = "/root/reference"
 PATCH = os.path.join(ROOT, "integration", "hdl_graph_slam_hip.patch")
 OUT = os.path.join(ROOT, "integration", "_build")
-PATCHED = ["CMakeLists.txt", "src/hdl_graph_slam/registrations.cpp", "include/hdl_graph_slam/loop_detector.hpp", "apps/scan_matching_odometry_nodelet.cpp"]
-UNTOUCHED = ["include/hdl_graph_slam/registrations.hpp", "include/hdl_graph_slam/keyframe.hpp", "include/hdl_graph_slam/graph_slam.hpp"]
+PATCHED = ["CMakeLists.txt", "src/hdl_graph_slam/registrations.cpp", "include/hdl_graph_slam/loop_detector.hpp", "apps/scan_matching_odometry_nodelet.cpp",
+           "src/hdl_graph_slam/information_matrix_calculator.cpp", "src/hdl_graph_slam/map_cloud_generator.cpp", "apps/prefiltering_nodelet.cpp"]
+UNTOUCHED = ["include/hdl_graph_slam/registrations.hpp", "include/hdl_graph_slam/keyframe.hpp", "include/hdl_graph_slam/graph_slam.hpp",
+             "include/hdl_graph_slam/information_matrix_calculator.hpp", "include/hdl_graph_slam/map_cloud_generator.hpp"]
+# patched translation units that are compiled and linked into integration_main (the two apps/*.cpp nodelets need all of ROS: their hunks are
+# apply-checked, and everything the hunks call — adapters/registration_hip.hpp, adapters/resident_clouds_hip.hpp — is compiled and run here)
+COMPILED = ["src/hdl_graph_slam/registrations.cpp", "src/hdl_graph_slam/information_matrix_calculator.cpp", "src/hdl_graph_slam/map_cloud_generator.cpp"]
 
 
 def have_reference() -> bool:
@@ -30,7 +35,8 @@ def exe(kind: str) -> str:
 
 def _deps(lib):
     d = [PATCH, lib, os.path.join(ROOT, "tests", "cpp", "integration_main.cpp"), os.path.join(ROOT, "adapters", "registration_hip.hpp"),
-         os.path.join(ROOT, "adapters", "loop_match_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"), os.path.abspath(__file__)]
+         os.path.join(ROOT, "adapters", "loop_match_hip.hpp"), os.path.join(ROOT, "adapters", "resident_clouds_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"),
+         os.path.join(ROOT, "oracle", "mapcloud.hpp"), os.path.abspath(__file__)]
     for mock in ("mock_ros", "mock_pcl", "mock_eigen"):
         for base, _, files in os.walk(os.path.join(ROOT, "tests", mock)):
             d += [os.path.join(base, f) for f in files]
@@ -68,14 +74,23 @@ def build(kind: str = "hip") -> str | None:
         for d in (os.path.join(ROOT, "tests", "mock_ros"), os.path.join(ROOT, "tests", "mock_pcl"), os.path.join(ROOT, "tests", "mock_eigen"),
                   os.path.join(tmp, "include"), os.path.join(ROOT, "include"), os.path.join(ROOT, "adapters")):
             inc += ["-I", d]
-        flags = ["g++", "-std=c++17", "-O1", "-Wall", "-DUSE_HGS_HIP", *inc]
-        subprocess.run([*flags, "-c", os.path.join(tmp, "src", "hdl_graph_slam", "registrations.cpp"), "-o", os.path.join(tmp, "registrations.o")], check=True)
-        subprocess.run([*flags, "-c", os.path.join(ROOT, "tests", "cpp", "integration_main.cpp"), "-o", os.path.join(tmp, "main.o")], check=True)
-        # the factory must also still build WITHOUT the backend (the patch is all #ifdef USE_HGS_HIP)
-        subprocess.run([f for f in flags if f != "-DUSE_HGS_HIP"] + ["-fsyntax-only", os.path.join(tmp, "src", "hdl_graph_slam", "registrations.cpp")], check=True)
+        flags = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unknown-pragmas", "-DUSE_HGS_HIP", *inc]
+        objs = []
+        for i, unit in enumerate(COMPILED):
+            objs.append(os.path.join(tmp, f"unit{i}.o"))
+            subprocess.run([*flags, "-c", os.path.join(tmp, unit), "-o", objs[-1]], check=True)
+            # every patched unit must also still build WITHOUT the backend (the patch is all #ifdef USE_HGS_HIP)
+            subprocess.run([f for f in flags if f != "-DUSE_HGS_HIP"] + ["-fsyntax-only", os.path.join(tmp, unit)], check=True)
+        # ... and the UNPATCHED units, under other symbol names, so that the tests can run the reference's CPU code next to the device path
+        for i, (unit, rename) in enumerate((("src/hdl_graph_slam/information_matrix_calculator.cpp", "InformationMatrixCalculator=InformationMatrixCalculatorCPU"),
+                                            ("src/hdl_graph_slam/map_cloud_generator.cpp", "MapCloudGenerator=MapCloudGeneratorCPU"))):
+            objs.append(os.path.join(tmp, f"cpu{i}.o"))
+            subprocess.run([f for f in flags if f != "-DUSE_HGS_HIP"] + ["-ffp-contract=off", f"-D{rename}", "-c", os.path.join(REFERENCE, unit), "-o", objs[-1]], check=True)
+        objs.append(os.path.join(tmp, "main.o"))
+        subprocess.run([*flags, "-c", os.path.join(ROOT, "tests", "cpp", "integration_main.cpp"), "-o", objs[-1]], check=True)
         libdir = os.path.dirname(lib)
         rpath = "$ORIGIN/" + os.path.relpath(libdir, OUT)
         link = ["-l:libhgs_simt.so"] if kind == "simt" else ["-lhgs_hip"]
-        subprocess.run(["g++", os.path.join(tmp, "registrations.o"), os.path.join(tmp, "main.o"), "-o", out + ".tmp", "-L", libdir, *link, "-pthread", f"-Wl,-rpath,{rpath}"], check=True)
+        subprocess.run(["g++", *objs, "-o", out + ".tmp", "-L", libdir, *link, "-pthread", f"-Wl,-rpath,{rpath}"], check=True)
         os.replace(out + ".tmp", out)
     return out

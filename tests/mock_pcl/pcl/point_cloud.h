@@ -2,6 +2,7 @@
 #pragma once
 #include <cstddef>
 #include <memory>
+#include <string>
 #include <vector>
 #define PCL_VERSION_CALC(a, b, c) ((a) * 100000 + (b) * 100 + (c))
 #ifdef HGS_MOCK_PCL_1_12   // the other side of the adapter's PCL_VERSION_COMPARE branches: search::KdTree::setInputCloud returns bool from 1.12 on
@@ -19,6 +20,17 @@ struct PointCloud {
   using Ptr = std::shared_ptr<PointCloud<PointT>>;
   using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
   std::vector<PointT> points;
+  struct Header {
+    unsigned seq = 0;
+    unsigned long long stamp = 0;
+    std::string frame_id;
+  } header;
+  unsigned width = 0, height = 0;
+  bool is_dense = true;
+  void reserve(size_t n) { points.reserve(n); }
+  void push_back(const PointT& p) { points.push_back(p); }
+  typename std::vector<PointT>::const_iterator begin() const { return points.begin(); }
+  typename std::vector<PointT>::const_iterator end() const { return points.end(); }
   size_t size() const { return points.size(); }
   bool empty() const { return points.empty(); }
   void resize(size_t n) { points.resize(n); }

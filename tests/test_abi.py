@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(L):
         assert hasattr(lib, name), name
     # 2: hgs_params grew ndt_line_search; 3: hgs_comm_* / hgs_loop_match_batch_sharded, new status codes; 4: the sharded call always reaches its
     # collectives and reports a rank's own error after the exchange, duplicate candidate ids are flagged, hgs_debug_merge_shard_records
-    assert lib.hgs_abi_version() == 4
+    assert lib.hgs_abi_version() == 5
 
 
 def test_struct_layouts_match_the_header(L):

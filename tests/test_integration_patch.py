@@ -187,3 +187,135 @@ def test_patched_factory_and_loop_detector_on_the_gpu(tmp_path):
         out = subprocess.run([exe, "loop", "FAST_GICP_HIP", devices, str(tmp_path / "t.bin"), str(tmp_path / "g.bin"), *files], check=True, capture_output=True, text=True).stdout.splitlines()
         # (LoopDetector rebuilds the guess from the pose-graph estimates through a quaternion: it differs from the mirror's in the last bits)
         _check_loop(out, int(best), T_best, 2e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------------ round 6: more hunks
+def _next_row_inputs(tmp_path):
+    """Committed clouds (tests/golden): the VLP-16 pair of the reference-code pins, three keyframes with poses, one raw sweep."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_refpin_golden as MG
+    from hdl_graph_slam_amd import synth
+    c, z, n = MG.small_clouds()
+    for k in ("pair_target", "pair_source", "kf0", "kf1", "kf2"):
+        c[k].tofile(tmp_path / (k + ".bin"))
+    np.stack([p.T.reshape(-1) for p in n["poses"]]).astype(np.float32).tofile(tmp_path / "poses.bin")
+    synth.to_xyzi(n["raw_xyzi"][:, :3], n["raw_xyzi"][:, 3]).tofile(tmp_path / "raw.bin")
+    return z, n, np.load(os.path.join(ROOT, "tests", "golden", "refpin_v1.npz"))
+
+
+def _run(exe, *args):
+    return subprocess.run([exe, *[str(a) for a in args]], check=True, capture_output=True, text=True).stdout.splitlines()
+
+
+def _check_next_rows(exe, tmp_path):
+    """f1 / f3 / f2 through the patched reference functions, next to the UNPATCHED translation units linked into the same binary."""
+    from hdl_graph_slam_amd import synth
+    z, n, gold = _next_row_inputs(tmp_path)
+    # f1: InformationMatrixCalculator::calc_fitness_score / calc_information_matrix (information_matrix_calculator.cpp:25-80)
+    for case in (0, 1, 3, 4, 15):     # ground truth at DBL_MAX / 4.0 / 0.25 / no inlier, the perturbed pose
+        T, r = gold["fit_pose"][case], float(gold["fit_max_range"][case])
+        out = _run(exe, "infomat", tmp_path / "pair_target.bin", tmp_path / "pair_source.bin", *[repr(float(v)) for v in T.reshape(-1)], "max" if r > 1e300 else repr(r))
+        assert not [ln for ln in out if ln.startswith("error")], out
+        dev = [ln.split() for ln in out if ln.startswith("fitness_device")]
+        cpu = [ln.split() for ln in out if ln.startswith("fitness_cpu")][0]
+        assert [int(d[3]) for d in dev] == [1, 2] and int(dev[1][5]) == 2 and int(dev[1][7]) > 0      # both calls on the device, two resident clouds with a size
+        assert float(cpu[1]) == float(gold["fit_score"][case])                                         # the unpatched unit IS the code that made the vectors
+        assert int(cpu[3]) >= 1                                                                        # ... and it built PCL's CPU tree; the device path never did before it
+        for d in dev:
+            s = float(d[1])
+            assert s == float(cpu[1]) if float(cpu[1]) > 1e300 else abs(s / float(cpu[1]) - 1) < 2e-6
+        inf_dev = np.array([float(v) for v in [ln for ln in out if ln.startswith("infomat_device")][0].split()[1:]])
+        inf_cpu = np.array([float(v) for v in [ln for ln in out if ln.startswith("infomat_cpu")][0].split()[1:]])
+        assert np.allclose(inf_dev, inf_cpu, rtol=1e-5, atol=0)
+    # f3: MapCloudGenerator::generate (map_cloud_generator.cpp:13-51)
+    out = _run(exe, "mapcloud", 0.4, tmp_path / "poses.bin", tmp_path / "dev.bin", tmp_path / "cpu.bin", tmp_path / "kf0.bin", tmp_path / "kf1.bin", tmp_path / "kf2.bin")
+    head = out[0].split()
+    assert head[0] == "mapcloud" and head[2] == head[4] and int(head[6]) == 1 and int(head[8]) == 3, out      # one device call, three resident keyframes
+    dev, cpu = np.fromfile(tmp_path / "dev.bin", synth.POINT_XYZI_DTYPE), np.fromfile(tmp_path / "cpu.bin", synth.POINT_XYZI_DTYPE)
+    assert len(dev) == len(n["map_cloud"]) and dev.tobytes() == cpu.tobytes()                                 # voxel centres, order, intensity 0, data[3] = 1
+    assert np.array_equal(np.stack([dev["x"], dev["y"], dev["z"]], 1), n["map_cloud"][:, :3])
+    # f2: the prefilter hunk's parameter mapping + device call (apps/prefiltering_nodelet.cpp:50-99, 131-133)
+    out = _run(exe, "prefilter", tmp_path / "raw.bin", tmp_path / "pf.bin", "APPROX_VOXELGRID", 0.3, "NONE")
+    assert out[0].split()[2] == "1", out
+    pf = np.fromfile(tmp_path / "pf.bin", synth.POINT_XYZI_DTYPE)
+    assert np.array_equal(np.stack([pf["x"], pf["y"], pf["z"], pf["intensity"]], 1), n["approx_voxelgrid_0.3"])
+
+
+def _check_regularization_param(exe, tmp_path, align_with):
+    """reg_regularization_method reaches both GICP branches of the patched factory (registrations.cpp:27-56) and changes the result like the mirror's."""
+    from hdl_graph_slam_amd import _lib as L
+    tgt, src = _write_pair(tmp_path)
+    poses = {}
+    for name, value in (("PLANE", L.HGS_REG_PLANE), ("FROBENIUS", L.HGS_REG_FROBENIUS), ("NOT_A_METHOD", L.HGS_REG_FROBENIUS)):
+        out = _run(exe, "factory", tmp_path / "t.bin", tmp_path / "s.bin", name)
+        lines = [ln for ln in out if ln.startswith(("factory", "pose"))]
+        for head, pose in zip(lines[0::2], lines[1::2]):
+            f = head.split()
+            if f[1] in ("FAST_GICP_HIP", "FAST_VGICP_HIP"):
+                assert int(f[f.index("regularization") + 1]) == value, head
+                poses[(f[1], name)] = _pose(pose)
+            elif f[1] == "NDT_HIP":
+                assert int(f[3]) == 1
+    for engine in ("FAST_GICP_HIP", "FAST_VGICP_HIP"):
+        assert not np.array_equal(poses[(engine, "PLANE")], poses[(engine, "FROBENIUS")])
+        assert np.array_equal(poses[(engine, "NOT_A_METHOD")], poses[(engine, "FROBENIUS")])       # unknown name: warning + the default
+    if align_with is not None:
+        for engine, method in (("FAST_GICP_HIP", "FAST_GICP"), ("FAST_VGICP_HIP", "FAST_VGICP")):
+            for name in ("PLANE", "FROBENIUS"):
+                assert np.array_equal(poses[(engine, name)], align_with(method, name, tgt, src)), (engine, name)     # the mirror's pose bit for bit
+
+
+def _check_loop_robustness(exe, tmp_path, best_want, T_want):
+    wl, files = _write_loop_set(tmp_path)
+    # a device batch that is refused (the same keyframe twice) must end in the reference's sequential loop, not in a silently dropped detection
+    out = _run(exe, "loop_dup", "FAST_GICP_HIP", 1, tmp_path / "t.bin", tmp_path / "g.bin", *files)
+    builds = _check_loop(out, best_want, T_want, 2e-4)
+    assert builds[0] >= 1, builds             # getFitnessScore on PCL's CPU tree = the sequential loop ran
+    # two resident keyframes allowed for five candidates: evicted keyframes are uploaded again, results unchanged
+    out = _run(exe, "loop_lru", "FAST_GICP_HIP", 1, tmp_path / "t.bin", tmp_path / "g.bin", *files)
+    assert _check_loop(out, best_want, T_want, 2e-4) == [0, 0]
+
+
+@needs_reference
+def test_next_row_hunks_and_robustness_on_the_emulated_kernels(tmp_path):
+    exe = IB.build("simt")
+    if exe is None:
+        pytest.skip("no clang++ for the host emulation")
+    import oracle as O
+    _check_next_rows(exe, tmp_path)
+    _check_regularization_param(exe, tmp_path, None)
+    wl, files = _write_loop_set(tmp_path)
+    o = O.OracleRegistration(O.default_params(O.HGS_FAST_GICP))
+    o.setInputTarget(wl.target)
+    best, best_score, T_best = -1, np.finfo(np.float64).max, None
+    for i, (c, g) in enumerate(zip(wl.candidates, wl.guesses)):
+        o.setInputSource(c)
+        r = o.align(g)
+        s = o.getFitnessScore(4.0)
+        if r.converged and not s > best_score:
+            best, best_score, T_best = i, s, r.matrix()
+    _check_loop_robustness(exe, tmp_path, best, T_best)
+
+
+@pytest.mark.gpu
+def test_next_row_hunks_and_robustness_on_the_gpu(tmp_path):
+    exe = IB.build("hip")
+    assert exe is not None and os.path.exists(exe)
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    _check_next_rows(exe, tmp_path)
+
+    def mirror(method, regularization, tgt, src):
+        reg = select_registration_method({"registration_method": method, "reg_regularization_method": regularization, "reg_resolution": 1.0})
+        reg.setInputTarget(tgt)
+        reg.setInputSource(src)
+        T = reg.align(np.eye(4)).matrix()
+        reg.close()
+        return T
+    _check_regularization_param(exe, tmp_path, mirror)
+    wl, files = _write_loop_set(tmp_path)
+    reg = select_registration_method({"registration_method": "FAST_GICP"})
+    reg.setInputTarget(wl.target)
+    rec, best = reg.loop_match_batch([reg.upload(c) for c in wl.candidates], wl.guesses, 4.0)
+    T_best = np.array(rec["final_transformation"][best]).reshape(4, 4).T
+    reg.close()
+    _check_loop_robustness(exe, tmp_path, int(best), T_best)

@@ -94,3 +94,30 @@ def test_information_matrix_fitness_score_on_device():
     for mr in (np.finfo(np.float64).max, 2.0):
         assert abs(reg.calc_fitness_score(c1, c2, T.astype(np.float32), mr) - o.getFitnessScore(mr, T=T.astype(np.float32))) < 1e-9
     reg.close()
+
+
+@pytest.mark.gpu
+def test_ndt_batches_of_different_shape_back_to_back():
+    """One engine, three NDT batches whose lanes get different work plans (tile prefix sums, queue heads; hgs_engine.hip run_batch) with nothing in between:
+    every lane must see ITS batch's plan (round-5 advisor finding: lanes 1.. were ordered behind an event recorded before the plan upload).  Records are
+    per problem, hence must equal the single registrations bit for bit whatever ran before."""
+    from hdl_graph_slam_amd import workloads
+    from hdl_graph_slam_amd.registrations import select_registration_method
+    wl = workloads.make_loop_closure_set("HDL-32E", 5, n_candidates=9, n_distinct=4, downsample=0.3)
+    pnh = {"registration_method": "NDT_OMP", "reg_resolution": 1.0}
+    reg = select_registration_method(pnh)
+    reg.setInputTarget(wl.target)
+    # different sizes per candidate -> different tile counts per lane
+    clouds = [c[: len(c) - 257 * i] for i, c in enumerate(wl.candidates)]
+    dev = [reg.upload(c) for c in clouds]
+    single = []
+    for c, g in zip(dev, wl.guesses):
+        reg.setInputSource(c)
+        r = reg.align(g)
+        single.append((bytes(r.final_transformation), r.iterations, r.converged))
+    for order in ([0, 1, 2, 3, 4, 5, 6, 7, 8], [8, 3, 5, 1, 0], [2, 7, 4, 6, 8, 1, 3], [5, 0], [4, 4 - 1, 8, 0, 2, 6, 7, 5, 1]):
+        for _ in range(3):
+            rec, _best = reg.loop_match_batch([dev[i] for i in order], [wl.guesses[i] for i in order])
+            for k, i in enumerate(order):
+                assert rec["final_transformation"][k].tobytes() == single[i][0] and rec["iterations"][k] == single[i][1] and rec["converged"][k] == single[i][2], (order, k)
+    reg.close()
