@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--no-adapter-record", action="store_true", help="config 3: skip the `adapter_path` sub-record (the stream through the C++ pcl::Registration adapter)")
     ap.add_argument("--no-kitti-records", action="store_true", help="config 3: skip the two sub-records that run the stream behind the KITTI launch file's prefilter")
     ap.add_argument("--oracle-sweeps", type=int, default=12, help="config 3: sweeps the CPU oracle runs through the same caller for the trajectory agreement (0: none)")
-    ap.add_argument("--speed", type=float, default=0.0, help="config 3: vehicle speed in m/s (default: 8.0 as SURVEY 8d, plus a 3.0 m/s sub-record)")
+    ap.add_argument("--speed", type=float, default=0.0, help="config 3: vehicle speed in m/s (default: 2.0 — where NDT_OMP keeps track, profiles/r06_ndt_tracking.md — plus an 8.0 m/s sub-record as SURVEY 8d)")
     ap.add_argument("--method", default="", choices=["", "FAST_GICP", "FAST_VGICP", "NDT_OMP"])
     ap.add_argument("--downsample", type=float, default=0.0, help="voxel size applied to every cloud (0 = raw scans, the metric's configuration)")
     ap.add_argument("--seeds", type=int, default=-1, help="scene seeds: the timed region runs on seed 0, the others are reported next to it "
@@ -825,12 +825,15 @@ def run_odometry(ctx):
     """Config 3: ScanMatchingOdometryNodelet::matching (apps/scan_matching_odometry_nodelet.cpp:165-262) on a 64-beam stream with
     the keyframe rule of launch/hdl_graph_slam_kitti.launch:41-43; a step = one sweep, host buffer in -> pose out (upload, index /
     voxelisation when the keyframe switches, align, result download ALL inside the timed step).  The path is sequential in time:
-    replicas only at N > 1.  SURVEY 8d's stream drives at 8 m/s (0.8 m per sweep); the line also carries the same measurement at
-    3 m/s (`at_3_mps`, the speed rounds 1-2 reported) and, for both, how far the CPU oracle run through the same caller ends from
-    the device's trajectory (`oracle_stream`): whether NDT at resolution 1.0 keeps track is a property of the algorithm on this
-    scene, identical on both sides."""
+    replicas only at N > 1.  SURVEY 8d's stream drives at 8 m/s (0.8 m per sweep), which NDT_OMP as ndt_omp runs it (Newton step, no line search, guess =
+    previous result) cannot follow on the synthetic scene: the estimate stays at the origin on every scene / prefilter / resolution variant, on the CPU oracle
+    exactly as on the device (profiles/r06_ndt_tracking.md: noise-free planes make the cells' Gaussians a few centimetres thin, 0.8 m is outside their
+    support; 3 m/s is the edge of the basin, <= 2 m/s tracks in every variant).  Round 6: `value` is therefore measured at 2 m/s (`keeps_track` true), the
+    8 m/s stream rides along as `at_8_mps` with its `keeps_track: false`, and the KITTI launch file's own pipeline (prefilter + FAST_GICP, which does
+    track at 8 m/s) stays at 8 m/s.  `oracle_stream`: how far the CPU oracle run through the same caller ends from the device's trajectory."""
     a = ctx["args"]
-    speeds = [a.speed] if a.speed > 0 else [8.0, 3.0]
+    speeds = [a.speed] if a.speed > 0 else [2.0, 8.0]
+    kitti_speed = a.speed if a.speed > 0 else 8.0
     out = odometry_at_speed(ctx, speeds[0], ctx["n_seeds"], not a.no_cpu_baseline)
     keys = ("value", "ms_per_step", "steps", "latency_ms", "mean_iterations", "max_iterations", "keyframes", "us_per_iteration_p50", "trajectory_error_vs_ground_truth",
             "oracle_stream")
@@ -844,7 +847,7 @@ def run_odometry(ctx):
         # (distance 0.1-100 m, VoxelGrid 0.25 m, radius outlier removal 0.5 m / 2 neighbours) ON THE DEVICE, then (a) the engine SURVEY 8d names for
         # config 3 (NDT_OMP) and (b) the engine that launch file selects (FAST_GICP, transformation epsilon 0.1, max correspondence distance 2.0)
         for name, pipeline in (("kitti_prefilter_ndt_omp", "kitti_prefilter"), ("kitti_launch_fast_gicp", "kitti_launch")):
-            o = odometry_at_speed(ctx, speeds[0], 1, not a.no_cpu_baseline, pipeline=pipeline)
+            o = odometry_at_speed(ctx, kitti_speed, 1, not a.no_cpu_baseline, pipeline=pipeline)
             out[name] = {k: o[k] for k in keys + ("cpu_baseline", "roofline")}
             out[name]["workload"] = o["config"]["workload"]
             out[name]["points_after_prefilter"] = o["config"]["points_after_prefilter"]
@@ -1016,7 +1019,9 @@ def odometry_at_speed(ctx, speed, n_seeds, with_cpu, pipeline="raw"):
                 "value_by_scene_seed": by_seed, "value_mean_std_over_seeds": [round(float(np.mean(by_seed)), 2), round(float(np.std(by_seed)), 2)],
                 "trajectory_error_vs_ground_truth": {"final_translation_m": round(err[-1][0], 4), "rmse_translation_m": round(rmse_t, 4),
                                                      "rmse_rotation_rad": round(float(np.sqrt(np.mean([e[1] ** 2 for e in err]))), 5),
-                                                     "keeps_track": bool(err[-1][0] < 2.0)},
+                                                     "distance_travelled_m": round(speed / 10.0 * max(len(err) - 1, 1), 2),
+                                                     # final error below 2 % of the distance travelled (and 0.25 m): the criterion of profiles/r06_ndt_tracking.md
+                                                     "keeps_track": bool(err[-1][0] < max(0.25, 0.02 * speed / 10.0 * max(len(err) - 1, 1)))},
                 "oracle_stream": oracle_stream, "roofline": roofline, "cpu_baseline": cpu})
     reg.close()
     return out

@@ -44,7 +44,8 @@ struct TargetView {
   const float4* cov;
   const CloudMeta* meta;
   int P;
-  int pad;
+  int seed_bits;             // log2 of the finest seed table's size (0: no seed grid)
+  const unsigned* seed_tab;  // the cloud's seed grid (seed_grid_lookup, hgs_kernels.hip): three direct-mapped tables back to back
 };
 
 // NDT target tables
@@ -85,6 +86,7 @@ struct Progress {
   int pad;
 };
 
+constexpr int kFusedTailMaxProblems = 4;  // launches of at most this many problems run the LM control steps in the tails of k_gicp_linearize / k_gicp_error
 constexpr int kBlock = 256;
 constexpr int kKnnLaneList = 16;          // leaves a lane of k_knn_cov remembers as its own candidates' (more: the wave falls back to the replay / walk)
 constexpr int kKnnLeafLog = 128;           // leaves pass 1 of k_knn_cov remembers per wave for pass 2 (more: pass 2 walks the tree)
@@ -92,21 +94,23 @@ constexpr int kNW = 1;                    // packets of 64 queries a wave walks 
 constexpr int kTileNN = kBlock * kNW;     // source points per block of k_gicp_linearize / k_fitness
 
 // ---- launchers (hgs_kernels.hip) --------------------------------------------------------------------------
-void launch_pack_aos(hipStream_t s, const float4* staged /* {x, y, z, intensity} */, int n, float4* raw, float* intensity /* may be null */, CloudMeta* meta_to_reset /* may be null */);
+void launch_pack_aos(hipStream_t s, const float4* staged /* {x, y, z, intensity} */, int n, float4* raw, float* intensity /* may be null */, CloudMeta* meta_to_reset /* may be null */,
+                     const CloudDesc* desc = nullptr /* + the cloud's resident descriptor: *desc -> *desc_out */, CloudDesc* desc_out = nullptr);
 void launch_meta_init(hipStream_t s, const CloudDesc* descs, int ncloud);
 void launch_bbox_count(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n);
 void launch_hilbert_keys(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, unsigned long long* keys, unsigned* vals, int drop_bits);
 void launch_gather_sorted(hipStream_t s, const CloudDesc* descs, int ncloud, int max_slots, const unsigned* sorted_vals);
 void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int max_P);
-void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method,
-                    int gather /* pass 2: 0 tree walk, 1 leaf-log replay, 2 per-lane leaf lists */);
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, int gather /* 0 walk, 1 leaf-log replay, 2 per-lane lists */,
+                    double* raw_stage = nullptr /* ncloud * max_n * 6 doubles: non-FROBENIUS regularisations run as search + k_cov_regularize */);
 
-void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog);
-void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B,
-                           int qpw /* queries per wave: 64, or 16 for launches too small to fill the chip */);
+void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog, unsigned* tickets = nullptr /* [2 * B]: the fused tails' tile tickets */);
+void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, GicpState* states, GicpConsts c, double* partials, int max_blocks, int B,
+                           int qpw, unsigned* tickets = nullptr /* non-null: k_gicp_linearize<true> — the LM solve runs in the tail of the problem's last block */);
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
                        int tile_points /* points per block of the linearize kernel that filled `partials` */);
-void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B);
+void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, GicpState* states, double* partials_err, int max_blocks, int B,
+                       const GicpConsts* fused_c = nullptr, unsigned* tickets = nullptr /* non-null: k_gicp_error<true> — accept / reject + progress tick in the tail */, Progress prog = Progress{});
 void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B, Progress prog);
 void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out, int B);
 
@@ -118,6 +122,9 @@ struct hgs_result;  // include/hgs_registration.h
 namespace hgs {
 void launch_results_to_records(hipStream_t s, const DevResult* res, const int* candidate_ids, int n, int n_slots, ::hgs_result* out);
 void launch_nn_query(hipStream_t s, TargetView tgt, const float4* q, int nq, int* idx, float* d2);
+// seed grid of a target cloud: every sorted point enters three direct-mapped tables (cells of 0.25 / 1 / 4 m, sizes 2^bits, 2^(bits-2), 2^(bits-4))
+void launch_seed_grid_build(hipStream_t s, const float4* pts, const CloudMeta* meta, int n_max, unsigned* tab, int bits);
+inline size_t seed_grid_entries(int bits) { return ((size_t)1 << bits) + ((size_t)1 << (bits - 2)) + ((size_t)1 << (bits - 4)); }
 void launch_transform(hipStream_t s, const float4* raw, int n, const float* T16_colmajor_dev, float4* out);
 
 void launch_ndt_grid_params(hipStream_t s, CloudDesc desc, float inv_leaf);
@@ -177,7 +184,8 @@ void launch_map_centers(hipStream_t s, const unsigned long long* keys, const uns
                         int* count_out);
 
 // prefilter (apps/prefiltering_nodelet.cpp)
-void launch_pf_load(hipStream_t s, const float4* staged /* {x, y, z, intensity} */, int n, float4* out, const float* deskew_w /* -(gyro rate), or null */, double scan_period);
+void launch_pf_load(hipStream_t s, const float4* staged, int n, float4* out, const float* deskew_w /* null: no deskewing */, double scan_period, int* count_out,
+                    unsigned* meta_out /* [16]: the voxel-grid record, initialised here */);
 void launch_pf_distance_flags(hipStream_t s, const float4* pts, int n, int use_filter, double near_thresh, double far_thresh, unsigned* keep);
 void launch_pf_compact(hipStream_t s, const float4* in, int n, const unsigned* keep, const unsigned* slot, float4* out, int* count);
 void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta);
@@ -196,7 +204,7 @@ void launch_pf_approx_centroids(hipStream_t s, const float4* pts, const unsigned
 void launch_pf_radius_flags(hipStream_t s, CloudDesc d, float r2, int min_neighbors, unsigned* keep);
 void launch_pf_mean_knn_dist(hipStream_t s, CloudDesc d, int mean_k, double* dist);
 void launch_pf_statistical(hipStream_t s, const double* dist, int n, double* stats, double stddev_mul, unsigned* keep);
-void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity, CloudMeta* meta_to_reset);
+void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity, CloudMeta* meta_to_reset, const CloudDesc* desc = nullptr, CloudDesc* desc_out = nullptr);
 
 // stage-level test hooks
 void launch_gicp_debug_state(hipStream_t s, GicpState* st, const double* T12_dev);

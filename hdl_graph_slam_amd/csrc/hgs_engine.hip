@@ -259,6 +259,7 @@ struct hgs_cloud {
   void* block = nullptr;
   size_t block_bytes = 0;
   CloudDesc desc{};
+  CloudDesc* dev_desc = nullptr;  // the descriptor inside the cloud's block (pad = 1, sort_off = 0), written by the kernel that fills raw[]: upload_descs of ONE cloud returns it
   float* intensity = nullptr;  // [n_input] PointXYZI intensity (what hgs_cloud_download / the prefilter hand back)
   bool has_index = false;
   bool corr_stale = false;  // hgs_cloud_invalidate: the correspondence seeds are forgotten when the index is rebuilt (k_gather_sorted)
@@ -281,6 +282,11 @@ struct hgs_cloud {
   int vg_cov_k = 0;
   void* vg_block = nullptr;
   size_t vg_block_bytes = 0;
+  // seed grid (target role of the 1-NN kernels: seed_grid_lookup, hgs_kernels.hip)
+  bool has_seed = false;
+  void* seed_block = nullptr;
+  size_t seed_block_bytes = 0;
+  int seed_bits = 0;
   int* vg_hash_keys = nullptr;
   int* vg_hash_vals = nullptr;
   NdtCellRec* vg_cells = nullptr;
@@ -311,6 +317,11 @@ struct hgs_handle {
   // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default).  Round 2, 64 x 119 k-point batch:
   // 1 / 2 / 3 / 4 lanes = 3680 / 3999 / 3937 / 3913 GICP reg/s and 1064 / 1403 / 1384 / 1326 NDT — with 32 problems per lane a lane's
   // launches fill the device on their own and two chains are enough to cover each other's solves and tails.
+  int fused_tails = 1;     // launches of <= kFusedTailMaxProblems GICP problems: LM control steps in the point kernels' tails (0: four launches per round; HGS_FUSED_TAILS, A/B runs)
+  int cov_split = 1;       // non-FROBENIUS regularisations: search kernel + k_cov_regularize (0: one kernel with the eigen-decomposition inline; HGS_COV_SPLIT, A/B runs)
+  int resident_descs = 1;  // HGS_RESIDENT_DESCS=0: every stage uploads its descriptor array (A/B runs)
+  int knn_qpw_tiny = 16;  // queries per packet of k_knn_cov for launches below 32 k queries (0: 32 as for every small launch); HGS_KNN_QPW_TINY (A/B runs)
+  int seed_grid = 1;    // targets of 1-NN searches get a seed grid (ensure_seed_grid); HGS_SEED_GRID=0 (A/B runs)
   int knn_replay = -1;  // k_knn_cov gather: -1 default (2), 0 tree walk, 1 leaf-log replay, 2 per-lane leaf lists; HGS_KNN_REPLAY (A/B runs, tests)
   int batch_lanes = 0;  // 0: open_lanes chooses (4; NDT_OMP above 32 problems 3; never more than the process's hardware-queue budget has room for); HGS_BATCH_LANES fixes it (A/B runs)
   std::string err;
@@ -324,6 +335,8 @@ struct hgs_handle {
   DeviceBuffer ndt_accum;  // NdtAccum per problem of the running NDT batch
   hgs::Comm* comm = nullptr;            // hgs_comm_init: the ranks of a sharded loop-closure batch
   DeviceBuffer comm_send, comm_recv, comm_ids;
+  DeviceBuffer tickets;          // fused LM tails: two tile tickets per problem (k_gicp_linearize<true> / k_gicp_error<true>)
+  DeviceBuffer cov_raw;          // staged fp64 neighbourhood covariances between k_knn_cov<.., 2, ..> and k_cov_regularize
   DeviceBuffer ndt_plan;         // per lane: work queue head + tile prefix sums of the running NDT batch
   // blocks per k_ndt_pass launch (0: by the lane count, below); HGS_NDT_RESIDENT (A/B runs).  Two blocks per CU are resident (the round-4 kernel
   // holds 57 KB of LDS per block).  One lane: 768 — the third block per CU fills the tail (512 / 768 / 1024: 497 / 473 / 452 us per whole-device pass
@@ -490,6 +503,8 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   size_t off = 0;
   const size_t o_meta = off;
   off = align_up(off + sizeof(CloudMeta), 256);
+  const size_t o_desc = off;
+  off = align_up(off + sizeof(CloudDesc), 256);
   const size_t o_raw = off;
   off = align_up(off + n_cap * sizeof(float4), 256);
   const size_t o_pts = off;
@@ -522,6 +537,7 @@ int cloud_alloc(hgs_handle* h, size_t n, hgs_cloud** out) {
   }
   char* base = (char*)c->block;
   c->desc.meta = (CloudMeta*)(base + o_meta);
+  c->dev_desc = (CloudDesc*)(base + o_desc);
   c->desc.raw = (const float4*)(base + o_raw);
   c->desc.pts = (float4*)(base + o_pts);
   c->desc.lpts = (float4*)(base + o_lpts);
@@ -549,8 +565,9 @@ void cloud_release_device(hgs_cloud* c, bool pool) {
   }
   if (c->ndt_block) (void)hipFree(c->ndt_block);
   if (c->vg_block) (void)hipFree(c->vg_block);
-  c->block = nullptr, c->ndt_block = nullptr, c->vg_block = nullptr;
-  c->has_index = c->has_cov = c->has_ndt = c->has_vg = false;
+  if (c->seed_block) (void)hipFree(c->seed_block);
+  c->block = nullptr, c->ndt_block = nullptr, c->vg_block = nullptr, c->seed_block = nullptr;
+  c->has_index = c->has_cov = c->has_ndt = c->has_vg = c->has_seed = false;
 }
 
 void cloud_free(hgs_cloud* c) {
@@ -564,8 +581,21 @@ void cloud_free(hgs_cloud* c) {
 }
 
 // Upload descriptors of a set of clouds (with their sort offsets) into h->descs; returns device pointer.
+// what a cloud's resident descriptor holds: pad = 1 (an index build always follows a creation or an invalidation, both of which ask for corr[] to be
+// cleared; nothing else reads pad), sort_off = 0 (a cloud alone in a batch sort)
+CloudDesc resident_desc(const hgs_cloud* c) {
+  CloudDesc d = c->desc;
+  d.sort_off = 0, d.pad = 1;
+  return d;
+}
+
 int upload_descs(hgs_handle* h, const std::vector<hgs_cloud*>& clouds, bool with_sort_offsets, const CloudDesc** dev, size_t* total_n) {
   const size_t B = clouds.size();
+  if (B == 1 && clouds[0]->dev_desc && h->resident_descs) {  // one cloud: its resident descriptor, no copy
+    if (total_n) *total_n = clouds[0]->n_input;
+    *dev = clouds[0]->dev_desc;
+    return HGS_OK;
+  }
   HGS_HIP(h, h->descs.reserve(B * sizeof(CloudDesc)));
   void* staged = nullptr;
   int slot = 0;
@@ -588,7 +618,13 @@ int upload_descs(hgs_handle* h, const std::vector<hgs_cloud*>& clouds, bool with
 // (one 120 k-point cloud is 1.8 waves per SIMD) and is bound by the dependent-load chain of a single walk; 32-query
 // packets walk fewer nodes and put more waves in flight (0.91 -> 0.66 ms for one 120 k-point cloud).  Large batches keep
 // 64 (least total work); the 1-NN kernels always do (no measurable gain from shorter packets there).
-int queries_per_wave(size_t total_queries, int small) { return total_queries >= (size_t)600000 ? 64 : small; }
+// Round 6: a launch that cannot even give every SIMD one 32-query packet (an odometry source behind the KITTI prefilter: 13.5 k points = 422 packets)
+// is bound by ONE packet's serial chain; `tiny`-query packets make that chain shorter (fewer leaves in the union walk) — k_knn_cov 122 -> see
+// profiles/r06_ab_qpw.log.
+int queries_per_wave(size_t total_queries, int small, int tiny = 0) {
+  if (tiny > 0 && total_queries < (size_t)1024 * (size_t)small) return tiny;
+  return total_queries >= (size_t)600000 ? 64 : small;
+}
 
 // Build the search index (Hilbert sort + implicit tree) of every cloud in the list that lacks one — one
 // batched kernel sequence and ONE radix sort for the whole list.
@@ -662,12 +698,17 @@ int ensure_cov(hgs_handle* h, const std::vector<hgs_cloud*>& all, int k) {
   for (hgs_cloud* c : todo) max_n = std::max(max_n, (int)c->n_input);
   size_t total_q = 0;
   for (hgs_cloud* c : todo) total_q += c->n_input;
-  const int qpw = queries_per_wave(total_q, 32);  // >= k points in the pre-fill window
+  const int qpw = queries_per_wave(total_q, 32, h->knn_qpw_tiny);  // (32: >= k points in the pre-fill window)
   // the leaf-log gather pays for batches of LiDAR keyframes, not for one or two (dense) clouds: see launch_knn_cov
   // pass 2 of k_knn_cov: per-lane leaf lists (mode 2; measured against the leaf-log replay and the second tree walk: 64 LiDAR clouds
   // 4.25 -> 4.0 ms, dense 1 M-point pair 1.46 -> 1.27 ms, one HDL-32E pair unchanged); HGS_KNN_REPLAY=0|1|2 forces a mode (tests, A/B)
   const int gather = h->knn_replay >= 0 ? h->knn_replay : 2;
-  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, qpw, h->prm.regularization_method, gather);
+  double* raw_stage = nullptr;
+  if (h->prm.regularization_method != 0 && h->cov_split) {  // PLANE / MIN_EIG / ...: the eigen-decompositions in a kernel of their own (k_cov_regularize)
+    HGS_HIP(h, h->cov_raw.reserve(todo.size() * (size_t)std::max(max_n, 1) * 6 * sizeof(double)));
+    raw_stage = h->cov_raw.as<double>();
+  }
+  launch_knn_cov(h->stream, d_descs, (int)todo.size(), max_n, k, qpw, h->prm.regularization_method, gather, raw_stage);
   HGS_HIP(h, hipGetLastError());
   for (hgs_cloud* c : todo) c->has_cov = true, c->cov_k = key;
   return HGS_OK;
@@ -807,8 +848,28 @@ VgicpConsts vgicp_consts(const hgs_params& p) {
 
 TargetView target_view(const hgs_cloud* c) {
   TargetView t;
-  t.nodes = c->desc.nodes, t.pts = c->desc.pts, t.lpts = c->desc.lpts, t.cov = c->desc.cov, t.meta = c->desc.meta, t.P = c->P, t.pad = 0;
+  t.nodes = c->desc.nodes, t.pts = c->desc.pts, t.lpts = c->desc.lpts, t.cov = c->desc.cov, t.meta = c->desc.meta, t.P = c->P;
+  t.seed_bits = c->has_seed ? c->seed_bits : 0, t.seed_tab = c->has_seed ? static_cast<const unsigned*>(c->seed_block) : nullptr;
   return t;
+}
+
+// The seed grid of a cloud that serves as the target of 1-NN searches (hgs_kernels.hip, seed_grid_lookup): built once per index, ~10 us.
+int ensure_seed_grid(hgs_handle* h, hgs_cloud* c) {
+  if (!h->seed_grid || c->has_seed || !c->has_index || c->n_input == 0) return HGS_OK;
+  int bits = 12;
+  while (bits < 24 && ((size_t)1 << bits) < 4 * c->n_input) bits++;
+  const size_t bytes = seed_grid_entries(bits) * sizeof(unsigned);
+  if (!c->seed_block || c->seed_bits != bits) {
+    if (c->seed_block) (void)hipFree(c->seed_block);
+    c->seed_block = nullptr;
+    HGS_HIP(h, hipMalloc(&c->seed_block, bytes));
+    c->seed_block_bytes = bytes, c->seed_bits = bits;
+  }
+  HGS_HIP(h, hipMemsetAsync(c->seed_block, 0xff, bytes, h->stream));
+  launch_seed_grid_build(h->stream, c->desc.pts, c->desc.meta, (int)c->n_input, static_cast<unsigned*>(c->seed_block), bits);
+  HGS_HIP(h, hipGetLastError());
+  c->has_seed = true;
+  return HGS_OK;
 }
 
 GicpConsts gicp_consts(const hgs_params& p) {
@@ -1021,6 +1082,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   } else {
     HGS_TRY(ensure_ndt_target(h, tgt));
   }
+  if (fit_max_range && method != HGS_FAST_GICP) HGS_TRY(ensure_seed_grid(h, tgt));  // getFitnessScore without correspondences to start from (k_fitness)
   int max_n = 0;
   for (hgs_cloud* c : sources) max_n = std::max(max_n, (int)c->n_input);
   size_t total_q = 0;
@@ -1052,25 +1114,34 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       launch_gicp_results(L.stream, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
       if (fit_max_range) lane_fitness(h, L, d_descs, *fit_max_range, max_blocks, qpw, nn_tile);
     };
-    for (BatchLane& L : lanes) launch_gicp_init(L.stream, st + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, L.B, L.prog);
+    // A launch of a few problems (a single registration: the odometry step, config 2) is a chain of ~4 us kernels: the two per-problem control launches
+    // of an LM round then cost as much as its two point kernels.  Such launches run the control steps in the TAILS of the point kernels
+    // (k_gicp_linearize<true> / k_gicp_error<true>, hgs_kernels.hip): two launches per round, the same arithmetic in the same order.
+    unsigned* tickets = nullptr;
+    if (!voxel && h->fused_tails && B <= kFusedTailMaxProblems) {
+      HGS_HIP(h, h->tickets.reserve((size_t)B * 2 * sizeof(unsigned)));
+      tickets = h->tickets.as<unsigned>();
+    }
+    for (BatchLane& L : lanes) launch_gicp_init(L.stream, st + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, L.B, L.prog, tickets ? tickets + 2 * L.b0 : nullptr);
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       const CloudDesc* dd = d_descs + L.b0;
       GicpState* ls = st + L.b0;
+      unsigned* lt = tickets ? tickets + 2 * L.b0 : nullptr;
       {
         StageTimer tm(h, HGS_STAGE_LINEARIZE);
         if (voxel) launch_vgicp_linearize(L.stream, dd, vtv, ls, vc, L.partials, max_blocks, L.B);
-        else launch_gicp_linearize(L.stream, dd, tv, ls, c, L.partials, max_blocks, L.B, qpw);
+        else launch_gicp_linearize(L.stream, dd, tv, ls, c, L.partials, max_blocks, L.B, qpw, lt);
       }
-      {
+      if (!lt) {
         StageTimer tm(h, HGS_STAGE_SOLVE);
         launch_gicp_solve(L.stream, dd, ls, c, L.partials, max_blocks, L.B, voxel ? kBlock : nn_tile);
       }
       {
         StageTimer tm(h, HGS_STAGE_ERROR);
         if (voxel) launch_vgicp_error(L.stream, dd, vtv, ls, vc, L.partials_err, max_blocks, L.B);
-        else launch_gicp_error(L.stream, dd, tv, ls, L.partials_err, max_blocks, L.B);
+        else launch_gicp_error(L.stream, dd, tv, ls, L.partials_err, max_blocks, L.B, &c, lt, L.prog);
       }
-      {
+      if (!lt) {
         StageTimer tm(h, HGS_STAGE_SOLVE);
         launch_gicp_decide(L.stream, dd, ls, c, L.partials_err, max_blocks, L.B, L.prog);
       }
@@ -1165,11 +1236,14 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
 }
 
 // fitness of B sources against the target with the poses stored in h->results[b].T; fills fit_sum / fit_count
-int run_fitness(hgs_handle* h, const std::vector<hgs_cloud*>& sources, double max_range) {
+// use_corr_seeds: the sources' corr[] hold their correspondences against THIS target (hgs_fitness right behind a GICP align); otherwise the
+// searches start from the target's seed grid
+int run_fitness(hgs_handle* h, const std::vector<hgs_cloud*>& sources, double max_range, bool use_corr_seeds) {
   const int B = (int)sources.size();
   std::vector<hgs_cloud*> all(sources);
   all.push_back(h->target);
   HGS_TRY(ensure_index(h, all));
+  if (!use_corr_seeds) HGS_TRY(ensure_seed_grid(h, h->target));
   int max_n = 0;
   for (hgs_cloud* c : sources) max_n = std::max(max_n, (int)c->n_input);
   const int qpw = h->nn_qpw > 0 ? h->nn_qpw : 64;
@@ -1180,7 +1254,7 @@ int run_fitness(hgs_handle* h, const std::vector<hgs_cloud*>& sources, double ma
   HGS_HIP(h, h->partials_err.reserve((size_t)B * max_blocks * 2 * sizeof(double)));
   StageTimer tm(h, HGS_STAGE_FITNESS);
   launch_fitness(h->stream, d_descs, target_view(h->target), h->results.as<DevResult>(), max_range, h->partials_err.as<double>(), max_blocks, B,
-                 h->prm.method == HGS_FAST_GICP ? 1 : 0, qpw);
+                 use_corr_seeds ? 1 : 0, qpw);
   launch_fitness_final(h->stream, d_descs, h->partials_err.as<double>(), max_blocks, h->results.as<DevResult>(), B, nn_tile);
   HGS_HIP(h, hipGetLastError());
   return HGS_OK;
@@ -1297,6 +1371,11 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
   if (const char* e = std::getenv("HGS_BATCH_LANES")) h->batch_lanes = std::max(1, std::min(kMaxLanes, std::atoi(e)));  // A/B measurements
   if (const char* e = std::getenv("HGS_LANE_START")) h->lane_start = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("HGS_NDT_SORT")) h->ndt_sort = std::max(-1, std::min(1, std::atoi(e)));
+  if (const char* e = std::getenv("HGS_FUSED_TAILS")) h->fused_tails = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("HGS_COV_SPLIT")) h->cov_split = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("HGS_RESIDENT_DESCS")) h->resident_descs = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("HGS_KNN_QPW_TINY")) h->knn_qpw_tiny = std::max(0, std::min(32, std::atoi(e) & ~7));
+  if (const char* e = std::getenv("HGS_SEED_GRID")) h->seed_grid = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("HGS_KNN_REPLAY")) h->knn_replay = std::max(0, std::min(2, std::atoi(e)));
   if (const char* e = std::getenv("HGS_NDT_RESIDENT")) h->ndt_resident_blocks = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("HGS_NDT_CHUNK")) h->ndt_chunk = std::max(0, std::atoi(e));
@@ -1336,7 +1415,7 @@ int hgs_destroy(hgs_handle* h) try {
   h->live_clouds.clear();
   DeviceBuffer* bufs[] = {&h->staging, &h->sort_keys[0], &h->sort_keys[1], &h->sort_vals[0], &h->sort_vals[1], &h->sort_tmp, &h->descs, &h->states,
                           &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc,
-                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum,    &h->ndt_plan,
+                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum,    &h->ndt_plan,     &h->cov_raw,      &h->tickets,
                           &h->comm_send, &h->comm_recv,    &h->comm_ids};
   for (DeviceBuffer* b : bufs) b->release();
   for (int i = 0; i < kMaxLanes - 1; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
@@ -1390,14 +1469,11 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
         return rc;
       }
     }
-    launch_pack_aos(h->stream, staged, (int)n, const_cast<float4*>(c->desc.raw), c->intensity, c->desc.meta);  // (n == 0: the meta reset alone)
+    const CloudDesc resident = resident_desc(c);
+    launch_pack_aos(h->stream, staged, (int)n, const_cast<float4*>(c->desc.raw), c->intensity, c->desc.meta, &resident, c->dev_desc);  // (n == 0: the meta reset + descriptor alone)
     // nvalid + bounding box of the finite points
-    hipError_t e = h->descs.reserve(sizeof(CloudDesc));
-    if (e == hipSuccess) e = h->up.upload(h->descs.p, &c->desc, sizeof(CloudDesc), h->stream);
-    if (e == hipSuccess) {
-      launch_bbox_count(h->stream, h->descs.as<CloudDesc>(), 1, (int)n);  // (the meta record was reset by the packing kernel)
-      e = hipGetLastError();
-    }
+    launch_bbox_count(h->stream, c->dev_desc, 1, (int)n);  // (the meta record was reset and the descriptor written by the packing kernel)
+    hipError_t e = hipGetLastError();
     // (no synchronisation: the caller's buffer was read by the host while packing; everything else is ordered on the stream)
     if (e != hipSuccess) {
       h->err = std::string("cloud upload failed: ") + hipGetErrorString(e);
@@ -1438,14 +1514,14 @@ size_t hgs_cloud_size(const hgs_cloud* c) { return c ? c->n_input : 0; }
 
 size_t hgs_cloud_device_bytes(const hgs_cloud* c) {
   if (!c || !c->owner) return 0;
-  return (c->block ? c->block_bytes : 0) + (c->ndt_block ? c->ndt_block_bytes : 0) + (c->vg_block ? c->vg_block_bytes : 0);
+  return (c->block ? c->block_bytes : 0) + (c->ndt_block ? c->ndt_block_bytes : 0) + (c->vg_block ? c->vg_block_bytes : 0) + (c->seed_block ? c->seed_block_bytes : 0);
 }
 
 int hgs_cloud_invalidate(hgs_cloud* c) try {
   std::unique_lock<std::recursive_mutex> api_lock__;
   if (c && c->owner) api_lock__ = std::unique_lock<std::recursive_mutex>(c->owner->api_mutex);
   if (!c) return HGS_ERR_INVALID_ARGUMENT;
-  c->has_index = false, c->has_cov = false, c->has_ndt = false, c->has_vg = false;
+  c->has_index = false, c->has_cov = false, c->has_ndt = false, c->has_vg = false, c->has_seed = false;
   // also forget the correspondences of earlier registrations (they seed the next search): a truly cold cloud.  No launch here — 65
   // memsets per loop-closure batch were 65 launches of ~3 us —: the kernel that rebuilds the cloud's sorted arrays clears them
   // (a cloud without an index cannot be searched before ensure_index has run).
@@ -1573,7 +1649,7 @@ int hgs_fitness(hgs_handle* h, const float T[16], double max_range, double* scor
   HGS_TRY(set_device(h));
   HGS_TRY(upload_pose_as_result(h, T));
   std::vector<hgs_cloud*> src{h->source};
-  HGS_TRY(run_fitness(h, src, max_range));
+  HGS_TRY(run_fitness(h, src, max_range, h->prm.method == HGS_FAST_GICP));
   std::vector<DevResult> r;
   HGS_TRY(fetch_results(h, 1, r));
   *score = r[0].fit_count > 0 ? r[0].fit_sum / (double)r[0].fit_count : std::numeric_limits<double>::max();
@@ -1592,7 +1668,7 @@ int hgs_calc_fitness_score(hgs_handle* h, hgs_cloud* cloud1, hgs_cloud* cloud2, 
   h->target = cloud1;
   int rc = upload_pose_as_result(h, relpose);
   std::vector<hgs_cloud*> src{cloud2};
-  if (rc == HGS_OK) rc = run_fitness(h, src, max_range);
+  if (rc == HGS_OK) rc = run_fitness(h, src, max_range, false);  // two keyframe clouds: cloud2 holds no correspondences against cloud1
   std::vector<DevResult> r;
   if (rc == HGS_OK) rc = fetch_results(h, 1, r);
   h->target = saved_t;
@@ -2007,13 +2083,10 @@ int scan_u32(hgs_handle* h, const uint32_t* in, uint32_t* out, size_t n) {
 int cloud_from_device(hgs_handle* h, const float4* src, size_t m, hgs_cloud** out) {
   hgs_cloud* c = nullptr;
   HGS_TRY(cloud_alloc(h, m, &c));
-  launch_pf_to_cloud(h->stream, src, (int)m, const_cast<float4*>(c->desc.raw), c->intensity, c->desc.meta);
-  hipError_t e = h->descs.reserve(sizeof(CloudDesc));
-  if (e == hipSuccess) e = h->up.upload(h->descs.p, &c->desc, sizeof(CloudDesc), h->stream);
-  if (e == hipSuccess) {
-    launch_bbox_count(h->stream, h->descs.as<CloudDesc>(), 1, (int)m);  // (the meta record was reset by k_pf_to_cloud)
-    e = hipGetLastError();
-  }
+  const CloudDesc resident = resident_desc(c);
+  launch_pf_to_cloud(h->stream, src, (int)m, const_cast<float4*>(c->desc.raw), c->intensity, c->desc.meta, &resident, c->dev_desc);
+  launch_bbox_count(h->stream, c->dev_desc, 1, (int)m);  // (the meta record was reset and the descriptor written by k_pf_to_cloud)
+  hipError_t e = hipGetLastError();
   // (no synchronisation: `src` is a device array of this engine, read in stream order)
   if (e != hipSuccess) {
     h->err = std::string("prefilter: building the resident cloud failed: ") + hipGetErrorString(e);
@@ -2063,19 +2136,17 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
   HGS_HIP(h, h->pf_keep.reserve(cap * sizeof(uint32_t)));
   HGS_HIP(h, h->pf_slot.reserve(cap * sizeof(uint32_t)));
   HGS_HIP(h, h->pf_small.reserve(256));
-  HGS_HIP(h, h->h_small.reserve(64));
+  HGS_HIP(h, h->h_small.reserve(256));
   float4* cur = h->pf_a.as<float4>();
   float4* other = h->pf_b.as<float4>();
   int* d_count = h->pf_small.as<int>();                    // [0] current point count
   unsigned* d_meta = h->pf_small.as<unsigned>() + 16;      // voxel-grid bbox / grid parameters
   double* d_stats = reinterpret_cast<double*>(h->pf_small.as<char>() + 192);
-  if (n > 0) {
+  {
     const float4* staged = nullptr;
-    HGS_TRY(upload_points_packed(h, pts, n, stride_bytes, &staged));
-    launch_pf_load(h->stream, staged, (int)n, cur, deskew_w, scan_period);
+    if (n > 0) HGS_TRY(upload_points_packed(h, pts, n, stride_bytes, &staged));
+    launch_pf_load(h->stream, staged, (int)n, cur, deskew_w, scan_period, d_count, d_meta);  // (also: d_count = n, d_meta = the empty voxel-grid record)
   }
-  int host_n = (int)n;
-  HGS_HIP(h, h->up.upload(d_count, &host_n, sizeof(int), h->stream));
   if (n > 0 && p->use_distance_filter) {
     launch_pf_distance_flags(h->stream, cur, (int)n, 1, p->distance_near_thresh, p->distance_far_thresh, h->pf_keep.as<unsigned>());
     HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));
@@ -2084,8 +2155,6 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
   }
   if (n > 0 && p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID) {
     const float inv_leaf = 1.0f / (float)p->downsample_resolution;
-    unsigned init[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    HGS_HIP(h, hipMemcpyAsync(d_meta, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
     launch_pf_bbox(h->stream, cur, d_count, (int)n, d_meta);
     launch_pf_grid(h->stream, d_meta, inv_leaf);
     for (int i = 0; i < 2; i++) {
@@ -2147,11 +2216,11 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
   }
   HGS_HIP(h, hipGetLastError());
   int* hs = h->h_small.as<int>();
-  HGS_HIP(h, hipMemcpyAsync(hs, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HGS_HIP(h, hipMemcpyAsync(hs + 1, reinterpret_cast<int*>(d_meta) + 12, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  // the point count (pf_small[0]) and the voxel grid's overflow flag (d_meta[12] = pf_small[28]) in ONE copy
+  HGS_HIP(h, hipMemcpyAsync(hs, d_count, 32 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HGS_HIP(h, hipStreamSynchronize(h->stream));
   size_t m = (size_t)std::max(0, hs[0]);
-  if (n > 0 && p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID && hs[1]) {
+  if (n > 0 && p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID && hs[16 + 12]) {
     h->err = "prefilter: voxel grid too fine for this cloud (index overflow; pcl::VoxelGrid refuses it too)";
     return HGS_ERR_INVALID_ARGUMENT;
   }

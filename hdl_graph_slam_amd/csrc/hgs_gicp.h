@@ -48,9 +48,8 @@ HGS_HD Sym3 gicp_regularized_cov(const double* s1, const Sym3& s2, int found, in
 // NORMALIZED_MIN_EIG replace the singular values of C (JacobiSVD upstream; C is symmetric positive semi-definite, so U = V
 // = its eigenvectors and the singular values are its eigenvalues) by (1, 1, 1e-3) in descending order / max(sigma, 1e-3) /
 // max(sigma / sigma_max, 1e-3) and rebuild U diag(values) V^T.
-HGS_HD Sym3 gicp_regularized_cov(const double* s1, const Sym3& s2, int found, int k, int method) {
-  if (method == 0) return gicp_regularized_cov(s1, s2, found, k);
-  const Sym3 c = gicp_neighbour_cov(s1, s2, found, k, 0.0);
+// the part behind the neighbourhood covariance c (what k_cov_regularize runs on the covariances k_knn_cov<.., 2, ..> staged in fp64)
+HGS_HD Sym3 gicp_regularize_cov(const Sym3& c, int method) {
   if (method == 4) return c;
   const double A[9] = {c.xx, c.xy, c.xz, c.xy, c.yy, c.yz, c.xz, c.yz, c.zz};
   double w[3], V[9];
@@ -71,6 +70,10 @@ HGS_HD Sym3 gicp_regularized_cov(const double* s1, const Sym3& s2, int found, in
     o.xx += v[i] * x * x, o.xy += v[i] * x * y, o.xz += v[i] * x * z, o.yy += v[i] * y * y, o.yz += v[i] * y * z, o.zz += v[i] * z * z;
   }
   return o;
+}
+HGS_HD Sym3 gicp_regularized_cov(const double* s1, const Sym3& s2, int found, int k, int method) {
+  if (method == 0) return gicp_regularized_cov(s1, s2, found, k);
+  return gicp_regularize_cov(gicp_neighbour_cov(s1, s2, found, k, 0.0), method);
 }
 
 // Mahalanobis matrix of one correspondence at the linearisation pose: M = (C_B + R C_A R^T)^-1

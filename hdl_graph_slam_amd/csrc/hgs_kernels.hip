@@ -53,7 +53,7 @@ __device__ __forceinline__ float4 hgs_load_global_xyz(const float4* p) {  // .w 
 #endif                  // 5 waves (96 VGPRs, 64 bytes of spills outside the walk) 3.66 ms, 6 waves (80 VGPRs, spills inside the insertion chains) 6.7 ms
 // (the 32- / 64-slot lists and the instantiation with the per-point eigen-decomposition keep the compiler's choice: capped at 96 VGPRs the
 // latter spills 536 bytes and its covariance pass takes 5.8 instead of 3.5 ms)
-#define HGS_KNN_OCCUPANCY __attribute__((amdgpu_waves_per_eu((KMAX <= 20 && !REG_GENERAL) ? HGS_KNN_WAVES : 1)))
+#define HGS_KNN_OCCUPANCY __attribute__((amdgpu_waves_per_eu((KMAX <= 20 && REG != 1) ? HGS_KNN_WAVES : 1)))
 // The block-per-problem control kernels (k_gicp_solve: 4 waves, k_gicp_decide: 1 wave) run next to the other lanes' point kernels.  Compiled freely they
 // take 108 / 118 VGPRs: a wave of theirs then fits a SIMD only after TWO of k_gicp_linearize's 72-VGPR waves have left it (7 x 72 = 504 of 512 are
 // taken), and the 30 k-block launch refills every hole with its own next block first — round 4's lanes profile shows k_gicp_solve at 40.7 us on
@@ -244,17 +244,22 @@ __device__ __forceinline__ void meta_reset(CloudMeta* m) {
   for (int d = 0; d < 3; d++) m->bbmin[d] = 0xffffffffu, m->bbmax[d] = 0u;
 }
 // `staged`: the points as the host packed them on their way up (hgs_engine.hip, upload_points_packed): 16-byte records {x, y, z, intensity}
-__global__ __launch_bounds__(kBlock) void k_pack_aos(const float4* __restrict__ staged, int n, float4* __restrict__ raw, float* __restrict__ intensity, CloudMeta* meta) {
+// (round 6) ... and writes the cloud's RESIDENT descriptor (`desc_out`, inside the cloud's own block): the single-cloud launches of a registration read
+// it from there instead of from a descriptor array that a copy kernel has to fill in front of every stage (6 of the ~14 copies of an odometry sweep)
+__global__ __launch_bounds__(kBlock) void k_pack_aos(const float4* __restrict__ staged, int n, float4* __restrict__ raw, float* __restrict__ intensity, CloudMeta* meta,
+                                                     CloudDesc desc, CloudDesc* desc_out) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (meta && i == 0) meta_reset(meta);
+  if (desc_out && i == 0) *desc_out = desc;
   if (i >= n) return;
   const float4 p = staged[i];
   raw[i] = make_float4(p.x, p.y, p.z, __int_as_float(i));
   if (intensity) intensity[i] = p.w;
 }
-void launch_pack_aos(hipStream_t s, const float4* staged, int n, float4* raw, float* intensity, CloudMeta* meta) {
+void launch_pack_aos(hipStream_t s, const float4* staged, int n, float4* raw, float* intensity, CloudMeta* meta, const CloudDesc* desc, CloudDesc* desc_out) {
   if (n <= 0 && !meta) return;
-  hipLaunchKernelGGL(k_pack_aos, dim3(std::max(1, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, staged, n, raw, intensity, meta);
+  hipLaunchKernelGGL(k_pack_aos, dim3(std::max(1, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, staged, n, raw, intensity, meta, desc ? *desc : CloudDesc{},
+                     desc ? desc_out : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ search index
@@ -469,8 +474,14 @@ void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 // point), a separate instantiation so that the default kernel carries none of it.
 // GATHER: how pass 2 finds a lane's neighbours again — 0: a second tree walk bounded by r2; 1: replay of the leaves pass 1 visited (all
 // lanes over the union); 2: per-lane leaf lists (every lane over the leaves that gave IT a candidate; own leaves in lock-step).
-template <int KMAX, bool REG_GENERAL, int GATHER>
-__global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const CloudDesc* descs, int k, int qpw, int reg_method) {
+// (Round 6 measured a mode 3 — the same lists, fp64 sums neighbour by neighbour from per-leaf bit masks instead of leaf by leaf with predicated adds,
+// bit-identical sums — at 3.41 vs 3.43 ms per 65-cloud pass: pass 2 is not where this kernel's time is.  Removed; profiles/r06_ab_gather_seed.log.)
+// REG: 0 = FROBENIUS inline (the mode hdl_graph_slam runs by SURVEY A.2); 1 = any hgs_regularization inline (3x3 eigen-decomposition per point: the
+// compiler then needs > 96 VGPRs for the whole kernel); 2 = the neighbourhood covariance staged in fp64 (`raw`, 48 bytes per point) for
+// k_cov_regularize — the search keeps FROBENIUS's register budget and occupancy, the eigen-decompositions run in a streaming kernel of their own.
+template <int KMAX, int REG, int GATHER>
+__global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const CloudDesc* descs, int k, int qpw, int reg_method, double* __restrict__ raw, int raw_stride) {
+  constexpr bool REG_GENERAL = REG == 1;
   constexpr bool REPLAY = GATHER == 1, LISTS = GATHER == 2;
   const CloudDesc d = descs[blockIdx.y];
   const int n = d.meta->nvalid;
@@ -611,45 +622,69 @@ __global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const Clou
     s2 = Sym3{L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
   }
   if (!active) return;
+  if (REG == 2) {  // staged: k_cov_regularize finishes the point
+    const Sym3 c = gicp_neighbour_cov(s1, s2, found, k, 0.0);
+    double* o = raw + ((size_t)blockIdx.y * (size_t)raw_stride + (size_t)i) * 6;
+    o[0] = c.xx, o[1] = c.xy, o[2] = c.xz, o[3] = c.yy, o[4] = c.yz, o[5] = c.zz;
+    return;
+  }
   const Sym3 c = REG_GENERAL ? gicp_regularized_cov(s1, s2, found, k, reg_method) : gicp_regularized_cov(s1, s2, found, k);
   d.cov[2 * i] = make_float4((float)c.xx, (float)c.xy, (float)c.xz, (float)c.yy);
   d.cov[2 * i + 1] = make_float4((float)c.yz, (float)c.zz, 0.f, 0.f);
 }
-template <bool REG_GENERAL, int REPLAY>
-static void launch_knn_cov_t(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method) {
+// The regularisation of the staged covariances (REG == 2): 48 bytes in, 24 out per point, one point per thread, nothing else live — the 3x3 Jacobi
+// eigen-decomposition that cost k_knn_cov<.., 1, ..> its 5-waves-per-SIMD register budget for the WHOLE search runs here at full occupancy.
+__global__ __launch_bounds__(kBlock) void k_cov_regularize(const CloudDesc* descs, const double* __restrict__ raw, int raw_stride, int reg_method) {
+  const CloudDesc d = descs[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= d.meta->nvalid) return;
+  const double* r = raw + ((size_t)blockIdx.y * (size_t)raw_stride + (size_t)i) * 6;
+  const Sym3 c = gicp_regularize_cov(Sym3{r[0], r[1], r[2], r[3], r[4], r[5]}, reg_method);
+  d.cov[2 * i] = make_float4((float)c.xx, (float)c.xy, (float)c.xz, (float)c.yy);
+  d.cov[2 * i + 1] = make_float4((float)c.yz, (float)c.zz, 0.f, 0.f);
+}
+template <int REG, int REPLAY>
+static void launch_knn_cov_t(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, double* raw, int raw_stride) {
   const int tile_pts = (kBlock / 64) * qpw;
   const dim3 grid(HGS_GRID_X((max_n + tile_pts - 1) / tile_pts), ncloud), block(kBlock);
-  if (k <= 8) hipLaunchKernelGGL((k_knn_cov<8, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
-  else if (k <= 16) hipLaunchKernelGGL((k_knn_cov<16, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
-  else if (k <= 20) hipLaunchKernelGGL((k_knn_cov<20, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
-  else if (k <= 32) hipLaunchKernelGGL((k_knn_cov<32, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method);
-  else hipLaunchKernelGGL((k_knn_cov<64, REG_GENERAL, REPLAY>), grid, block, 0, s, descs, k < 64 ? k : 64, qpw, reg_method);
+  if (k <= 8) hipLaunchKernelGGL((k_knn_cov<8, REG, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method, raw, raw_stride);
+  else if (k <= 16) hipLaunchKernelGGL((k_knn_cov<16, REG, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method, raw, raw_stride);
+  else if (k <= 20) hipLaunchKernelGGL((k_knn_cov<20, REG, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method, raw, raw_stride);
+  else if (k <= 32) hipLaunchKernelGGL((k_knn_cov<32, REG, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method, raw, raw_stride);
+  else hipLaunchKernelGGL((k_knn_cov<64, REG, REPLAY>), grid, block, 0, s, descs, k < 64 ? k : 64, qpw, reg_method, raw, raw_stride);
+}
+template <int REG>
+static void launch_knn_cov_g(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, int gather, double* raw, int raw_stride) {
+  if (gather == 2) launch_knn_cov_t<REG, 2>(s, descs, ncloud, max_n, k, qpw, reg_method, raw, raw_stride);
+  else if (gather == 1) launch_knn_cov_t<REG, 1>(s, descs, ncloud, max_n, k, qpw, reg_method, raw, raw_stride);
+  else launch_knn_cov_t<REG, 0>(s, descs, ncloud, max_n, k, qpw, reg_method, raw, raw_stride);
 }
 // replay: the gather pass replays pass 1's leaf log instead of walking the tree again.  Measured (same-box A/B): 64 LiDAR clouds in one
 // launch 6.28 -> 6.14 ms; a single HDL-32E pair 0.33 -> 0.41 ms and a dense 1 M-point pair 1.91 -> 2.15 ms (a dense cloud's first walk
-// visits far more leaves than the gather needs) — hence two instantiations and a choice per launch (hgs_engine.hip).
-void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, int gather) {
+// visits far more leaves than the gather needs) — hence the instantiations and a choice per launch (hgs_engine.hip).
+// raw_stage (>= ncloud * max_n * 6 doubles, or null): regularisations other than FROBENIUS run as search (REG 2) + k_cov_regularize; without it inline (REG 1).
+void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, int gather, double* raw_stage) {
   if (max_n <= 0) return;
   if (reg_method == 0) {
-    if (gather == 2) launch_knn_cov_t<false, 2>(s, descs, ncloud, max_n, k, qpw, reg_method);
-    else if (gather == 1) launch_knn_cov_t<false, 1>(s, descs, ncloud, max_n, k, qpw, reg_method);
-    else launch_knn_cov_t<false, 0>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    launch_knn_cov_g<0>(s, descs, ncloud, max_n, k, qpw, reg_method, gather, nullptr, 0);
+  } else if (raw_stage) {
+    launch_knn_cov_g<2>(s, descs, ncloud, max_n, k, qpw, reg_method, gather, raw_stage, max_n);
+    hipLaunchKernelGGL(k_cov_regularize, dim3((max_n + kBlock - 1) / kBlock, ncloud), dim3(kBlock), 0, s, descs, raw_stage, max_n, reg_method);
   } else {
-    if (gather == 2) launch_knn_cov_t<true, 2>(s, descs, ncloud, max_n, k, qpw, reg_method);
-    else if (gather == 1) launch_knn_cov_t<true, 1>(s, descs, ncloud, max_n, k, qpw, reg_method);
-    else launch_knn_cov_t<true, 0>(s, descs, ncloud, max_n, k, qpw, reg_method);
+    launch_knn_cov_g<1>(s, descs, ncloud, max_n, k, qpw, reg_method, gather, nullptr, 0);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ GICP iteration
-__global__ void k_gicp_init(GicpState* states, const float* guesses, int B, Progress prog) {
+__global__ void k_gicp_init(GicpState* states, const float* guesses, int B, Progress prog, unsigned* tickets) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0) prog.dev[0] = 0, prog.dev[1] = 0;
   if (b >= B) return;
   gicp_state_init(states[b], guesses + 16 * b);
+  if (tickets) tickets[2 * b] = 0u, tickets[2 * b + 1] = 0u;  // the fused tails' per-problem tile tickets (linearize, error)
 }
-void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog) {
-  hipLaunchKernelGGL(k_gicp_init, dim3((B + 63) / 64), dim3(64), 0, s, states, guesses, B, prog);
+void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog, unsigned* tickets) {
+  hipLaunchKernelGGL(k_gicp_init, dim3((B + 63) / 64), dim3(64), 0, s, states, guesses, B, prog, tickets);
 }
 
 __device__ __forceinline__ Sym3 load_cov(const float4* cov, int i) {
@@ -684,6 +719,77 @@ __device__ __forceinline__ void last_wave_stores(const double* lds /* [4 * N] */
 // Exact 1-NN of one packet of queries for the kernels below: the quad walk (hgs_wave_bvh.h), nearest-first only when some lane
 // has no seed; position and original index resolved from the lane's best leaf, or — when some lane reached its minimum in two
 // leaves — by the exact keyed walk.  pos < 0: no target point within bound2.
+// ---- seed grid (round 6) -------------------------------------------------------------------------------------------------------
+// What makes a 1-NN packet cheap is a per-lane starting bound close to the answer: a packet seeded with the previous correspondences walks ~2.2x
+// fewer steps than an unseeded one (k_fitness 0.68 vs 1.48 ms on the 64 x 119 k batch).  getFitnessScore queries that have no correspondences —
+// behind NDT / VGICP, calc_fitness_score — get a bound from a grid over the TARGET: three direct-mapped tables (cells of 0.25 / 1 / 4 m) whose
+// entry is the sorted position of SOME target point that hashed there (atomicMin: deterministic).  A lookup reads the three entries of the query's
+// cells and keeps the nearest of the (up to) three points.  Nothing about it needs to be exact — any target point is a valid upper bound of the
+// nearest-neighbour distance, a hash collision only loosens it — and the search result does not depend on the seed (the walk is exact for every
+// bound).  2.6 MB per 119 k-point target, built once per target index (~10 us), shared by all candidates of a batch.  Measured (round 6,
+// profiles/r06_ab_seed_grid.log): NDT batch k_fitness 1.52 -> 1.13 ms.  NOT used by k_gicp_linearize: the first linearisation of a registration is
+// slow because its true nearest-neighbour distances are large (the guess is off by decimetres), not because it lacks a bound — with grid seeds
+// the stage measured 6.40 instead of 6.33 ms.
+#ifndef HGS_SEED_INV0
+#define HGS_SEED_INV0 4.0f  // finest cell: 0.25 m
+#endif
+constexpr float kSeedInv0 = HGS_SEED_INV0;
+__device__ __forceinline__ unsigned seed_hash(int cx, int cy, int cz) {
+  unsigned h = (unsigned)cx * 73856093u ^ (unsigned)cy * 19349663u ^ (unsigned)cz * 83492791u;
+  h ^= h >> 15;
+  h *= 0x2c1b3c6du;
+  h ^= h >> 12;
+  return h;
+}
+__device__ __forceinline__ void seed_cells(float x, float y, float z, int& cx, int& cy, int& cz) {
+  cx = (int)floorf(fminf(fmaxf(x * kSeedInv0, -1.0e9f), 1.0e9f));  // NaN -> -1e9 (fmaxf drops it): any cell will do
+  cy = (int)floorf(fminf(fmaxf(y * kSeedInv0, -1.0e9f), 1.0e9f));
+  cz = (int)floorf(fminf(fmaxf(z * kSeedInv0, -1.0e9f), 1.0e9f));
+}
+__device__ __forceinline__ void seed_slots(int cx, int cy, int cz, int bits, unsigned& s0, unsigned& s1, unsigned& s2) {
+  const unsigned n0 = 1u << bits, n1 = n0 >> 2, n2 = n0 >> 4;
+  s0 = seed_hash(cx, cy, cz) & (n0 - 1u);
+  s1 = n0 + (seed_hash(cx >> 2, cy >> 2, cz >> 2) & (n1 - 1u));  // (arithmetic shifts: floor division, the same cell for negative coordinates)
+  s2 = n0 + n1 + (seed_hash(cx >> 4, cy >> 4, cz >> 4) & (n2 - 1u));
+}
+__global__ __launch_bounds__(kBlock) void k_seed_grid_build(const float4* __restrict__ pts, const CloudMeta* meta, unsigned* __restrict__ tab, int bits) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= meta->nvalid) return;
+  const float4 p = pts[i];
+  int cx, cy, cz;
+  seed_cells(p.x, p.y, p.z, cx, cy, cz);
+  unsigned s0, s1, s2;
+  seed_slots(cx, cy, cz, bits, s0, s1, s2);
+  atomicMin(tab + s0, (unsigned)i);
+  atomicMin(tab + s1, (unsigned)i);
+  atomicMin(tab + s2, (unsigned)i);
+}
+void launch_seed_grid_build(hipStream_t s, const float4* pts, const CloudMeta* meta, int n_max, unsigned* tab, int bits) {
+  if (n_max <= 0) return;
+  hipLaunchKernelGGL(k_seed_grid_build, dim3((n_max + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, meta, tab, bits);
+}
+// the nearest of the (up to three) target points the grid holds for q's cells, or -1
+__device__ __forceinline__ int seed_grid_lookup(const TargetView& t, const F3& q) {
+  int cx, cy, cz;
+  seed_cells(q.x, q.y, q.z, cx, cy, cz);
+  unsigned s0, s1, s2;
+  seed_slots(cx, cy, cz, t.seed_bits, s0, s1, s2);
+  const unsigned e0 = t.seed_tab[s0], e1 = t.seed_tab[s1], e2 = t.seed_tab[s2];
+  const unsigned n = (unsigned)t.meta->nvalid;
+  int best = -1;
+  float best_d = FLT_MAX;
+  const unsigned e[3] = {e0, e1, e2};
+#pragma unroll
+  for (int l = 0; l < 3; l++) {
+    if (e[l] < n) {
+      const float4 p = t.pts[e[l]];
+      const float d = dist2f(q, p.x, p.y, p.z);
+      if (d < best_d) best_d = d, best = (int)e[l];
+    }
+  }
+  return best;
+}
+
 __device__ __forceinline__ void packet_nn1(const BvhView& tv, float* park, const F3& q, bool active, float bound2, int seed, int qpw, float& d2, int& pos, int& orig) {
   const bool seeded = seed >= 0 && seed < tv.n;
   int leaf;
@@ -703,11 +809,30 @@ __device__ __forceinline__ void packet_nn1(const BvhView& tv, float* park, const
   }
 }
 
+// Fused tails (round 6, launches of <= kFusedTailMaxProblems problems: a single registration is a chain of ~4 us kernels in which the two per-problem
+// control launches of an LM round cost as much as its two point kernels): every block of a problem that has written its tile partial takes a ticket; the
+// block that takes the LAST one runs the control step in its tail.  Release: the partial is written, then a device-scope fence, then the ticket; acquire:
+// the ticket (acq_rel, device scope) before any partial is read.  Returns true in every thread of the last block; the ticket is reset for the next round.
+__device__ __forceinline__ void gicp_solve_block(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials);
+__device__ __forceinline__ bool gicp_decide_wave(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials_err);
+__device__ __forceinline__ bool last_block_of_problem(unsigned* ticket, int ntiles) {
+  __shared__ unsigned last;
+  __syncthreads();  // every wave of this block has stored what it owes (and, FUSED, fenced it)
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = t + 1u == (unsigned)ntiles ? 1u : 0u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return last != 0u;
+}
+
 // update_correspondences + linearize fused: per source point 1-NN in the target tree, Mahalanobis matrix,
 // 6x6 normal-equation terms; wave shuffle reduction, one LDS row per wave, the last wave of the block adds the rows.
 // Algorithmic bytes per source point: 16 (a_i) + 24 (C_A) + 4 (corr) + 16 (b_j) + 24 (C_B) = 84.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINEARIZE_WAVES))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
-                                                           double* __restrict__ partials, int max_blocks, int qpw) {
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FUSED ? 4 : HGS_LINEARIZE_WAVES))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, GicpState* states, GicpConsts c,
+                                                           double* __restrict__ partials, int max_blocks, int qpw, unsigned* tickets) {
   const int b = blockIdx.y;
   if (states[b].phase != GICP_LINEARIZE) return;
   const CloudDesc d = descs[b];
@@ -715,6 +840,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINE
   const int tile_pts = (kBlock / 64) * qpw * kNW;
   const int ntiles = (n + tile_pts - 1) / tile_pts;
   const int tile = xcd_tile(blockIdx.x, ntiles);
+  if constexpr (FUSED) {
+    if (ntiles == 0) {  // an empty source: no tile takes a ticket — block 0 runs the control step on zero partials (what k_gicp_solve does)
+      if (blockIdx.x == 0) gicp_solve_block(0, states + b, c, partials + (size_t)b * max_blocks * kAcc);
+      return;
+    }
+  }
   if (tile >= ntiles) return;
   __shared__ double lds[4 * kAcc];
   __shared__ unsigned arrivals;
@@ -770,30 +901,40 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINE
   }
   wave_sums28_to(even, odd, row, lane);
   last_wave_stores<kAcc>(lds, &arrivals, partials + ((size_t)b * max_blocks + tile) * kAcc, lane);
+  if constexpr (FUSED) {
+    __threadfence();  // (the wave that stored the tile partial: visible device-wide before the block's ticket)
+    if (last_block_of_problem(tickets + 2 * b, ntiles)) gicp_solve_block(ntiles, states + b, c, partials + (size_t)b * max_blocks * kAcc);
+  }
 }
-void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
-                           int max_blocks, int B, int qpw) {
-  hipLaunchKernelGGL(k_gicp_linearize, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw);
+void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, GicpState* states, GicpConsts c, double* partials,
+                           int max_blocks, int B, int qpw, unsigned* tickets) {
+  if (tickets) hipLaunchKernelGGL(k_gicp_linearize<true>, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw, tickets);
+  else hipLaunchKernelGGL(k_gicp_linearize<false>, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw, tickets);
 }
 
+// The LM control step behind a linearisation, run by a whole 256-thread block: fixed-order tile reduction, then ONE lane factorises and steps.  The
+// control step is a chain of dependent loads and stores on the problem's state and on the factorisation's pivoted arrays: both live in LDS for its
+// duration (state copied in and out by the block; round 3 ran it on HBM + 592 bytes of scratch).  Shared by k_gicp_solve and the fused tail of
+// k_gicp_linearize<true>: the same code on the same partials in the same order — bitwise the same state.
+__device__ __forceinline__ void gicp_solve_block(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials) {
+  __shared__ double acc[kAcc];
+  __shared__ double scratch[kSolveBlock];
+  __shared__ GicpState st;
+  __shared__ double ws[kGicpControlWorkspace];
+  static_assert(sizeof(GicpState) % sizeof(double) == 0 && sizeof(GicpState) / sizeof(double) <= kSolveBlock, "state copied one double per thread");
+  if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(&st)[threadIdx.x] = reinterpret_cast<const double*>(state)[threadIdx.x];
+  reduce_tiles<kAcc>(problem_partials, ntiles, acc, scratch);  // (ends with a barrier: the state copy is complete)
+  if (threadIdx.x == 0) gicp_after_linearize(st, acc, c, ws);
+  __syncthreads();
+  if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(state)[threadIdx.x] = reinterpret_cast<const double*>(&st)[threadIdx.x];
+}
 __global__ __launch_bounds__(kSolveBlock) __attribute__((amdgpu_waves_per_eu(HGS_CONTROL_WAVES))) void k_gicp_solve(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials,
                                                       int max_blocks, int tile_points) {
   const int b = blockIdx.x;
   if (states[b].phase != GICP_LINEARIZE) return;
   if (HGS_CONTROL_PRIO) __builtin_amdgcn_s_setprio(HGS_CONTROL_PRIO);
-  __shared__ double acc[kAcc];
-  __shared__ double scratch[kSolveBlock];
-  // the control step runs on ONE lane and is a chain of dependent loads and stores on the problem's state and on the factorisation's
-  // pivoted arrays: both live in LDS for its duration (state copied in and out by the block; round 3 ran it on HBM + 592 bytes of scratch)
-  __shared__ GicpState st;
-  __shared__ double ws[kGicpControlWorkspace];
-  static_assert(sizeof(GicpState) % sizeof(double) == 0 && sizeof(GicpState) / sizeof(double) <= kSolveBlock, "state copied one double per thread");
-  if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(&st)[threadIdx.x] = reinterpret_cast<const double*>(&states[b])[threadIdx.x];
   const int ntiles = (descs[b].meta->nvalid + tile_points - 1) / tile_points;  // tiles of the linearize kernel that filled `partials`
-  reduce_tiles<kAcc>(partials + (size_t)b * max_blocks * kAcc, ntiles, acc, scratch);  // (ends with a barrier: the state copy is complete)
-  if (threadIdx.x == 0) gicp_after_linearize(st, acc, c, ws);
-  __syncthreads();
-  if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(&states[b])[threadIdx.x] = reinterpret_cast<const double*>(&st)[threadIdx.x];
+  gicp_solve_block(ntiles, states + b, c, partials + (size_t)b * max_blocks * kAcc);
 }
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
                        int tile_points) {
@@ -801,13 +942,27 @@ void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states,
 }
 
 // compute_error(xi): same correspondences, Mahalanobis matrices of the linearisation pose x0, residuals at xi.
-__global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, TargetView tgt, const GicpState* states, double* __restrict__ partials_err,
-                                                       int max_blocks) {
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, TargetView tgt, GicpState* states, double* __restrict__ partials_err,
+                                                       int max_blocks, GicpConsts c, unsigned* tickets, Progress prog) {
   const int b = blockIdx.y;
-  if (states[b].phase != GICP_TRY) return;
+  if (states[b].phase != GICP_TRY) {
+    // FUSED: the round's tick of a problem that has nothing to decide (k_gicp_decide ticks once per problem per round whatever its phase)
+    if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) progress_tick(prog, false);
+    return;
+  }
   const CloudDesc d = descs[b];
   const int n = d.meta->nvalid;
   const int ntiles = (n + kBlock - 1) / kBlock;
+  if constexpr (FUSED) {
+    if (ntiles == 0) {
+      if (blockIdx.x == 0) {
+        const bool finished_now = gicp_decide_wave(0, states + b, c, partials_err + (size_t)b * max_blocks);
+        if (threadIdx.x == 0) progress_tick(prog, finished_now);
+      }
+      return;
+    }
+  }
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = (int)blockIdx.x;
   const int i = tile * kBlock + threadIdx.x;
@@ -825,31 +980,50 @@ __global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, T
     }
   }
   block_reduce_store<1>(&err, partials_err + (size_t)b * max_blocks + tile, lds);
+  if constexpr (FUSED) {
+    __threadfence();
+    if (last_block_of_problem(tickets + 2 * b + 1, ntiles)) {
+      const bool finished_now = gicp_decide_wave(ntiles, states + b, c, partials_err + (size_t)b * max_blocks);
+      if (threadIdx.x == 0) progress_tick(prog, finished_now);
+    }
+  }
 }
-void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B) {
-  hipLaunchKernelGGL(k_gicp_error, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks);
+void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, GicpState* states, double* partials_err, int max_blocks, int B, const GicpConsts* fused_c,
+                       unsigned* tickets, Progress prog) {
+  if (tickets) hipLaunchKernelGGL(k_gicp_error<true>, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks, *fused_c, tickets, prog);
+  else hipLaunchKernelGGL(k_gicp_error<false>, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks, GicpConsts{}, tickets, prog);
 }
 
+// The LM accept / reject step behind compute_error, run by ONE wave (the first 64 threads of the calling block; the others only pass the barriers):
+// shared by k_gicp_decide and the fused tail of k_gicp_error<true>.  Returns (to thread 0) whether the problem finished with this step.
+__device__ __forceinline__ bool gicp_decide_wave(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials_err) {
+  __shared__ GicpState st;  // as in gicp_solve_block: the one-lane control step works on LDS
+  __shared__ double ws[kGicpControlWorkspace];
+  bool finished_now = false;
+  double s = 0;
+  if (threadIdx.x < 64) {
+    for (int k = threadIdx.x; k < (int)(sizeof(GicpState) / sizeof(double)); k += 64) reinterpret_cast<double*>(&st)[k] = reinterpret_cast<const double*>(state)[k];
+    for (int t = threadIdx.x; t < ntiles; t += 64) s += problem_partials_err[t];
+    s = wave_sum(s);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gicp_after_error(st, s, c, ws);
+    finished_now = st.phase == GICP_DONE;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64)
+    for (int k = threadIdx.x; k < (int)(sizeof(GicpState) / sizeof(double)); k += 64) reinterpret_cast<double*>(state)[k] = reinterpret_cast<const double*>(&st)[k];
+  return finished_now;
+}
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_CONTROL_WAVES))) void k_gicp_decide(const CloudDesc* descs, GicpState* states, GicpConsts c, const double* __restrict__ partials_err,
                                                    int max_blocks, Progress prog) {
   const int b = blockIdx.x;
   bool finished_now = false;
   if (HGS_CONTROL_PRIO) __builtin_amdgcn_s_setprio(HGS_CONTROL_PRIO);
   if (states[b].phase == GICP_TRY) {  // (block-uniform)
-    __shared__ GicpState st;  // as in k_gicp_solve: the one-lane control step works on LDS
-    __shared__ double ws[kGicpControlWorkspace];
-    for (int k = threadIdx.x; k < (int)(sizeof(GicpState) / sizeof(double)); k += 64) reinterpret_cast<double*>(&st)[k] = reinterpret_cast<const double*>(&states[b])[k];
     const int ntiles = (descs[b].meta->nvalid + kBlock - 1) / kBlock;
-    double s = 0;
-    for (int t = threadIdx.x; t < ntiles; t += 64) s += partials_err[(size_t)b * max_blocks + t];
-    s = wave_sum(s);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      gicp_after_error(st, s, c, ws);
-      finished_now = st.phase == GICP_DONE;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < (int)(sizeof(GicpState) / sizeof(double)); k += 64) reinterpret_cast<double*>(&states[b])[k] = reinterpret_cast<const double*>(&st)[k];
+    finished_now = gicp_decide_wave(ntiles, states + b, c, partials_err + (size_t)b * max_blocks);
     // (the tick below only tells the host how far the batch is; states[] is read by later kernels of this stream, after this one has ended)
   }
   if (threadIdx.x == 0) progress_tick(prog, finished_now);
@@ -903,8 +1077,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_FITN
   const float4 a = active ? load_stream(d.pts + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
   const F3 q = transform_point_f(Tf, a.x, a.y, a.z);
   // use_seed: corr[] holds this cloud's last GICP correspondences against this target — a tight starting bound
-  const int seed = (active && use_seed) ? __builtin_nontemporal_load(d.corr + idx) : -1;
+  int seed = (active && use_seed) ? __builtin_nontemporal_load(d.corr + idx) : -1;
   const BvhView tv = view_of(tgt);
+  if (tgt.seed_bits && __ballot(active && !(seed >= 0 && seed < tv.n)) != 0ull) {  // NDT / VGICP / calc_fitness_score: no correspondences -> the seed grid
+    if (active && !(seed >= 0 && seed < tv.n)) seed = seed_grid_lookup(tgt, q);
+  }
   const bool seeded = seed >= 0 && seed < tv.n;
   float d2;
   int leaf;
@@ -1752,18 +1929,25 @@ void launch_vgicp_error(hipStream_t s, const CloudDesc* descs, NdtTargetView tgt
 // of the NDT / VGICP targets with FLOAT centroids accumulated in input order (CentroidPoint semantics).
 // deskew != 0: the deskewing step of cloud_callback (:112, :182-243) on the way in — point i of the sweep rotated back by the
 // first-order rotation of delta_t = scan_period * i / n at the gyro rate w (pf_deskew_point, hgs_math.h).
-__global__ __launch_bounds__(kBlock) void k_pf_load(const float4* __restrict__ staged, int n, float4* __restrict__ out, int deskew, float wx, float wy, float wz, double scan_period) {
+// (round 6) thread 0 also sets the pipeline's point count and the initial voxel-grid record {bbox min = max uint, bbox max = 0, ...} — two copy
+// kernels less per sweep
+__global__ __launch_bounds__(kBlock) void k_pf_load(const float4* __restrict__ staged, int n, float4* __restrict__ out, int deskew, float wx, float wy, float wz, double scan_period,
+                                                    int* __restrict__ count_out, unsigned* __restrict__ meta_out) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) {
+    *count_out = n;
+#pragma unroll
+    for (int k = 0; k < 16; k++) meta_out[k] = k < 3 ? 0xffffffffu : 0u;
+  }
   if (i >= n) return;
   const float4 p = staged[i];  // {x, y, z, intensity}, packed by the host (upload_points_packed)
   float x = p.x, y = p.y, z = p.z;
   if (deskew) pf_deskew_point(wx, wy, wz, scan_period, i, n, &x, &y, &z);
   out[i] = make_float4(x, y, z, p.w);
 }
-void launch_pf_load(hipStream_t s, const float4* staged, int n, float4* out, const float* deskew_w, double scan_period) {
-  if (n > 0)
-    hipLaunchKernelGGL(k_pf_load, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, staged, n, out, deskew_w ? 1 : 0, deskew_w ? deskew_w[0] : 0.f,
-                       deskew_w ? deskew_w[1] : 0.f, deskew_w ? deskew_w[2] : 0.f, scan_period);
+void launch_pf_load(hipStream_t s, const float4* staged, int n, float4* out, const float* deskew_w, double scan_period, int* count_out, unsigned* meta_out) {
+  hipLaunchKernelGGL(k_pf_load, dim3(std::max(1, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, staged, n, out, deskew_w ? 1 : 0, deskew_w ? deskew_w[0] : 0.f,
+                     deskew_w ? deskew_w[1] : 0.f, deskew_w ? deskew_w[2] : 0.f, scan_period, count_out, meta_out);
 }
 
 // keep[i] = near < |p| < far  (float norm against double thresholds, :170-173); use_filter == 0 keeps everything
@@ -2242,16 +2426,19 @@ void launch_map_centers(hipStream_t s, const unsigned long long* keys, const uns
 }
 
 // pack a resident float4 {x,y,z,intensity} array into a cloud: raw = {x,y,z,index}, intensity kept beside it
-__global__ __launch_bounds__(kBlock) void k_pf_to_cloud(const float4* __restrict__ in, int n, float4* __restrict__ raw, float* __restrict__ intensity, CloudMeta* meta) {
+__global__ __launch_bounds__(kBlock) void k_pf_to_cloud(const float4* __restrict__ in, int n, float4* __restrict__ raw, float* __restrict__ intensity, CloudMeta* meta,
+                                                        CloudDesc desc, CloudDesc* desc_out) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i == 0) meta_reset(meta);
+  if (desc_out && i == 0) *desc_out = desc;
   if (i >= n) return;
   const float4 p = in[i];
   raw[i] = make_float4(p.x, p.y, p.z, __int_as_float(i));
   intensity[i] = p.w;
 }
-void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity, CloudMeta* meta) {
-  hipLaunchKernelGGL(k_pf_to_cloud, dim3(std::max(1, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, in, n, raw, intensity, meta);
+void launch_pf_to_cloud(hipStream_t s, const float4* in, int n, float4* raw, float* intensity, CloudMeta* meta, const CloudDesc* desc, CloudDesc* desc_out) {
+  hipLaunchKernelGGL(k_pf_to_cloud, dim3(std::max(1, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, in, n, raw, intensity, meta, desc ? *desc : CloudDesc{},
+                     desc ? desc_out : nullptr);
 }
 
 }  // namespace hgs

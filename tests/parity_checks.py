@@ -76,18 +76,46 @@ def check_covariances_both_gathers(make_engine):
     clouds = [synth.scan(scene, "VLP-16", synth.pose_matrix([0, 0, 0], [0, 0, 0]), 31), tie_heavy_cloud(), outlier_cloud()]
     old = os.environ.get("HGS_KNN_REPLAY")
     try:
+        per_mode = {}
         for replay in ("0", "1", "2"):
             os.environ["HGS_KNN_REPLAY"] = replay          # read in hgs_create
-            for cloud in clouds:
+            for ci, cloud in enumerate(clouds):
                 e = make_engine(O.default_params(O.HGS_FAST_GICP))
                 e.setInputTarget(cloud)
                 check_covariances(e, cloud, 20)
+                per_mode[(replay, ci)] = e.target_covariances(len(cloud)).copy()
                 e.close()
     finally:
         if old is None:
             os.environ.pop("HGS_KNN_REPLAY", None)
         else:
             os.environ["HGS_KNN_REPLAY"] = old
+
+
+def check_cov_split_equals_inline(make_engine):
+    """Non-FROBENIUS regularisations: the search kernel staging fp64 covariances + k_cov_regularize (default) against the single kernel with the
+    eigen-decomposition inline (HGS_COV_SPLIT=0): the same arithmetic on the same fp64 values, identical bits."""
+    import os
+    scene = synth.make_scene(3)
+    cloud = synth.scan(scene, "VLP-16", synth.pose_matrix([0, 0, 0], [0, 0, 0]), 31)
+    old = os.environ.get("HGS_COV_SPLIT")
+    try:
+        for method in (O.HGS_REG_PLANE, O.HGS_REG_MIN_EIG, O.HGS_REG_NONE):
+            got = {}
+            for split in ("0", "1"):
+                os.environ["HGS_COV_SPLIT"] = split          # read in hgs_create
+                p = O.default_params(O.HGS_FAST_GICP)
+                p.regularization_method = method
+                e = make_engine(p)
+                e.setInputTarget(cloud)
+                got[split] = e.target_covariances(len(cloud)).copy()
+                e.close()
+            assert np.array_equal(got["0"], got["1"]), method
+    finally:
+        if old is None:
+            os.environ.pop("HGS_COV_SPLIT", None)
+        else:
+            os.environ["HGS_COV_SPLIT"] = old
 
 
 def check_covariances_with_outliers(make_engine):

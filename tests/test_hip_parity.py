@@ -73,6 +73,11 @@ def test_covariances_with_both_gather_passes():
     PC.check_covariances_both_gathers(_hip)
 
 
+@pytest.mark.gpu
+def test_split_regularisation_kernel_equals_the_inline_one():
+    PC.check_cov_split_equals_inline(_hip)
+
+
 def test_covariances_when_the_leaf_log_overflows():
     """k_knn_cov with lanes whose k-NN ball covers hundreds of leaves: the gather pass falls back from the logged leaves to the tree."""
     PC.check_covariances_with_outliers(_hip)

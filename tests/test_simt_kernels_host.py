@@ -89,6 +89,10 @@ def test_covariances_with_both_gather_passes():
     PC.check_covariances_both_gathers(_engine)
 
 
+def test_split_regularisation_kernel_equals_the_inline_one():
+    PC.check_cov_split_equals_inline(_engine)
+
+
 def test_covariances_when_the_leaf_log_overflows():
     PC.check_covariances_with_outliers(_engine)
 
