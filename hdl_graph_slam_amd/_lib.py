@@ -78,7 +78,7 @@ EXPORTS = [
     "hgs_comm_get_unique_id", "hgs_comm_init", "hgs_comm_finalize", "hgs_loop_match_batch_sharded",
     "hgs_prefilter_params_default", "hgs_prefilter", "hgs_prefilter_deskewed", "hgs_cloud_download", "hgs_map_cloud_generate",
     "hgs_profile_enable", "hgs_profile_read", "hgs_synchronize",
-    "hgs_debug_target_covariances", "hgs_debug_gicp_linearize", "hgs_debug_ndt_cells", "hgs_debug_ndt_derivatives", "hgs_debug_merge_shard_records",
+    "hgs_debug_target_covariances", "hgs_debug_gicp_linearize", "hgs_debug_ndt_cells", "hgs_debug_ndt_derivatives", "hgs_debug_merge_shard_records", "hgs_debug_set_option",
 ]
 
 _lib = None
@@ -129,6 +129,7 @@ def lib():
     L.hgs_profile_read.argtypes = [vp, vp, vp, C.c_int]
     L.hgs_synchronize.argtypes = [vp]
     L.hgs_debug_target_covariances.argtypes = [vp, vp]
+    L.hgs_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int32]
     L.hgs_debug_gicp_linearize.argtypes = [vp, vp, vp, vp, vp, vp]
     L.hgs_debug_ndt_cells.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.POINTER(C.c_int32)]
     L.hgs_debug_ndt_derivatives.argtypes = [vp, vp, vp, vp, vp]

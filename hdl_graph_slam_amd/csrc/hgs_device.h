@@ -86,7 +86,6 @@ struct Progress {
   int pad;
 };
 
-constexpr int kFusedTailMaxProblems = 4;  // launches of at most this many problems run the LM control steps in the tails of k_gicp_linearize / k_gicp_error
 constexpr int kBlock = 256;
 constexpr int kKnnLaneList = 16;          // leaves a lane of k_knn_cov remembers as its own candidates' (more: the wave falls back to the replay / walk)
 constexpr int kKnnLeafLog = 128;           // leaves pass 1 of k_knn_cov remembers per wave for pass 2 (more: pass 2 walks the tree)
@@ -104,13 +103,12 @@ void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, int gather /* 0 walk, 1 leaf-log replay, 2 per-lane lists */,
                     double* raw_stage = nullptr /* ncloud * max_n * 6 doubles: non-FROBENIUS regularisations run as search + k_cov_regularize */);
 
-void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog, unsigned* tickets = nullptr /* [2 * B]: the fused tails' tile tickets */);
-void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, GicpState* states, GicpConsts c, double* partials, int max_blocks, int B,
-                           int qpw, unsigned* tickets = nullptr /* non-null: k_gicp_linearize<true> — the LM solve runs in the tail of the problem's last block */);
+void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog);
+void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B,
+                           int qpw);
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
                        int tile_points /* points per block of the linearize kernel that filled `partials` */);
-void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, GicpState* states, double* partials_err, int max_blocks, int B,
-                       const GicpConsts* fused_c = nullptr, unsigned* tickets = nullptr /* non-null: k_gicp_error<true> — accept / reject + progress tick in the tail */, Progress prog = Progress{});
+void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B);
 void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B, Progress prog);
 void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out, int B);
 
@@ -188,14 +186,17 @@ void launch_pf_load(hipStream_t s, const float4* staged, int n, float4* out, con
                     unsigned* meta_out /* [16]: the voxel-grid record, initialised here */);
 void launch_pf_distance_flags(hipStream_t s, const float4* pts, int n, int use_filter, double near_thresh, double far_thresh, unsigned* keep);
 void launch_pf_compact(hipStream_t s, const float4* in, int n, const unsigned* keep, const unsigned* slot, float4* out, int* count);
-void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta);
+void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta, int dist_filter = 0, double near_thresh = 0, double far_thresh = 0);
 void launch_pf_grid(hipStream_t s, unsigned* meta, float inv_leaf);
-void launch_pf_voxel_keys(hipStream_t s, const float4* pts, const int* count, const unsigned* meta, float inv_leaf, int cap, unsigned long long* keys, unsigned* vals);
+void launch_pf_voxel_keys(hipStream_t s, const float4* pts, const int* count, const unsigned* meta, float inv_leaf, int cap, unsigned long long* keys, unsigned* vals,
+                          int dist_filter = 0, double near_thresh = 0, double far_thresh = 0);
 void launch_pf_voxel_heads(hipStream_t s, const unsigned long long* keys, int cap, unsigned* head, unsigned long long invalid_key);
 constexpr unsigned long long kVoxelInvalidKey = 0xffffffffull;  // prefilter voxel grid: 31-bit linear indices like pcl::VoxelGrid
 constexpr unsigned long long kMapInvalidKey = ~0ull;            // map cloud: interleaved keys use at most 63 bits
-void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* slot,
-                               int cap, float4* out, int* count_out);
+void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* slot, int cap,
+                               float4* out, int* count_out, unsigned* ukeys = nullptr /* [cap]: the voxels' keys in output order */);
+void launch_pf_grid_radius_flags(hipStream_t s, const float4* cen, const int* count, const unsigned* ukeys, const unsigned* meta, float inv_leaf, float radius, float r2,
+                                 int min_neighbors, int cap, unsigned* keep);
 void launch_pf_approx_keys(hipStream_t s, const float4* pts, const int* count, float inv_leaf, int cap, unsigned long long* keys, unsigned* vals);
 void launch_pf_approx_heads(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, float inv_leaf, int cap, unsigned* head, unsigned* evict,
                             unsigned* bucket_used /* [512], zeroed */, unsigned* bucket_rank /* [513] */);

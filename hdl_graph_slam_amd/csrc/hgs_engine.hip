@@ -317,7 +317,8 @@ struct hgs_handle {
   // 8 lanes: 2440 / 665 (the HIP runtime multiplexes streams onto 4 hardware queues by default).  Round 2, 64 x 119 k-point batch:
   // 1 / 2 / 3 / 4 lanes = 3680 / 3999 / 3937 / 3913 GICP reg/s and 1064 / 1403 / 1384 / 1326 NDT — with 32 problems per lane a lane's
   // launches fill the device on their own and two chains are enough to cover each other's solves and tails.
-  int fused_tails = 1;     // launches of <= kFusedTailMaxProblems GICP problems: LM control steps in the point kernels' tails (0: four launches per round; HGS_FUSED_TAILS, A/B runs)
+  int prefilter_fast = 1;  // hgs_prefilter: distance filter inside the voxel grid's kernels, RadiusOutlierRemoval on the voxel grid (0: the separate passes + search tree; A/B, tests)
+  int upload_trace = 0;
   int cov_split = 1;       // non-FROBENIUS regularisations: search kernel + k_cov_regularize (0: one kernel with the eigen-decomposition inline; HGS_COV_SPLIT, A/B runs)
   int resident_descs = 1;  // HGS_RESIDENT_DESCS=0: every stage uploads its descriptor array (A/B runs)
   int knn_qpw_tiny = 16;  // queries per packet of k_knn_cov for launches below 32 k queries (0: 32 as for every small launch); HGS_KNN_QPW_TINY (A/B runs)
@@ -335,7 +336,7 @@ struct hgs_handle {
   DeviceBuffer ndt_accum;  // NdtAccum per problem of the running NDT batch
   hgs::Comm* comm = nullptr;            // hgs_comm_init: the ranks of a sharded loop-closure batch
   DeviceBuffer comm_send, comm_recv, comm_ids;
-  DeviceBuffer tickets;          // fused LM tails: two tile tickets per problem (k_gicp_linearize<true> / k_gicp_error<true>)
+  DeviceBuffer pf_ukeys;         // prefilter: the voxels' keys in output order (k_pf_grid_radius_flags)
   DeviceBuffer cov_raw;          // staged fp64 neighbourhood covariances between k_knn_cov<.., 2, ..> and k_cov_regularize
   DeviceBuffer ndt_plan;         // per lane: work queue head + tile prefix sums of the running NDT batch
   // blocks per k_ndt_pass launch (0: by the lane count, below); HGS_NDT_RESIDENT (A/B runs).  Two blocks per CU are resident (the round-4 kernel
@@ -1114,34 +1115,25 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       launch_gicp_results(L.stream, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
       if (fit_max_range) lane_fitness(h, L, d_descs, *fit_max_range, max_blocks, qpw, nn_tile);
     };
-    // A launch of a few problems (a single registration: the odometry step, config 2) is a chain of ~4 us kernels: the two per-problem control launches
-    // of an LM round then cost as much as its two point kernels.  Such launches run the control steps in the TAILS of the point kernels
-    // (k_gicp_linearize<true> / k_gicp_error<true>, hgs_kernels.hip): two launches per round, the same arithmetic in the same order.
-    unsigned* tickets = nullptr;
-    if (!voxel && h->fused_tails && B <= kFusedTailMaxProblems) {
-      HGS_HIP(h, h->tickets.reserve((size_t)B * 2 * sizeof(unsigned)));
-      tickets = h->tickets.as<unsigned>();
-    }
-    for (BatchLane& L : lanes) launch_gicp_init(L.stream, st + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, L.B, L.prog, tickets ? tickets + 2 * L.b0 : nullptr);
+    for (BatchLane& L : lanes) launch_gicp_init(L.stream, st + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, L.B, L.prog);
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       const CloudDesc* dd = d_descs + L.b0;
       GicpState* ls = st + L.b0;
-      unsigned* lt = tickets ? tickets + 2 * L.b0 : nullptr;
       {
         StageTimer tm(h, HGS_STAGE_LINEARIZE);
         if (voxel) launch_vgicp_linearize(L.stream, dd, vtv, ls, vc, L.partials, max_blocks, L.B);
-        else launch_gicp_linearize(L.stream, dd, tv, ls, c, L.partials, max_blocks, L.B, qpw, lt);
+        else launch_gicp_linearize(L.stream, dd, tv, ls, c, L.partials, max_blocks, L.B, qpw);
       }
-      if (!lt) {
+      {
         StageTimer tm(h, HGS_STAGE_SOLVE);
         launch_gicp_solve(L.stream, dd, ls, c, L.partials, max_blocks, L.B, voxel ? kBlock : nn_tile);
       }
       {
         StageTimer tm(h, HGS_STAGE_ERROR);
         if (voxel) launch_vgicp_error(L.stream, dd, vtv, ls, vc, L.partials_err, max_blocks, L.B);
-        else launch_gicp_error(L.stream, dd, tv, ls, L.partials_err, max_blocks, L.B, &c, lt, L.prog);
+        else launch_gicp_error(L.stream, dd, tv, ls, L.partials_err, max_blocks, L.B);
       }
-      if (!lt) {
+      {
         StageTimer tm(h, HGS_STAGE_SOLVE);
         launch_gicp_decide(L.stream, dd, ls, c, L.partials_err, max_blocks, L.B, L.prog);
       }
@@ -1324,6 +1316,37 @@ extern "C" {
 
 int hgs_abi_version(void) { return HGS_ABI_VERSION; }
 
+// Measurement / test knobs of one engine (A/B runs, tests that force a code path).  Rounds 1-5 read them from the environment in hgs_create; a plugin
+// should not — the library now reads GPU_MAX_HW_QUEUES (HIP's own variable), HGS_COMM_TIMEOUT_MS and HGS_TRACE only.  The Python harness maps
+// HGS_ENGINE_OPTIONS="key=value,..." onto this call (hdl_graph_slam_amd/registration.py); nothing in adapters/ uses it.
+int hgs_debug_set_option(hgs_handle* h, const char* key, int value) try {
+  std::unique_lock<std::recursive_mutex> api_lock__;
+  if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
+  if (!h || !key) return HGS_ERR_INVALID_ARGUMENT;
+  const std::string k(key);
+  if (k == "batch_lanes") h->batch_lanes = value <= 0 ? 0 : std::min(kMaxLanes, value);                  // 0: open_lanes chooses
+  else if (k == "lane_start") h->lane_start = value != 0 ? 1 : 0;
+  else if (k == "ndt_sort") h->ndt_sort = std::max(-1, std::min(1, value));
+  else if (k == "cov_split") h->cov_split = value != 0 ? 1 : 0;
+  else if (k == "resident_descs") h->resident_descs = value != 0 ? 1 : 0;
+  else if (k == "knn_qpw_tiny") h->knn_qpw_tiny = std::max(0, std::min(32, value & ~7));
+  else if (k == "seed_grid") h->seed_grid = value != 0 ? 1 : 0;
+  else if (k == "knn_replay") h->knn_replay = std::max(-1, std::min(2, value));                           // -1: the engine chooses
+  else if (k == "ndt_resident") h->ndt_resident_blocks = std::max(0, value);
+  else if (k == "ndt_chunk") h->ndt_chunk = std::max(0, value);
+  else if (k == "hilbert_levels") h->hilbert_levels = std::max(4, std::min(16, value));
+  else if (k == "nn_qpw") h->nn_qpw = value == 16 ? 16 : (value == 32 ? 32 : (value == 64 ? 64 : 0));
+  else if (k == "upload_trace") h->upload_trace = value != 0 ? 1 : 0;
+  else if (k == "prefilter_fast") h->prefilter_fast = value != 0 ? 1 : 0;
+  else {
+    h->err = "hgs_debug_set_option: unknown option '" + k + "'";
+    return HGS_ERR_INVALID_ARGUMENT;
+  }
+  return HGS_OK;
+} catch (...) {
+  return status_of_current_exception(h);
+}
+
 int hgs_params_default(int32_t method, hgs_params* p) try {
   if (!p || method < HGS_FAST_GICP || method > HGS_NDT_OMP) return HGS_ERR_INVALID_ARGUMENT;
   std::memset(p, 0, sizeof(*p));
@@ -1368,19 +1391,7 @@ int hgs_create(const hgs_params* p, hgs_handle** out) try {
   h->device = p->device_id;
   for (int i = 0; i < 16; i++) h->final_T[i] = (i % 5 == 0) ? 1.f : 0.f;
   for (int i = 0; i < HGS_STAGE_COUNT; i++) h->prof_ms[i] = 0, h->prof_launches[i] = 0;
-  if (const char* e = std::getenv("HGS_BATCH_LANES")) h->batch_lanes = std::max(1, std::min(kMaxLanes, std::atoi(e)));  // A/B measurements
-  if (const char* e = std::getenv("HGS_LANE_START")) h->lane_start = std::atoi(e) != 0 ? 1 : 0;
-  if (const char* e = std::getenv("HGS_NDT_SORT")) h->ndt_sort = std::max(-1, std::min(1, std::atoi(e)));
-  if (const char* e = std::getenv("HGS_FUSED_TAILS")) h->fused_tails = std::atoi(e) != 0 ? 1 : 0;
-  if (const char* e = std::getenv("HGS_COV_SPLIT")) h->cov_split = std::atoi(e) != 0 ? 1 : 0;
-  if (const char* e = std::getenv("HGS_RESIDENT_DESCS")) h->resident_descs = std::atoi(e) != 0 ? 1 : 0;
-  if (const char* e = std::getenv("HGS_KNN_QPW_TINY")) h->knn_qpw_tiny = std::max(0, std::min(32, std::atoi(e) & ~7));
-  if (const char* e = std::getenv("HGS_SEED_GRID")) h->seed_grid = std::atoi(e) != 0 ? 1 : 0;
-  if (const char* e = std::getenv("HGS_KNN_REPLAY")) h->knn_replay = std::max(0, std::min(2, std::atoi(e)));
-  if (const char* e = std::getenv("HGS_NDT_RESIDENT")) h->ndt_resident_blocks = std::max(1, std::atoi(e));
-  if (const char* e = std::getenv("HGS_NDT_CHUNK")) h->ndt_chunk = std::max(0, std::atoi(e));
-  if (const char* e = std::getenv("HGS_HILBERT_LEVELS")) h->hilbert_levels = std::max(4, std::min(16, std::atoi(e)));
-  if (const char* e = std::getenv("HGS_NN_QPW")) h->nn_qpw = std::atoi(e) == 16 ? 16 : (std::atoi(e) == 32 ? 32 : 64);  // A/B: queries per packet of the 1-NN kernels
+  // (measurement / test knobs: hgs_debug_set_option below — the library reads no tuning variable from the environment)
   if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     g_create_error = "hipSetDevice / hipStreamCreate failed";
     delete h;
@@ -1415,7 +1426,7 @@ int hgs_destroy(hgs_handle* h) try {
   h->live_clouds.clear();
   DeviceBuffer* bufs[] = {&h->staging, &h->sort_keys[0], &h->sort_keys[1], &h->sort_vals[0], &h->sort_vals[1], &h->sort_tmp, &h->descs, &h->states,
                           &h->angles,  &h->partials,     &h->partials_err, &h->results,      &h->guesses,      &h->done,     &h->misc,
-                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum,    &h->ndt_plan,     &h->cov_raw,      &h->tickets,
+                          &h->pf_a,    &h->pf_b,         &h->pf_keep,      &h->pf_slot,      &h->pf_small,     &h->pf_dist,      &h->ndt_accum,    &h->ndt_plan,     &h->cov_raw,      &h->pf_ukeys,
                           &h->comm_send, &h->comm_recv,    &h->comm_ids};
   for (DeviceBuffer* b : bufs) b->release();
   for (int i = 0; i < kMaxLanes - 1; i++) h->lane_partials[i].release(), h->lane_partials_err[i].release();
@@ -1452,7 +1463,7 @@ int hgs_cloud_create(hgs_handle* h, const void* pts, size_t n, size_t stride_byt
   if (h) api_lock__ = std::unique_lock<std::recursive_mutex>((h)->api_mutex);
   if (!h || !out || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes % 4) != 0 || n > (size_t)1 << 30) return HGS_ERR_INVALID_ARGUMENT;
   HGS_TRY(set_device(h));
-  static const bool trace = std::getenv("HGS_UPLOAD_TRACE") != nullptr;  // host-side phase times of an upload on stderr (diagnostics)
+  const bool trace = h->upload_trace != 0;  // host-side phase times of an upload on stderr (diagnostics: hgs_debug_set_option "upload_trace")
   const auto t0 = std::chrono::steady_clock::now();
   hgs_cloud* c = nullptr;
   HGS_TRY(cloud_alloc(h, n, &c));
@@ -2139,6 +2150,7 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
   HGS_HIP(h, h->h_small.reserve(256));
   float4* cur = h->pf_a.as<float4>();
   float4* other = h->pf_b.as<float4>();
+  bool grid_radius = false;  // the outlier removal ran on the voxel grid (below): nothing left to do behind the read-back
   int* d_count = h->pf_small.as<int>();                    // [0] current point count
   unsigned* d_meta = h->pf_small.as<unsigned>() + 16;      // voxel-grid bbox / grid parameters
   double* d_stats = reinterpret_cast<double*>(h->pf_small.as<char>() + 192);
@@ -2147,7 +2159,11 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
     if (n > 0) HGS_TRY(upload_points_packed(h, pts, n, stride_bytes, &staged));
     launch_pf_load(h->stream, staged, (int)n, cur, deskew_w, scan_period, d_count, d_meta);  // (also: d_count = n, d_meta = the empty voxel-grid record)
   }
-  if (n > 0 && p->use_distance_filter) {
+  // VoxelGrid behind the distance filter (every launch file's prefilter): the filter is applied inside the voxel grid's bounding-box and key kernels
+  // instead of by flags + scan + compaction in front of them (four launches less; prefilter_fast = 0 keeps the separate pass — A/B, tests)
+  const bool voxelgrid = n > 0 && p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID;
+  const int inline_dist = (voxelgrid && p->use_distance_filter && h->prefilter_fast) ? 1 : 0;
+  if (n > 0 && p->use_distance_filter && !inline_dist) {
     launch_pf_distance_flags(h->stream, cur, (int)n, 1, p->distance_near_thresh, p->distance_far_thresh, h->pf_keep.as<unsigned>());
     HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));
     launch_pf_compact(h->stream, cur, (int)n, h->pf_keep.as<unsigned>(), h->pf_slot.as<unsigned>(), other, d_count);
@@ -2155,13 +2171,14 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
   }
   if (n > 0 && p->downsample_method == HGS_DOWNSAMPLE_VOXELGRID) {
     const float inv_leaf = 1.0f / (float)p->downsample_resolution;
-    launch_pf_bbox(h->stream, cur, d_count, (int)n, d_meta);
+    launch_pf_bbox(h->stream, cur, d_count, (int)n, d_meta, inline_dist, p->distance_near_thresh, p->distance_far_thresh);
     launch_pf_grid(h->stream, d_meta, inv_leaf);
     for (int i = 0; i < 2; i++) {
       HGS_HIP(h, h->sort_keys[i].reserve(n * sizeof(uint64_t)));
       HGS_HIP(h, h->sort_vals[i].reserve(n * sizeof(uint32_t)));
     }
-    launch_pf_voxel_keys(h->stream, cur, d_count, d_meta, inv_leaf, (int)n, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>());
+    launch_pf_voxel_keys(h->stream, cur, d_count, d_meta, inv_leaf, (int)n, h->sort_keys[0].as<unsigned long long>(), h->sort_vals[0].as<unsigned>(), inline_dist,
+                         p->distance_near_thresh, p->distance_far_thresh);
     size_t tmp_bytes = 0;
     int rc = hgs_sort_pairs_u64_u32(nullptr, &tmp_bytes, h->sort_keys[0].as<uint64_t>(), h->sort_keys[1].as<uint64_t>(), h->sort_vals[0].as<uint32_t>(),
                                     h->sort_vals[1].as<uint32_t>(), n, 0, 32, h->stream);
@@ -2176,9 +2193,25 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
     }
     launch_pf_voxel_heads(h->stream, h->sort_keys[1].as<unsigned long long>(), (int)n, h->pf_keep.as<unsigned>(), kVoxelInvalidKey);
     HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));
+    // RadiusOutlierRemoval right behind it (the KITTI launch file's prefilter) needs no search tree: the centroids come out in voxel-key order, a point's
+    // neighbours are found by key (k_pf_grid_radius_flags) — no resident cloud + index built only to be thrown away, and no host read-back of the voxel
+    // count in the middle of the pipeline to size them (the rows of the r-box: at most (2 ceil(r / leaf) + 2)^2 binary searches per point)
+    grid_radius = h->prefilter_fast && p->outlier_removal_method == HGS_OUTLIER_RADIUS && p->radius_radius / p->downsample_resolution <= 4.0;
+    unsigned* ukeys = nullptr;
+    if (grid_radius) {
+      HGS_HIP(h, h->pf_ukeys.reserve(n * sizeof(uint32_t)));
+      ukeys = h->pf_ukeys.as<unsigned>();
+    }
     launch_pf_voxel_centroids(h->stream, cur, h->sort_keys[1].as<unsigned long long>(), h->sort_vals[1].as<unsigned>(), h->pf_keep.as<unsigned>(),
-                              h->pf_slot.as<unsigned>(), (int)n, other, d_count);
+                              h->pf_slot.as<unsigned>(), (int)n, other, d_count, ukeys);
     std::swap(cur, other);
+    if (grid_radius) {
+      launch_pf_grid_radius_flags(h->stream, cur, d_count, ukeys, d_meta, inv_leaf, (float)p->radius_radius, (float)(p->radius_radius * p->radius_radius),
+                                  p->radius_min_neighbors, (int)n, h->pf_keep.as<unsigned>());
+      HGS_TRY(scan_u32(h, h->pf_keep.as<uint32_t>(), h->pf_slot.as<uint32_t>(), n));
+      launch_pf_compact(h->stream, cur, (int)n, h->pf_keep.as<unsigned>(), h->pf_slot.as<unsigned>(), other, d_count);
+      std::swap(cur, other);
+    }
   }
   if (n > 0 && p->downsample_method == HGS_DOWNSAMPLE_APPROX_VOXELGRID) {
     // pcl::ApproximateVoxelGrid: stable sort by history bucket, runs of equal voxel, eviction order (k_pf_approx_*)
@@ -2226,7 +2259,7 @@ static int prefilter_impl(hgs_handle* h, const void* pts, size_t n, size_t strid
   }
   hgs_cloud* c = nullptr;
   HGS_TRY(cloud_from_device(h, cur, m, &c));
-  if (m > 0 && p->outlier_removal_method != HGS_OUTLIER_NONE) {
+  if (m > 0 && p->outlier_removal_method != HGS_OUTLIER_NONE && !grid_radius) {
     std::vector<hgs_cloud*> one{c};
     int rc = ensure_index(h, one);
     if (rc == HGS_OK) {

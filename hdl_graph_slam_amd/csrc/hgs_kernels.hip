@@ -676,15 +676,14 @@ void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n
 }
 
 // ------------------------------------------------------------------------------------------------ GICP iteration
-__global__ void k_gicp_init(GicpState* states, const float* guesses, int B, Progress prog, unsigned* tickets) {
+__global__ void k_gicp_init(GicpState* states, const float* guesses, int B, Progress prog) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0) prog.dev[0] = 0, prog.dev[1] = 0;
   if (b >= B) return;
   gicp_state_init(states[b], guesses + 16 * b);
-  if (tickets) tickets[2 * b] = 0u, tickets[2 * b + 1] = 0u;  // the fused tails' per-problem tile tickets (linearize, error)
 }
-void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog, unsigned* tickets) {
-  hipLaunchKernelGGL(k_gicp_init, dim3((B + 63) / 64), dim3(64), 0, s, states, guesses, B, prog, tickets);
+void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog) {
+  hipLaunchKernelGGL(k_gicp_init, dim3((B + 63) / 64), dim3(64), 0, s, states, guesses, B, prog);
 }
 
 __device__ __forceinline__ Sym3 load_cov(const float4* cov, int i) {
@@ -809,30 +808,15 @@ __device__ __forceinline__ void packet_nn1(const BvhView& tv, float* park, const
   }
 }
 
-// Fused tails (round 6, launches of <= kFusedTailMaxProblems problems: a single registration is a chain of ~4 us kernels in which the two per-problem
-// control launches of an LM round cost as much as its two point kernels): every block of a problem that has written its tile partial takes a ticket; the
-// block that takes the LAST one runs the control step in its tail.  Release: the partial is written, then a device-scope fence, then the ticket; acquire:
-// the ticket (acq_rel, device scope) before any partial is read.  Returns true in every thread of the last block; the ticket is reset for the next round.
-__device__ __forceinline__ void gicp_solve_block(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials);
-__device__ __forceinline__ bool gicp_decide_wave(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials_err);
-__device__ __forceinline__ bool last_block_of_problem(unsigned* ticket, int ntiles) {
-  __shared__ unsigned last;
-  __syncthreads();  // every wave of this block has stored what it owes (and, FUSED, fenced it)
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last = t + 1u == (unsigned)ntiles ? 1u : 0u;
-    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  return last != 0u;
-}
-
+// (Round 6 measured "fused tails" — the LM control steps run by the last block of a problem in the tail of k_gicp_linearize / k_gicp_error, two launches
+// per round instead of four — and dropped them: every block has to make its tile partial visible device-wide before it takes its ticket, and on a chip whose
+// L2 is per XCD that release is an L2 write-back per BLOCK: config 2 (254 tiles) 0.886 -> 1.139 ms, the 53-tile odometry source unchanged.  A kernel
+// boundary does that write-back once.  profiles/r06_ab_fused_tails_seed2.log)
 // update_correspondences + linearize fused: per source point 1-NN in the target tree, Mahalanobis matrix,
 // 6x6 normal-equation terms; wave shuffle reduction, one LDS row per wave, the last wave of the block adds the rows.
 // Algorithmic bytes per source point: 16 (a_i) + 24 (C_A) + 4 (corr) + 16 (b_j) + 24 (C_B) = 84.
-template <bool FUSED>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FUSED ? 4 : HGS_LINEARIZE_WAVES))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, GicpState* states, GicpConsts c,
-                                                           double* __restrict__ partials, int max_blocks, int qpw, unsigned* tickets) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINEARIZE_WAVES))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
+                                                           double* __restrict__ partials, int max_blocks, int qpw) {
   const int b = blockIdx.y;
   if (states[b].phase != GICP_LINEARIZE) return;
   const CloudDesc d = descs[b];
@@ -840,12 +824,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FUSED ? 
   const int tile_pts = (kBlock / 64) * qpw * kNW;
   const int ntiles = (n + tile_pts - 1) / tile_pts;
   const int tile = xcd_tile(blockIdx.x, ntiles);
-  if constexpr (FUSED) {
-    if (ntiles == 0) {  // an empty source: no tile takes a ticket — block 0 runs the control step on zero partials (what k_gicp_solve does)
-      if (blockIdx.x == 0) gicp_solve_block(0, states + b, c, partials + (size_t)b * max_blocks * kAcc);
-      return;
-    }
-  }
   if (tile >= ntiles) return;
   __shared__ double lds[4 * kAcc];
   __shared__ unsigned arrivals;
@@ -901,21 +879,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FUSED ? 
   }
   wave_sums28_to(even, odd, row, lane);
   last_wave_stores<kAcc>(lds, &arrivals, partials + ((size_t)b * max_blocks + tile) * kAcc, lane);
-  if constexpr (FUSED) {
-    __threadfence();  // (the wave that stored the tile partial: visible device-wide before the block's ticket)
-    if (last_block_of_problem(tickets + 2 * b, ntiles)) gicp_solve_block(ntiles, states + b, c, partials + (size_t)b * max_blocks * kAcc);
-  }
 }
-void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, GicpState* states, GicpConsts c, double* partials,
-                           int max_blocks, int B, int qpw, unsigned* tickets) {
-  if (tickets) hipLaunchKernelGGL(k_gicp_linearize<true>, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw, tickets);
-  else hipLaunchKernelGGL(k_gicp_linearize<false>, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw, tickets);
+void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
+                           int max_blocks, int B, int qpw) {
+  hipLaunchKernelGGL(k_gicp_linearize, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw);
 }
 
 // The LM control step behind a linearisation, run by a whole 256-thread block: fixed-order tile reduction, then ONE lane factorises and steps.  The
 // control step is a chain of dependent loads and stores on the problem's state and on the factorisation's pivoted arrays: both live in LDS for its
-// duration (state copied in and out by the block; round 3 ran it on HBM + 592 bytes of scratch).  Shared by k_gicp_solve and the fused tail of
-// k_gicp_linearize<true>: the same code on the same partials in the same order — bitwise the same state.
+// duration (state copied in and out by the block; round 3 ran it on HBM + 592 bytes of scratch).  
 __device__ __forceinline__ void gicp_solve_block(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials) {
   __shared__ double acc[kAcc];
   __shared__ double scratch[kSolveBlock];
@@ -942,27 +914,13 @@ void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states,
 }
 
 // compute_error(xi): same correspondences, Mahalanobis matrices of the linearisation pose x0, residuals at xi.
-template <bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, TargetView tgt, GicpState* states, double* __restrict__ partials_err,
-                                                       int max_blocks, GicpConsts c, unsigned* tickets, Progress prog) {
+__global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, TargetView tgt, const GicpState* states, double* __restrict__ partials_err,
+                                                       int max_blocks) {
   const int b = blockIdx.y;
-  if (states[b].phase != GICP_TRY) {
-    // FUSED: the round's tick of a problem that has nothing to decide (k_gicp_decide ticks once per problem per round whatever its phase)
-    if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) progress_tick(prog, false);
-    return;
-  }
+  if (states[b].phase != GICP_TRY) return;
   const CloudDesc d = descs[b];
   const int n = d.meta->nvalid;
   const int ntiles = (n + kBlock - 1) / kBlock;
-  if constexpr (FUSED) {
-    if (ntiles == 0) {
-      if (blockIdx.x == 0) {
-        const bool finished_now = gicp_decide_wave(0, states + b, c, partials_err + (size_t)b * max_blocks);
-        if (threadIdx.x == 0) progress_tick(prog, finished_now);
-      }
-      return;
-    }
-  }
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = (int)blockIdx.x;
   const int i = tile * kBlock + threadIdx.x;
@@ -980,22 +938,13 @@ __global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, T
     }
   }
   block_reduce_store<1>(&err, partials_err + (size_t)b * max_blocks + tile, lds);
-  if constexpr (FUSED) {
-    __threadfence();
-    if (last_block_of_problem(tickets + 2 * b + 1, ntiles)) {
-      const bool finished_now = gicp_decide_wave(ntiles, states + b, c, partials_err + (size_t)b * max_blocks);
-      if (threadIdx.x == 0) progress_tick(prog, finished_now);
-    }
-  }
 }
-void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, GicpState* states, double* partials_err, int max_blocks, int B, const GicpConsts* fused_c,
-                       unsigned* tickets, Progress prog) {
-  if (tickets) hipLaunchKernelGGL(k_gicp_error<true>, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks, *fused_c, tickets, prog);
-  else hipLaunchKernelGGL(k_gicp_error<false>, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks, GicpConsts{}, tickets, prog);
+void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B) {
+  hipLaunchKernelGGL(k_gicp_error, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks);
 }
 
 // The LM accept / reject step behind compute_error, run by ONE wave (the first 64 threads of the calling block; the others only pass the barriers):
-// shared by k_gicp_decide and the fused tail of k_gicp_error<true>.  Returns (to thread 0) whether the problem finished with this step.
+// Returns (to thread 0) whether the problem finished with this step.
 __device__ __forceinline__ bool gicp_decide_wave(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials_err) {
   __shared__ GicpState st;  // as in gicp_solve_block: the one-lane control step works on LDS
   __shared__ double ws[kGicpControlWorkspace];
@@ -1951,15 +1900,18 @@ void launch_pf_load(hipStream_t s, const float4* staged, int n, float4* out, con
 }
 
 // keep[i] = near < |p| < far  (float norm against double thresholds, :170-173); use_filter == 0 keeps everything
+__device__ __forceinline__ bool pf_distance_keeps(const float4& p, double near_thresh, double far_thresh) {
+  HGS_FP_STRICT
+  const float n2 = p.x * p.x + p.y * p.y + p.z * p.z;
+  const double d = (double)sqrtf(n2);
+  return d > near_thresh && d < far_thresh;
+}
 __global__ __launch_bounds__(kBlock) void k_pf_distance_flags(const float4* __restrict__ pts, int n, int use_filter, double near_thresh, double far_thresh,
                                                               unsigned* __restrict__ keep) {
-  HGS_FP_STRICT
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];
-  const float n2 = p.x * p.x + p.y * p.y + p.z * p.z;
-  const double d = (double)sqrtf(n2);
-  keep[i] = (!use_filter || (d > near_thresh && d < far_thresh)) ? 1u : 0u;
+  keep[i] = (!use_filter || pf_distance_keeps(p, near_thresh, far_thresh)) ? 1u : 0u;
 }
 void launch_pf_distance_flags(hipStream_t s, const float4* pts, int n, int use_filter, double near_thresh, double far_thresh, unsigned* keep) {
   if (n > 0) hipLaunchKernelGGL(k_pf_distance_flags, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, n, use_filter, near_thresh, far_thresh, keep);
@@ -1978,7 +1930,10 @@ void launch_pf_compact(hipStream_t s, const float4* in, int n, const unsigned* k
 }
 
 // pcl::VoxelGrid pass 1: bounding box of the finite points (getMinMax3D) into meta[0..5] (ordered-uint encoding)
-__global__ __launch_bounds__(kBlock) void k_pf_bbox(const float4* __restrict__ pts, const int* __restrict__ count, unsigned* __restrict__ meta) {
+// (round 6) dist_filter: the distance filter of :138-156 applied HERE and in k_pf_voxel_keys instead of by flags + scan + compaction in front (four launches
+// less): a point the filter drops takes part in neither the bounding box nor a voxel — the voxel grid sees exactly the cloud the compaction would have handed it
+__global__ __launch_bounds__(kBlock) void k_pf_bbox(const float4* __restrict__ pts, const int* __restrict__ count, unsigned* __restrict__ meta, int dist_filter, double near_thresh,
+                                                    double far_thresh) {
   const int n = *count;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   // as in k_bbox_count: a thread's points loaded together, ONE set of atomics per block (their serialisation on the six words was this kernel's time)
@@ -1991,7 +1946,7 @@ __global__ __launch_bounds__(kBlock) void k_pf_bbox(const float4* __restrict__ p
     }
 #pragma unroll
     for (int k = 0; k < kBboxPerThread; k++)
-      if (finite3(p[k])) {
+      if (finite3(p[k]) && (!dist_filter || pf_distance_keeps(p[k], near_thresh, far_thresh))) {
         mn[0] = fminf(mn[0], p[k].x), mn[1] = fminf(mn[1], p[k].y), mn[2] = fminf(mn[2], p[k].z);
         mx[0] = fmaxf(mx[0], p[k].x), mx[1] = fmaxf(mx[1], p[k].y), mx[2] = fmaxf(mx[2], p[k].z);
       }
@@ -2034,14 +1989,15 @@ __global__ void k_pf_grid(unsigned* meta, float inv_leaf) {
   im[9] = 1, im[10] = (int)div[0], im[11] = (int)(div[0] * div[1]);
 }
 __global__ __launch_bounds__(kBlock) void k_pf_voxel_keys(const float4* __restrict__ pts, const int* __restrict__ count, const unsigned* __restrict__ meta, float inv_leaf,
-                                                          int cap, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+                                                          int cap, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals, int dist_filter, double near_thresh,
+                                                          double far_thresh) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= cap) return;
   const int* im = reinterpret_cast<const int*>(meta);
   unsigned long long key = 0xffffffffull;
   if (i < *count && !im[12]) {
     const float4 p = pts[i];
-    if (finite3(p)) {
+    if (finite3(p) && (!dist_filter || pf_distance_keeps(p, near_thresh, far_thresh))) {
       const int ix = (int)floorf(p.x * inv_leaf) - im[6], iy = (int)floorf(p.y * inv_leaf) - im[7], iz = (int)floorf(p.z * inv_leaf) - im[8];
       key = (unsigned long long)(unsigned)(ix * im[9] + iy * im[10] + iz * im[11]);
     }
@@ -2060,13 +2016,14 @@ __global__ __launch_bounds__(kBlock) void k_pf_voxel_heads(const unsigned long l
 // one thread per voxel: float centroid of x, y, z, intensity over the run in (stable) input order
 __global__ __launch_bounds__(kBlock) void k_pf_voxel_centroids(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
                                                                const unsigned* __restrict__ head, const unsigned* __restrict__ slot, int cap,
-                                                               float4* __restrict__ out, int* __restrict__ count_out) {
+                                                               float4* __restrict__ out, int* __restrict__ count_out, unsigned* __restrict__ ukeys /* may be null */) {
   HGS_FP_STRICT
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= cap) return;
   if (i == cap - 1) *count_out = (int)(slot[i] + head[i]);
   if (!head[i]) return;
   const unsigned long long key = keys[i];
+  if (ukeys) ukeys[slot[i]] = (unsigned)key;  // ascending: the lookup table of k_pf_grid_radius_flags
   float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
   int n = 0;
   for (int j = i; j < cap && keys[j] == key; j++) {
@@ -2077,23 +2034,81 @@ __global__ __launch_bounds__(kBlock) void k_pf_voxel_centroids(const float4* __r
   const float fn = (float)n;
   out[slot[i]] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
 }
-void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta) {
+void launch_pf_bbox(hipStream_t s, const float4* pts, const int* count, int cap, unsigned* meta, int dist_filter, double near_thresh, double far_thresh) {
   int gx = (cap + kBlock * kBboxPerThread - 1) / (kBlock * kBboxPerThread);
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(k_pf_bbox, dim3(gx), dim3(kBlock), 0, s, pts, count, meta);
+  hipLaunchKernelGGL(k_pf_bbox, dim3(gx), dim3(kBlock), 0, s, pts, count, meta, dist_filter, near_thresh, far_thresh);
 }
 void launch_pf_grid(hipStream_t s, unsigned* meta, float inv_leaf) { hipLaunchKernelGGL(k_pf_grid, dim3(1), dim3(1), 0, s, meta, inv_leaf); }
 void launch_pf_voxel_keys(hipStream_t s, const float4* pts, const int* count, const unsigned* meta, float inv_leaf, int cap, unsigned long long* keys,
-                          unsigned* vals) {
-  if (cap > 0) hipLaunchKernelGGL(k_pf_voxel_keys, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, count, meta, inv_leaf, cap, keys, vals);
+                          unsigned* vals, int dist_filter, double near_thresh, double far_thresh) {
+  if (cap > 0)
+    hipLaunchKernelGGL(k_pf_voxel_keys, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, count, meta, inv_leaf, cap, keys, vals, dist_filter, near_thresh, far_thresh);
 }
 void launch_pf_voxel_heads(hipStream_t s, const unsigned long long* keys, int cap, unsigned* head, unsigned long long invalid_key) {
   if (cap > 0) hipLaunchKernelGGL(k_pf_voxel_heads, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, keys, cap, head, invalid_key);
 }
 void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned long long* keys, const unsigned* vals, const unsigned* head, const unsigned* slot,
-                               int cap, float4* out, int* count_out) {
+                               int cap, float4* out, int* count_out, unsigned* ukeys) {
   if (cap > 0)
-    hipLaunchKernelGGL(k_pf_voxel_centroids, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, keys, vals, head, slot, cap, out, count_out);
+    hipLaunchKernelGGL(k_pf_voxel_centroids, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pts, keys, vals, head, slot, cap, out, count_out, ukeys);
+}
+
+// pcl::RadiusOutlierRemoval behind pcl::VoxelGrid WITHOUT a search tree (round 6): the cloud is one centroid per occupied voxel, in ascending voxel-key order
+// (`cen[j]`, `ukeys[j]`), so the points within r of a centroid sit in the voxels its r-box overlaps — a few rows of consecutive keys, each found by one
+// binary search in ukeys.  Same predicate as k_pf_radius_flags (keep iff more than min_neighbors points, the point itself included, lie strictly within
+// the radius; the same float distance), same output order; what it saves is building a resident cloud + search index just to throw both away, and the host
+// read-back of the voxel count that sizing them needs (hgs_engine.hip, prefilter_impl).  A centroid may round a hair outside its voxel: the box is taken
+// 1e-3 voxel widths larger.  One thread per centroid; threads beyond *count clear their flag.
+__global__ __launch_bounds__(kBlock) void k_pf_grid_radius_flags(const float4* __restrict__ cen, const int* __restrict__ count, const unsigned* __restrict__ ukeys,
+                                                                 const unsigned* __restrict__ meta, float inv_leaf, float radius, float r2, int min_neighbors, int cap,
+                                                                 unsigned* __restrict__ keep) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= cap) return;
+  const int m = *count;
+  if (j >= m) {
+    keep[j] = 0u;
+    return;
+  }
+  const int* im = reinterpret_cast<const int*>(meta);
+  const float4 p = cen[j];
+  const F3 q = {p.x, p.y, p.z};
+  const int nx = im[10], ny = im[10] > 0 ? im[11] / im[10] : 0;
+  int lo[3], hi[3];
+  const float c[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    lo[a] = (int)floorf((c[a] - radius) * inv_leaf - 1.0e-3f) - im[6 + a];
+    hi[a] = (int)floorf((c[a] + radius) * inv_leaf + 1.0e-3f) - im[6 + a];
+  }
+  lo[0] = max(lo[0], 0), lo[1] = max(lo[1], 0), lo[2] = max(lo[2], 0);
+  hi[0] = min(hi[0], nx - 1), hi[1] = min(hi[1], ny - 1);  // (z: rows beyond the grid simply hold no key)
+  int cnt = 0;
+  int a = 0;  // the rows are visited in ascending key order: every lower bound is searched from the previous one (gallop, then bisect)
+  for (int iz = lo[2]; iz <= hi[2] && cnt <= min_neighbors; iz++)
+    for (int iy = lo[1]; iy <= hi[1] && cnt <= min_neighbors; iy++) {
+      const long long row = (long long)iy * im[10] + (long long)iz * im[11];
+      const long long k0 = row + lo[0], k1 = row + hi[0];
+      if (k1 < 0 || k0 > 0xfffffffell) continue;
+      const unsigned key0 = (unsigned)max(k0, 0ll), key1 = (unsigned)min(k1, 0xfffffffell);
+      int b = a, step = a == 0 ? m : 1;  // (the first row: a plain bisection of the whole table)
+      while (b < m && ukeys[b] < key0) a = b + 1, b = min(b + step, m), step <<= 1;
+      while (a < b) {  // lower bound of key0 in [a, b)
+        const int mid = (a + b) >> 1;
+        if (ukeys[mid] < key0) a = mid + 1;
+        else b = mid;
+      }
+      for (; a < m && ukeys[a] <= key1 && cnt <= min_neighbors; a++) {
+        const float4 o = cen[a];
+        cnt += dist2f(q, o.x, o.y, o.z) < r2 ? 1 : 0;
+      }
+    }
+  keep[j] = cnt > min_neighbors ? 1u : 0u;
+}
+void launch_pf_grid_radius_flags(hipStream_t s, const float4* cen, const int* count, const unsigned* ukeys, const unsigned* meta, float inv_leaf, float radius, float r2,
+                                 int min_neighbors, int cap, unsigned* keep) {
+  if (cap > 0)
+    hipLaunchKernelGGL(k_pf_grid_radius_flags, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cen, count, ukeys, meta, inv_leaf, radius, r2, min_neighbors, cap, keep);
 }
 
 // ---- pcl::ApproximateVoxelGrid (apps/prefiltering_nodelet.cpp:59-63, scan_matching_odometry_nodelet.cpp:91-96) ------------------

@@ -8,6 +8,7 @@ C-ABI of include/hgs_registration.h into the HIP library; nothing here computes 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -94,6 +95,14 @@ class RegistrationHIP:
         self._source_n = 0
         self._source_stride = 0
         self._keep = {}
+        # measurement / test knobs (A/B scripts, tests that force a code path): HGS_ENGINE_OPTIONS="knn_replay=1,batch_lanes=1" — read HERE, by the
+        # test / bench harness; the library itself reads no tuning variable from the environment (include/hgs_registration.h, hgs_debug_set_option)
+        for item in filter(None, os.environ.get("HGS_ENGINE_OPTIONS", "").split(",")):
+            key, _, value = item.partition("=")
+            self.set_option(key.strip(), int(value))
+
+    def set_option(self, key: str, value: int):
+        self._check(L.lib().hgs_debug_set_option(self._h, key.encode(), int(value)))
 
     # ---- life cycle
     def close(self):

@@ -10,11 +10,11 @@ echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout
 if [ -n "${DIAG:-}" ]; then echo "== diag"; timeout 1200 python scripts/gpu_diag.py $DIAG > gpurun_out/diag.log 2>&1; echo "diag exit $?"; cat gpurun_out/diag.log | tail -40; fi
 echo "== bench"; timeout 900 python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.log 2>&1; echo "bench exit $?" | tee -a gpurun_out/bench.log; tail -3 gpurun_out/bench.log
 if [ "${DO_PROF:-1}" = "1" ]; then
-  # two kernel traces of the bench command: whole-device launches (HGS_BATCH_LANES=1, the launch shape bench.py's HIP-event
+  # two kernel traces of the bench command: whole-device launches (engine option batch_lanes=1, the launch shape bench.py's HIP-event
   # roofline measurement times) and the default 4 concurrent lanes of the timed region
   for lanes in 1 4; do
     echo "== rocprofv3 lanes=$lanes"
-    (cd /tmp && HGS_BATCH_LANES=$lanes timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof_lanes$lanes" -o bench -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > "$OLDPWD/gpurun_out/prof_lanes$lanes.log" 2>&1); echo "prof exit $?"
+    (cd /tmp && HGS_ENGINE_OPTIONS=batch_lanes=$lanes timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof_lanes$lanes" -o bench -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > "$OLDPWD/gpurun_out/prof_lanes$lanes.log" 2>&1); echo "prof exit $?"
     f=$(find gpurun_out/prof_lanes$lanes -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
   done
 fi

@@ -10,7 +10,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ -n "${PRETEST:-}" ]; then timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "$PRETEST" 2>&1 | tail -5 | tee -a gpurun_out/${LOG:-r06_ab}.log; fi
 for rep in $(seq 1 ${REPS:-2}); do for combo in ${COMBOS:-1:3}; do
-  export HGS_SEED_GRID=${combo%%:*} HGS_KNN_REPLAY=${combo##*:}
+  export HGS_ENGINE_OPTIONS="seed_grid=${combo%%:*},knn_replay=${combo##*:}"
   for W in ${WORKLOADS:-gicp plane ndt cfg2}; do
     case $W in
       gicp) ARGS="--method FAST_GICP --steps 20 --warmup 5 --no-cpu-baseline --no-ndt-record --no-plane-record --seeds 1";;
@@ -20,7 +20,7 @@ for rep in $(seq 1 ${REPS:-2}); do for combo in ${COMBOS:-1:3}; do
       cfg5) ARGS="--config 5 --steps 20 --warmup 3 --no-cpu-baseline --seeds 1";;
       cfg3) ARGS="--config 3 --speed 3 --steps 40 --warmup 3 --no-cpu-baseline --seeds 1 --oracle-sweeps 0 --no-kitti-records --no-adapter-record";;
     esac
-    echo -n "seed=$HGS_SEED_GRID knn=$HGS_KNN_REPLAY $W: "
+    echo -n "$HGS_ENGINE_OPTIONS $W: "
     timeout 300 python bench.py $ARGS 2>/dev/null | python -c "
 import sys, json
 for ln in sys.stdin:

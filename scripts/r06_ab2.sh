@@ -19,9 +19,9 @@ cp hdl_graph_slam_amd/lib/libhgs_hip.so /tmp/current.so
 for rep in 1 2; do
   for split in 0 1; do
     echo -n "cov_split=$split plane: " | tee -a $LOG
-    HGS_COV_SPLIT=$split timeout 300 python bench.py --method FAST_GICP --regularization PLANE --steps 20 --warmup 5 --no-cpu-baseline --no-ndt-record --seeds 1 2>/dev/null | line | tee -a $LOG
+    HGS_ENGINE_OPTIONS=cov_split=$split timeout 300 python bench.py --method FAST_GICP --regularization PLANE --steps 20 --warmup 5 --no-cpu-baseline --no-ndt-record --seeds 1 2>/dev/null | line | tee -a $LOG
     echo -n "cov_split=$split cfg5 plane: " | tee -a $LOG
-    HGS_COV_SPLIT=$split timeout 300 python bench.py --config 5 --regularization PLANE --steps 20 --warmup 3 --no-cpu-baseline --seeds 1 2>/dev/null | line | tee -a $LOG
+    HGS_ENGINE_OPTIONS=cov_split=$split timeout 300 python bench.py --config 5 --regularization PLANE --steps 20 --warmup 3 --no-cpu-baseline --seeds 1 2>/dev/null | line | tee -a $LOG
   done
   for v in base seed8 seed16; do
     cp ab_libs/$v.so hdl_graph_slam_amd/lib/libhgs_hip.so

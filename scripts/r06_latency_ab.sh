@@ -10,10 +10,10 @@ mkdir -p gpurun_out
 LOG=gpurun_out/${LOG:-r06_latency_ab}.log
 if [ -n "${PRETEST:-}" ]; then timeout 1200 python -m pytest tests/test_prefilter.py tests/test_odometry.py tests/test_hip_parity.py -m gpu -x -q 2>&1 | tail -4 | tee -a $LOG; fi
 for rep in $(seq 1 ${REPS:-2}); do for combo in ${COMBOS:-1:16}; do
-  export HGS_RESIDENT_DESCS=${combo%%:*} HGS_KNN_QPW_TINY=${combo##*:}
-  echo -n "resident=$HGS_RESIDENT_DESCS qpw_tiny=$HGS_KNN_QPW_TINY kitti: " | tee -a $LOG
+  export HGS_ENGINE_OPTIONS="resident_descs=${combo%%:*},knn_qpw_tiny=${combo##*:}"
+  echo -n "$HGS_ENGINE_OPTIONS kitti: " | tee -a $LOG
   timeout 300 python scripts/probes/kitti_pipeline_probe.py 2>&1 | tail -1 | tee -a $LOG
-  echo -n "resident=$HGS_RESIDENT_DESCS qpw_tiny=$HGS_KNN_QPW_TINY cfg2: " | tee -a $LOG
+  echo -n "$HGS_ENGINE_OPTIONS cfg2: " | tee -a $LOG
   timeout 300 python bench.py --config 2 --steps 400 --warmup 20 --no-cpu-baseline --seeds 1 2>/dev/null | python -c "
 import sys, json
 for ln in sys.stdin:

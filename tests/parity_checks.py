@@ -69,16 +69,16 @@ def outlier_cloud(seed=5, n_dense=3000, n_far=40):
 
 
 def check_covariances_both_gathers(make_engine):
-    """k_knn_cov's two gather passes — the tree walk and the replay of pass 1's leaf log (HGS_KNN_REPLAY forces either, the engine
+    """k_knn_cov's two gather passes — the tree walk and the replay of pass 1's leaf log (the harness option knn_replay forces either, the engine
     otherwise chooses by launch shape) — on a LiDAR scan, a tie-heavy cloud and the outlier cloud whose log overflows."""
     import os
     scene = synth.make_scene(3)
     clouds = [synth.scan(scene, "VLP-16", synth.pose_matrix([0, 0, 0], [0, 0, 0]), 31), tie_heavy_cloud(), outlier_cloud()]
-    old = os.environ.get("HGS_KNN_REPLAY")
+    old = os.environ.get("HGS_ENGINE_OPTIONS")
     try:
         per_mode = {}
         for replay in ("0", "1", "2"):
-            os.environ["HGS_KNN_REPLAY"] = replay          # read in hgs_create
+            os.environ["HGS_ENGINE_OPTIONS"] = "knn_replay=" + replay          # applied by the harness when the engine is created
             for ci, cloud in enumerate(clouds):
                 e = make_engine(O.default_params(O.HGS_FAST_GICP))
                 e.setInputTarget(cloud)
@@ -87,23 +87,23 @@ def check_covariances_both_gathers(make_engine):
                 e.close()
     finally:
         if old is None:
-            os.environ.pop("HGS_KNN_REPLAY", None)
+            os.environ.pop("HGS_ENGINE_OPTIONS", None)
         else:
-            os.environ["HGS_KNN_REPLAY"] = old
+            os.environ["HGS_ENGINE_OPTIONS"] = old
 
 
 def check_cov_split_equals_inline(make_engine):
     """Non-FROBENIUS regularisations: the search kernel staging fp64 covariances + k_cov_regularize (default) against the single kernel with the
-    eigen-decomposition inline (HGS_COV_SPLIT=0): the same arithmetic on the same fp64 values, identical bits."""
+    eigen-decomposition inline (engine option cov_split=0): the same arithmetic on the same fp64 values, identical bits."""
     import os
     scene = synth.make_scene(3)
     cloud = synth.scan(scene, "VLP-16", synth.pose_matrix([0, 0, 0], [0, 0, 0]), 31)
-    old = os.environ.get("HGS_COV_SPLIT")
+    old = os.environ.get("HGS_ENGINE_OPTIONS")
     try:
         for method in (O.HGS_REG_PLANE, O.HGS_REG_MIN_EIG, O.HGS_REG_NONE):
             got = {}
             for split in ("0", "1"):
-                os.environ["HGS_COV_SPLIT"] = split          # read in hgs_create
+                os.environ["HGS_ENGINE_OPTIONS"] = "cov_split=" + split
                 p = O.default_params(O.HGS_FAST_GICP)
                 p.regularization_method = method
                 e = make_engine(p)
@@ -113,9 +113,9 @@ def check_cov_split_equals_inline(make_engine):
             assert np.array_equal(got["0"], got["1"]), method
     finally:
         if old is None:
-            os.environ.pop("HGS_COV_SPLIT", None)
+            os.environ.pop("HGS_ENGINE_OPTIONS", None)
         else:
-            os.environ["HGS_COV_SPLIT"] = old
+            os.environ["HGS_ENGINE_OPTIONS"] = old
 
 
 def check_covariances_with_outliers(make_engine):

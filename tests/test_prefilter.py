@@ -119,6 +119,38 @@ def test_hip_prefilter_matches_oracle(outlier, leaf):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("leaf,radius,min_neighbors,use_filter", [(0.25, 0.5, 2, 1), (0.25, 0.5, 2, 0), (0.3, 0.8, 5, 1), (0.4, 1.6, 12, 1), (0.2, 0.2, 1, 1), (0.5, 0.25, 0, 1)])
+def test_hip_prefilter_on_the_voxel_grid_equals_the_separate_passes(leaf, radius, min_neighbors, use_filter):
+    """Round 6: with VoxelGrid in front, the distance filter runs inside the voxel grid's kernels and RadiusOutlierRemoval counts neighbours by voxel key
+    (k_pf_grid_radius_flags) instead of on a search tree built for the purpose.  Same cloud, same order, as the separate passes (engine option
+    prefilter_fast = 0) and as the oracle — the KITTI launch file's parameters first, then radii of 1 .. 4 voxel widths, radii below one, NaN / far points."""
+    from hdl_graph_slam_amd import _lib as L
+    from hdl_graph_slam_amd.registration import RegistrationHIP
+    cloud = _scan(7)
+    rng = np.random.default_rng(11)
+    # stragglers that only the outlier removal drops, points the distance filter drops, and non-finite returns
+    extra = synth.to_xyzi(np.concatenate([rng.uniform(-80, 80, (300, 3)) * [1, 1, 0.05] + [0, 0, 20.0], rng.uniform(-0.05, 0.05, (20, 3)),
+                                          np.array([[np.nan, 1, 1], [np.inf, 0, 0], [500.0, 0, 0]])]).astype(np.float32))
+    cloud = np.concatenate([cloud[:4000], extra, cloud[4000:]])
+    p = L.HgsPrefilterParams()
+    L.lib().hgs_prefilter_params_default(C.byref(p))
+    p.use_distance_filter, p.distance_near_thresh, p.distance_far_thresh = use_filter, 0.1, 100.0
+    p.downsample_method, p.downsample_resolution = L.HGS_DOWNSAMPLE_VOXELGRID, leaf
+    p.outlier_removal_method, p.radius_radius, p.radius_min_neighbors = L.HGS_OUTLIER_RADIUS, radius, min_neighbors
+    out = {}
+    for fast in (1, 0):
+        reg = RegistrationHIP(L.default_params(L.HGS_FAST_GICP))
+        reg.set_option("prefilter_fast", fast)
+        got = reg.prefilter(cloud, p).download()
+        out[fast] = np.stack([got["x"], got["y"], got["z"], got["intensity"]], axis=1)
+        reg.close()
+    assert out[1].tobytes() == out[0].tobytes()
+    ref = O.prefilter(cloud, p)
+    assert len(out[1]) == len(ref) and np.array_equal(out[1], ref, equal_nan=True)
+    assert 0 < len(ref) < len(cloud)
+
+
+@pytest.mark.gpu
 def test_hip_prefilter_edge_cases():
     from hdl_graph_slam_amd import _lib as L
     from hdl_graph_slam_amd.registration import RegistrationHIP

@@ -322,6 +322,11 @@ def test_gpu_suite_information_matrix_fitness():
     _gpu_test("test_loop_detector", "test_information_matrix_fitness_score_on_device")()
 
 
+@pytest.mark.parametrize("leaf,radius,min_neighbors,use_filter", [(0.25, 0.5, 2, 1), (0.4, 1.6, 12, 1), (0.5, 0.25, 0, 0)])
+def test_gpu_suite_prefilter_on_the_voxel_grid(leaf, radius, min_neighbors, use_filter):
+    _gpu_test("test_prefilter", "test_hip_prefilter_on_the_voxel_grid_equals_the_separate_passes")(leaf, radius, min_neighbors, use_filter)
+
+
 def test_gpu_suite_prefilter_edges_and_download():
     _gpu_test("test_prefilter", "test_hip_prefilter_edge_cases")()
     _gpu_test("test_prefilter", "test_cloud_download_round_trip")()
