@@ -321,7 +321,7 @@ struct hgs_handle {
   int upload_trace = 0;
   int cov_split = 1;       // non-FROBENIUS regularisations: search kernel + k_cov_regularize (0: one kernel with the eigen-decomposition inline; HGS_COV_SPLIT, A/B runs)
   int resident_descs = 1;  // HGS_RESIDENT_DESCS=0: every stage uploads its descriptor array (A/B runs)
-  int knn_qpw_tiny = 16;  // queries per packet of k_knn_cov for launches below 32 k queries (0: 32 as for every small launch); HGS_KNN_QPW_TINY (A/B runs)
+  int knn_qpw_tiny = 0;   // queries per packet of k_knn_cov for launches below 32 k queries (0: 32 as for every small launch).  16 measured equal, 8 slower (profiles/r06_ab_resident_descs_qpw.log): off
   int seed_grid = 1;    // targets of 1-NN searches get a seed grid (ensure_seed_grid); HGS_SEED_GRID=0 (A/B runs)
   int knn_replay = -1;  // k_knn_cov gather: -1 default (2), 0 tree walk, 1 leaf-log replay, 2 per-lane leaf lists; HGS_KNN_REPLAY (A/B runs, tests)
   int batch_lanes = 0;  // 0: open_lanes chooses (4; NDT_OMP above 32 problems 3; never more than the process's hardware-queue budget has room for); HGS_BATCH_LANES fixes it (A/B runs)
@@ -619,9 +619,8 @@ int upload_descs(hgs_handle* h, const std::vector<hgs_cloud*>& clouds, bool with
 // (one 120 k-point cloud is 1.8 waves per SIMD) and is bound by the dependent-load chain of a single walk; 32-query
 // packets walk fewer nodes and put more waves in flight (0.91 -> 0.66 ms for one 120 k-point cloud).  Large batches keep
 // 64 (least total work); the 1-NN kernels always do (no measurable gain from shorter packets there).
-// Round 6: a launch that cannot even give every SIMD one 32-query packet (an odometry source behind the KITTI prefilter: 13.5 k points = 422 packets)
-// is bound by ONE packet's serial chain; `tiny`-query packets make that chain shorter (fewer leaves in the union walk) — k_knn_cov 122 -> see
-// profiles/r06_ab_qpw.log.
+// Round 6 tried `tiny`-query packets (16 / 8) for launches that cannot even give every SIMD one 32-query packet (an odometry source behind the KITTI prefilter:
+// 13.5 k points = 422 packets): 16 measures equal, 8 slower (profiles/r06_ab_resident_descs_qpw.log) — the option stays for A/B runs, default off.
 int queries_per_wave(size_t total_queries, int small, int tiny = 0) {
   if (tiny > 0 && total_queries < (size_t)1024 * (size_t)small) return tiny;
   return total_queries >= (size_t)600000 ? 64 : small;

@@ -1,4 +1,4 @@
-"""Host mirror of hdl_graph_slam::InformationMatrixCalculator (include/hdl_graph_slam/information_matrix_calculator.hpp:14-61,
+"""Host mirror of hdl_graph_slam::InformationMatrixCalculator (include/hdl_graph_slam/information_matrix_calculator.hpp:14-59,
 src/hdl_graph_slam/information_matrix_calculator.cpp:10-47): the information matrix of an odometry / loop edge from the fitness score of the two
 keyframe clouds.  The fitness score itself is the device kernel (`RegistrationHIP.calc_fitness_score` -> `hgs_calc_fitness_score`, row f1); what is
 left on the host is a dozen scalar operations, restated here with the reference's quirks: the weights are truncated to `float` before the

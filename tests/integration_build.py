@@ -20,8 +20,9 @@ PATCHED = ["CMakeLists.txt", "src/hdl_graph_slam/registrations.cpp", "include/hd
            "src/hdl_graph_slam/information_matrix_calculator.cpp", "src/hdl_graph_slam/map_cloud_generator.cpp", "apps/prefiltering_nodelet.cpp"]
 UNTOUCHED = ["include/hdl_graph_slam/registrations.hpp", "include/hdl_graph_slam/keyframe.hpp", "include/hdl_graph_slam/graph_slam.hpp",
              "include/hdl_graph_slam/information_matrix_calculator.hpp", "include/hdl_graph_slam/map_cloud_generator.hpp"]
-# patched translation units that are compiled and linked into integration_main (the two apps/*.cpp nodelets need all of ROS: their hunks are
-# apply-checked, and everything the hunks call — adapters/registration_hip.hpp, adapters/resident_clouds_hip.hpp — is compiled and run here)
+# patched translation units that are compiled and linked into integration_main.  apps/prefiltering_nodelet.cpp is compiled too (into prefilter_nodelet_main,
+# against the stand-in ROS graph / PCL filters) and its onInit / cloud_callback run; apps/scan_matching_odometry_nodelet.cpp needs message_filters, tf
+# broadcasting and generated messages: its hunk is apply-checked, and what it calls (fitnessScoreHIP, nearestTargetHIP) is compiled and run by the adapter tests
 COMPILED = ["src/hdl_graph_slam/registrations.cpp", "src/hdl_graph_slam/information_matrix_calculator.cpp", "src/hdl_graph_slam/map_cloud_generator.cpp"]
 
 
@@ -29,12 +30,14 @@ def have_reference() -> bool:
     return all(os.path.exists(os.path.join(REFERENCE, f)) for f in PATCHED + UNTOUCHED)
 
 
-def exe(kind: str) -> str:
-    return os.path.join(OUT, "integration_main" + ("_simt" if kind == "simt" else ""))
+def exe(kind: str, name: str = "integration_main") -> str:
+    """name: "integration_main" (factory, loop detector, f1, f3, the f2 adapter call) or "prefilter_nodelet_main" (the patched apps/prefiltering_nodelet.cpp itself)"""
+    return os.path.join(OUT, name + ("_simt" if kind == "simt" else ""))
 
 
 def _deps(lib):
-    d = [PATCH, lib, os.path.join(ROOT, "tests", "cpp", "integration_main.cpp"), os.path.join(ROOT, "adapters", "registration_hip.hpp"),
+    d = [PATCH, lib, os.path.join(ROOT, "tests", "cpp", "integration_main.cpp"), os.path.join(ROOT, "tests", "cpp", "prefilter_nodelet_main.cpp"),
+         os.path.join(ROOT, "oracle", "prefilter.hpp"), os.path.join(ROOT, "adapters", "registration_hip.hpp"),
          os.path.join(ROOT, "adapters", "loop_match_hip.hpp"), os.path.join(ROOT, "adapters", "resident_clouds_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"),
          os.path.join(ROOT, "oracle", "mapcloud.hpp"), os.path.abspath(__file__)]
     for mock in ("mock_ros", "mock_pcl", "mock_eigen"):
@@ -62,10 +65,10 @@ def build(kind: str = "hip") -> str | None:
     else:
         from hdl_graph_slam_amd import build as hip_build
         lib = hip_build.build_lib()
-    out = exe(kind)
+    out, out_nodelet = exe(kind), exe(kind, "prefilter_nodelet_main")
     if not have_reference():
-        return out if os.path.exists(out) else None
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in _deps(lib)):
+        return out if os.path.exists(out) and os.path.exists(out_nodelet) else None
+    if all(os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in _deps(lib)) for o in (out, out_nodelet)):
         return out
     os.makedirs(OUT, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -93,4 +96,11 @@ def build(kind: str = "hip") -> str | None:
         link = ["-l:libhgs_simt.so"] if kind == "simt" else ["-lhgs_hip"]
         subprocess.run(["g++", *objs, "-o", out + ".tmp", "-L", libdir, *link, "-pthread", f"-Wl,-rpath,{rpath}"], check=True)
         os.replace(out + ".tmp", out)
+        # the patched prefiltering nodelet: the class lives in the .cpp, the driver includes it (the stand-in ROS graph of tests/mock_ros lets onInit / cloud_callback run);
+        # it must also still compile without the backend
+        nodelet_flags = [*flags, "-I", tmp]
+        subprocess.run([*nodelet_flags, "-c", os.path.join(ROOT, "tests", "cpp", "prefilter_nodelet_main.cpp"), "-o", os.path.join(tmp, "nodelet.o")], check=True)
+        subprocess.run([f for f in flags if f != "-DUSE_HGS_HIP"] + ["-fsyntax-only", os.path.join(tmp, "apps", "prefiltering_nodelet.cpp")], check=True)
+        subprocess.run(["g++", os.path.join(tmp, "nodelet.o"), "-o", out_nodelet + ".tmp", "-L", libdir, *link, "-pthread", f"-Wl,-rpath,{rpath}"], check=True)
+        os.replace(out_nodelet + ".tmp", out_nodelet)
     return out

@@ -15,18 +15,20 @@ namespace pcl {
 template <typename T>
 using shared_ptr = std::shared_ptr<T>;
 using IndicesConstPtr = std::shared_ptr<const std::vector<int>>;
+struct PCLHeader {  // pcl::PCLHeader: shared by the clouds of every point type
+  unsigned seq = 0;
+  unsigned long long stamp = 0;
+  std::string frame_id;
+};
 template <typename PointT>
 struct PointCloud {
   using Ptr = std::shared_ptr<PointCloud<PointT>>;
   using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
   std::vector<PointT> points;
-  struct Header {
-    unsigned seq = 0;
-    unsigned long long stamp = 0;
-    std::string frame_id;
-  } header;
+  PCLHeader header;
   unsigned width = 0, height = 0;
   bool is_dense = true;
+  Ptr makeShared() const { return std::make_shared<PointCloud<PointT>>(*this); }
   void reserve(size_t n) { points.reserve(n); }
   void push_back(const PointT& p) { points.push_back(p); }
   typename std::vector<PointT>::const_iterator begin() const { return points.begin(); }

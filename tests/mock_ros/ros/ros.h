@@ -1,15 +1,53 @@
 // Minimal stand-in for <ros/ros.h> (TEST ONLY): ros::NodeHandle::param<T>(name, default) over a string map — the only part of roscpp that
 // select_registration_method (src/hdl_graph_slam/registrations.cpp:22-124) and LoopDetector's constructor (loop_detector.hpp:39-49) use.
 #pragma once
+#include <functional>
 #include <iostream>
 #include <map>
+#include <memory>
+#include <type_traits>
+#include <vector>
 #include <sstream>
 #include <string>
 #include "time.h"
 namespace ros {
+// topics of the stand-in graph: what a nodelet subscribed to (type-erased callbacks the test invokes) and what it published (copies the test reads back)
+namespace mock {
+inline std::map<std::string, std::function<void(const void*)>>& callbacks() {
+  static std::map<std::string, std::function<void(const void*)>> m;
+  return m;
+}
+inline std::map<std::string, std::vector<std::shared_ptr<void>>>& published() {
+  static std::map<std::string, std::vector<std::shared_ptr<void>>> m;
+  return m;
+}
+}  // namespace mock
+class Subscriber {};
+class Publisher {
+public:
+  std::string topic;
+  template <typename M>
+  void publish(const M& msg) const {
+    mock::published()[topic].push_back(std::make_shared<M>(msg));
+  }
+  unsigned getNumSubscribers() const { return 0; }
+};
 class NodeHandle {
 public:
   std::map<std::string, std::string> params;  // test code fills this
+  // nh.subscribe(topic, queue, &Class::callback, this): the callback lands in mock::callbacks()[topic]
+  template <typename M, typename T>
+  Subscriber subscribe(const std::string& topic, unsigned, void (T::*fp)(M), T* obj) {
+    using Arg = typename std::remove_cv<typename std::remove_reference<M>::type>::type;
+    mock::callbacks()[topic] = [obj, fp](const void* msg) { (obj->*fp)(*static_cast<const Arg*>(msg)); };
+    return Subscriber();
+  }
+  template <typename M>
+  Publisher advertise(const std::string& topic, unsigned) {
+    Publisher p;
+    p.topic = topic;
+    return p;
+  }
   template <typename T>
   T param(const std::string& name, const T& default_value) const {
     auto it = params.find(name);

@@ -1,5 +1,5 @@
 // Minimal stand-in for <ros/time.h> (TEST ONLY): ros::Time as roscpp lays it out — two uint32 members `sec`, `nsec` (KeyFrame::save / load,
-// src/hdl_graph_slam/keyframe.cpp:27,72, stream them directly) — plus now(), toSec() and the difference LoopDetector::matching prints.
+// src/hdl_graph_slam/keyframe.cpp:27,72, stream them directly) — plus now(), toSec(), comparisons and the difference LoopDetector::matching prints.
 #pragma once
 #include <chrono>
 #include <cmath>
@@ -7,6 +7,8 @@
 namespace ros {
 struct Duration {
   double s = 0;
+  Duration() = default;
+  explicit Duration(double t) : s(t) {}
   double toSec() const { return s; }
 };
 struct Time {
@@ -20,6 +22,8 @@ struct Time {
   }
   static Time now() { return Time(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
   double toSec() const { return (double)sec + 1e-9 * (double)nsec; }
-  Duration operator-(const Time& o) const { return Duration{((double)sec - (double)o.sec) + 1e-9 * ((double)nsec - (double)o.nsec)}; }
+  Duration operator-(const Time& o) const { return Duration(((double)sec - (double)o.sec) + 1e-9 * ((double)nsec - (double)o.nsec)); }
+  bool operator>(const Time& o) const { return sec > o.sec || (sec == o.sec && nsec > o.nsec); }
+  bool operator<(const Time& o) const { return o > *this; }
 };
 }  // namespace ros

@@ -104,3 +104,29 @@ def test_cpp_loop_matcher_on_the_gpu(tmp_path):
             assert np.array_equal(np.array([float(v) for v in f[4:]], np.float32), rec["final_transformation"][k])
         line += 1 + len(order)
     reg.close()
+
+
+def _capacity_line(exe, *args):
+    out = subprocess.run([exe, "capacity", *[str(a) for a in args]], check=True, capture_output=True, text=True).stdout.split()
+    return {out[i]: int(out[i + 1]) for i in range(1, len(out) - 1, 2)}
+
+
+@pytest.mark.gpu
+def test_resident_keyframes_stay_bounded_over_a_2000_keyframe_run():
+    """hdl_graph_slam never removes a keyframe: LoopMatcherHIP's budget (reg_hip_resident_keyframes / reg_hip_resident_mb of the patched LoopDetector) keeps the
+    device copies bounded, least recently matched first — 2000 keyframes, four per detection + one old one, at most 32 resident / 24 MiB; a keyframe that was
+    evicted and uploaded again gives the same record bit for bit."""
+    from hdl_graph_slam_amd import build as hip_build
+    lib = hip_build.build_lib()
+    exe = os.path.join(ROOT, "tests", "cpp", "loop_match_main")
+    src_cpp = os.path.join(ROOT, "tests", "cpp", "loop_match_main.cpp")
+    deps = [src_cpp, os.path.join(ROOT, "adapters", "loop_match_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"), lib]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), src_cpp, "-o", exe, "-L", os.path.dirname(lib), "-lhgs_hip",
+                        f"-Wl,-rpath,{os.path.dirname(lib)}"], check=True)
+    r = _capacity_line(exe, 0, 2000, 4, 32, 0, 2000)          # count budget
+    assert r["detections"] == 500 and r["high_water_keyframes"] <= 32 + 5 and r["resident_now"] <= 32 and r["evictions"] >= 1900 and r["mismatches"] == 0, r
+    r = _capacity_line(exe, 0, 2000, 4, 0, 24, 2000)           # byte budget: 24 MiB
+    assert r["high_water_bytes"] <= 24 * 2 ** 20 + 5 * 2 ** 20 and r["evictions"] >= 1500 and r["mismatches"] == 0, r
+    r = _capacity_line(exe, 0, 200, 4, 0, 0, 2000)             # no budget: everything stays
+    assert r["resident_now"] == 200 and r["evictions"] == 0 and r["mismatches"] == 0, r

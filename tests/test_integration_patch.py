@@ -241,6 +241,36 @@ def _check_next_rows(exe, tmp_path):
     assert np.array_equal(np.stack([pf["x"], pf["y"], pf["z"], pf["intensity"]], 1), n["approx_voxelgrid_0.3"])
 
 
+def _check_prefilter_nodelet(kind, tmp_path):
+    """f2, the nodelet itself: the reference's PrefilteringNodelet::onInit / initialize_params / cloud_callback from the PATCHED apps/prefiltering_nodelet.cpp,
+    once through the USE_HGS_HIP hunk (one hgs_prefilter call) and once with use_hip_prefilter=false (its own filter chain): the published clouds are identical,
+    header included — for the KITTI launch file's parameters, the nodelet's defaults (VOXELGRID 0.1 + STATISTICAL) and APPROX_VOXELGRID + RADIUS."""
+    from hdl_graph_slam_amd import synth
+    exe = IB.exe(kind, "prefilter_nodelet_main")
+    assert os.path.exists(exe)
+    _z, n, _gold = _next_row_inputs(tmp_path)
+    for params in (["downsample_method=VOXELGRID", "downsample_resolution=0.25", "outlier_removal_method=RADIUS", "radius_radius=0.5", "radius_min_neighbors=2", "distance_near_thresh=0.1"],
+                   [],
+                   ["downsample_method=APPROX_VOXELGRID", "downsample_resolution=0.3", "outlier_removal_method=RADIUS", "radius_radius=1.0", "radius_min_neighbors=2"]):
+        out = _run(exe, tmp_path / "raw.bin", tmp_path / "nd.bin", tmp_path / "nc.bin", *params)
+        line = [ln for ln in out if ln.startswith("prefilter_nodelet")][0].split()
+        assert not [ln for ln in out if ln.startswith("error")], out
+        n_dev, n_cpu, calls, calls_after = int(line[4]), int(line[6]), int(line[8]), int(line[10])
+        assert n_dev == n_cpu > 0 and calls == 1 and calls_after == 1, line       # the hunk took the device path once; use_hip_prefilter=false did not
+        assert open(tmp_path / "nd.bin", "rb").read() == open(tmp_path / "nc.bin", "rb").read()
+    got = np.fromfile(tmp_path / "nd.bin", synth.POINT_XYZI_DTYPE)
+    assert np.array_equal(np.stack([got["x"], got["y"], got["z"], got["intensity"]], 1), _approx_radius_golden(n))
+
+
+def _approx_radius_golden(n):
+    """the last parameter set above through the oracle, on the committed raw sweep"""
+    import oracle as O
+    from hdl_graph_slam_amd import synth
+    p = O.default_prefilter_params()
+    p.downsample_method, p.downsample_resolution, p.outlier_removal_method, p.radius_radius, p.radius_min_neighbors = 2, 0.3, 2, 1.0, 2
+    return O.prefilter(synth.to_xyzi(n["raw_xyzi"][:, :3], n["raw_xyzi"][:, 3]), p)
+
+
 def _check_regularization_param(exe, tmp_path, align_with):
     """reg_regularization_method reaches both GICP branches of the patched factory (registrations.cpp:27-56) and changes the result like the mirror's."""
     from hdl_graph_slam_amd import _lib as L
@@ -283,6 +313,7 @@ def test_next_row_hunks_and_robustness_on_the_emulated_kernels(tmp_path):
         pytest.skip("no clang++ for the host emulation")
     import oracle as O
     _check_next_rows(exe, tmp_path)
+    _check_prefilter_nodelet("simt", tmp_path)
     _check_regularization_param(exe, tmp_path, None)
     wl, files = _write_loop_set(tmp_path)
     o = O.OracleRegistration(O.default_params(O.HGS_FAST_GICP))
@@ -303,6 +334,7 @@ def test_next_row_hunks_and_robustness_on_the_gpu(tmp_path):
     assert exe is not None and os.path.exists(exe)
     from hdl_graph_slam_amd.registrations import select_registration_method
     _check_next_rows(exe, tmp_path)
+    _check_prefilter_nodelet("hip", tmp_path)
 
     def mirror(method, regularization, tgt, src):
         reg = select_registration_method({"registration_method": method, "reg_regularization_method": regularization, "reg_resolution": 1.0})
