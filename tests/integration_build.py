@@ -18,11 +18,11 @@ PATCH = os.path.join(ROOT, "integration", "hdl_graph_slam_hip.patch")
 OUT = os.path.join(ROOT, "integration", "_build")
 PATCHED = ["CMakeLists.txt", "src/hdl_graph_slam/registrations.cpp", "include/hdl_graph_slam/loop_detector.hpp", "apps/scan_matching_odometry_nodelet.cpp",
            "src/hdl_graph_slam/information_matrix_calculator.cpp", "src/hdl_graph_slam/map_cloud_generator.cpp", "apps/prefiltering_nodelet.cpp"]
-UNTOUCHED = ["include/hdl_graph_slam/registrations.hpp", "include/hdl_graph_slam/keyframe.hpp", "include/hdl_graph_slam/graph_slam.hpp",
+UNTOUCHED = ["include/hdl_graph_slam/registrations.hpp", "include/hdl_graph_slam/keyframe.hpp", "include/hdl_graph_slam/graph_slam.hpp", "include/hdl_graph_slam/ros_utils.hpp",
              "include/hdl_graph_slam/information_matrix_calculator.hpp", "include/hdl_graph_slam/map_cloud_generator.hpp"]
-# patched translation units that are compiled and linked into integration_main.  apps/prefiltering_nodelet.cpp is compiled too (into prefilter_nodelet_main,
-# against the stand-in ROS graph / PCL filters) and its onInit / cloud_callback run; apps/scan_matching_odometry_nodelet.cpp needs message_filters, tf
-# broadcasting and generated messages: its hunk is apply-checked, and what it calls (fitnessScoreHIP, nearestTargetHIP) is compiled and run by the adapter tests
+# patched translation units that are compiled and linked into integration_main.  The two patched nodelets (apps/*.cpp: the classes live in the .cpp files) are
+# compiled too — prefilter_nodelet_main, odometry_nodelet_main include them — against the stand-in ROS graph / messages / tf / PCL filters of tests/mock_*, and
+# their onInit / cloud_callback / matching / publish_scan_matching_status RUN
 COMPILED = ["src/hdl_graph_slam/registrations.cpp", "src/hdl_graph_slam/information_matrix_calculator.cpp", "src/hdl_graph_slam/map_cloud_generator.cpp"]
 
 
@@ -31,13 +31,14 @@ def have_reference() -> bool:
 
 
 def exe(kind: str, name: str = "integration_main") -> str:
-    """name: "integration_main" (factory, loop detector, f1, f3, the f2 adapter call) or "prefilter_nodelet_main" (the patched apps/prefiltering_nodelet.cpp itself)"""
+    """name: "integration_main" (factory, loop detector, f1, f3, the f2 adapter call), "prefilter_nodelet_main" / "odometry_nodelet_main" (the patched
+    apps/prefiltering_nodelet.cpp / apps/scan_matching_odometry_nodelet.cpp themselves, run against the stand-in ROS graph)"""
     return os.path.join(OUT, name + ("_simt" if kind == "simt" else ""))
 
 
 def _deps(lib):
     d = [PATCH, lib, os.path.join(ROOT, "tests", "cpp", "integration_main.cpp"), os.path.join(ROOT, "tests", "cpp", "prefilter_nodelet_main.cpp"),
-         os.path.join(ROOT, "oracle", "prefilter.hpp"), os.path.join(ROOT, "adapters", "registration_hip.hpp"),
+         os.path.join(ROOT, "tests", "cpp", "odometry_nodelet_main.cpp"), os.path.join(ROOT, "oracle", "prefilter.hpp"), os.path.join(ROOT, "adapters", "registration_hip.hpp"),
          os.path.join(ROOT, "adapters", "loop_match_hip.hpp"), os.path.join(ROOT, "adapters", "resident_clouds_hip.hpp"), os.path.join(ROOT, "include", "hgs_registration.h"),
          os.path.join(ROOT, "oracle", "mapcloud.hpp"), os.path.abspath(__file__)]
     for mock in ("mock_ros", "mock_pcl", "mock_eigen"):
@@ -65,10 +66,10 @@ def build(kind: str = "hip") -> str | None:
     else:
         from hdl_graph_slam_amd import build as hip_build
         lib = hip_build.build_lib()
-    out, out_nodelet = exe(kind), exe(kind, "prefilter_nodelet_main")
+    out, out_nodelet, out_odometry = exe(kind), exe(kind, "prefilter_nodelet_main"), exe(kind, "odometry_nodelet_main")
     if not have_reference():
-        return out if os.path.exists(out) and os.path.exists(out_nodelet) else None
-    if all(os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in _deps(lib)) for o in (out, out_nodelet)):
+        return out if all(os.path.exists(o) for o in (out, out_nodelet, out_odometry)) else None
+    if all(os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in _deps(lib)) for o in (out, out_nodelet, out_odometry)):
         return out
     os.makedirs(OUT, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -103,4 +104,9 @@ def build(kind: str = "hip") -> str | None:
         subprocess.run([f for f in flags if f != "-DUSE_HGS_HIP"] + ["-fsyntax-only", os.path.join(tmp, "apps", "prefiltering_nodelet.cpp")], check=True)
         subprocess.run(["g++", os.path.join(tmp, "nodelet.o"), "-o", out_nodelet + ".tmp", "-L", libdir, *link, "-pthread", f"-Wl,-rpath,{rpath}"], check=True)
         os.replace(out_nodelet + ".tmp", out_nodelet)
+        # the patched odometry nodelet + the patched factory: the reference's own ScanMatchingOdometryNodelet drives the engine
+        subprocess.run([*nodelet_flags, "-Wno-unused-function", "-c", os.path.join(ROOT, "tests", "cpp", "odometry_nodelet_main.cpp"), "-o", os.path.join(tmp, "odometry.o")], check=True)
+        subprocess.run([f for f in flags if f != "-DUSE_HGS_HIP"] + ["-Wno-unused-function", "-fsyntax-only", os.path.join(tmp, "apps", "scan_matching_odometry_nodelet.cpp")], check=True)
+        subprocess.run(["g++", os.path.join(tmp, "odometry.o"), objs[0], "-o", out_odometry + ".tmp", "-L", libdir, *link, "-pthread", f"-Wl,-rpath,{rpath}"], check=True)
+        os.replace(out_odometry + ".tmp", out_odometry)
     return out

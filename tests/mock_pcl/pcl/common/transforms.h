@@ -47,4 +47,9 @@ void transformPointCloud(const PointCloud<PointT>& cloud_in, PointCloud<PointT>&
     cloud_out.points[i].x = tgt[0], cloud_out.points[i].y = tgt[1], cloud_out.points[i].z = tgt[2], cloud_out.points[i].data3 = tgt[3];
   }
 }
+// the Matrix4f overload (ScanMatchingOdometryNodelet::matching publishes the aligned cloud with it)
+template <typename PointT>
+void transformPointCloud(const PointCloud<PointT>& cloud_in, PointCloud<PointT>& cloud_out, const Eigen::Matrix4f& transform, bool copy_all_fields = true) {
+  transformPointCloud(cloud_in, cloud_out, Eigen::Isometry3f(transform), copy_all_fields);
+}
 }  // namespace pcl

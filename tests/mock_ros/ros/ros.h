@@ -9,6 +9,7 @@
 #include <vector>
 #include <sstream>
 #include <string>
+#include <boost/bind.hpp>
 #include "time.h"
 namespace ros {
 // topics of the stand-in graph: what a nodelet subscribed to (type-erased callbacks the test invokes) and what it published (copies the test reads back)
@@ -21,6 +22,10 @@ inline std::map<std::string, std::vector<std::shared_ptr<void>>>& published() {
   static std::map<std::string, std::vector<std::shared_ptr<void>>> m;
   return m;
 }
+inline std::map<std::string, unsigned>& subscribers() {  // what Publisher::getNumSubscribers() reports per topic (default 0)
+  static std::map<std::string, unsigned> m;
+  return m;
+}
 }  // namespace mock
 class Subscriber {};
 class Publisher {
@@ -30,7 +35,10 @@ public:
   void publish(const M& msg) const {
     mock::published()[topic].push_back(std::make_shared<M>(msg));
   }
-  unsigned getNumSubscribers() const { return 0; }
+  unsigned getNumSubscribers() const {
+    auto it = mock::subscribers().find(topic);
+    return it == mock::subscribers().end() ? 0u : it->second;
+  }
 };
 class NodeHandle {
 public:
@@ -40,6 +48,13 @@ public:
   Subscriber subscribe(const std::string& topic, unsigned, void (T::*fp)(M), T* obj) {
     using Arg = typename std::remove_cv<typename std::remove_reference<M>::type>::type;
     mock::callbacks()[topic] = [obj, fp](const void* msg) { (obj->*fp)(*static_cast<const Arg*>(msg)); };
+    return Subscriber();
+  }
+  // nh.subscribe<M>(topic, queue, boost::bind(&Class::callback, this, _1, ...)): the callback takes a shared_ptr<const M>
+  template <typename M, typename F>
+  Subscriber subscribe(const std::string& topic, unsigned, F f) {
+    std::function<void(const std::shared_ptr<const M>&)> fn = f;
+    mock::callbacks()[topic] = [fn](const void* msg) { fn(*static_cast<const std::shared_ptr<const M>*>(msg)); };
     return Subscriber();
   }
   template <typename M>
@@ -68,6 +83,7 @@ template <>
 inline std::string NodeHandle::parse<std::string>(const std::string& v) {
   return v;
 }
+inline bool ok() { return true; }
 }  // namespace ros
 // rosconsole's stream macros, to stderr (KeyFrame::load, src/hdl_graph_slam/keyframe.cpp:121-135, reports its failures with them)
 #ifndef ROS_ERROR_STREAM

@@ -4,11 +4,13 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <ostream>
 namespace ros {
 struct Duration {
   double s = 0;
   Duration() = default;
   explicit Duration(double t) : s(t) {}
+  Duration(int sec, int nsec) : s((double)sec + 1e-9 * (double)nsec) {}
   double toSec() const { return s; }
 };
 struct Time {
@@ -25,5 +27,8 @@ struct Time {
   Duration operator-(const Time& o) const { return Duration(((double)sec - (double)o.sec) + 1e-9 * ((double)nsec - (double)o.nsec)); }
   bool operator>(const Time& o) const { return sec > o.sec || (sec == o.sec && nsec > o.nsec); }
   bool operator<(const Time& o) const { return o > *this; }
+  bool isZero() const { return sec == 0 && nsec == 0; }
+  Time operator+(const Duration& d) const { return Time(toSec() + d.s); }
 };
+inline std::ostream& operator<<(std::ostream& os, const Time& t) { return os << t.sec << "." << t.nsec; }
 }  // namespace ros

@@ -271,6 +271,58 @@ def _approx_radius_golden(n):
     return O.prefilter(synth.to_xyzi(n["raw_xyzi"][:, :3], n["raw_xyzi"][:, 3]), p)
 
 
+def _check_odometry_nodelet(kind, tmp_path, make_registration, tol):
+    """a2 / a4 with the reference's own caller: the PATCHED apps/scan_matching_odometry_nodelet.cpp (its class lives in the .cpp) + the patched factory run a
+    6-sweep stream — onInit, cloud_callback, matching (:165-262), publish_odometry and, with a status subscriber, publish_scan_matching_status (:298-335) through the
+    USE_HGS_HIP hunk — against hdl_graph_slam_amd.odometry.ScanMatchingOdometry (the Python restatement of the same function) over `make_registration(pnh)`: the
+    same odometry, converged flags, matching error (getFitnessScore) and inlier fraction; PCL's CPU kd-tree is never built."""
+    from hdl_graph_slam_amd import synth, workloads
+    from hdl_graph_slam_amd.odometry import ScanMatchingOdometry
+    exe = IB.exe(kind, "odometry_nodelet_main")
+    assert os.path.exists(exe)
+    st = workloads.make_odometry_stream("VLP-16", 0, 6, speed=2.0, downsample=0.3)
+    files = []
+    for i, c in enumerate(st.scans):
+        c.tofile(tmp_path / f"sw{i}.bin")
+        files.append(tmp_path / f"sw{i}.bin")
+    for method, mirror_method in (("FAST_GICP_HIP", "FAST_GICP"), ("NDT_HIP", "NDT_OMP")):
+        # run A: keyframe switches on (0.5 m), no status subscriber; run B: one keyframe, status subscribed (the status is published BEFORE a keyframe switch,
+        # so the mirror's scores are only comparable while the target stays)
+        for delta_trans, delta_time, subscribers in ((0.5, 1.0, 0), (5.0, 100.0, 1)):
+            out = _run(exe, method, subscribers, "downsample_method=NONE", f"keyframe_delta_trans={delta_trans}", f"keyframe_delta_time={delta_time}", "reg_resolution=1.0", "--", *files)
+            odom = [ln.split() for ln in out if ln.startswith("odom")]
+            status = {int(ln.split()[1]): ln.split() for ln in out if ln.startswith("status")}
+            assert len(odom) == 6 and all(o[-1] == "0" for o in odom), out          # every sweep published; no CPU kd-tree build anywhere (status path included)
+            assert len(status) == (5 if subscribers else 0)
+            reg = make_registration({"registration_method": mirror_method, "reg_resolution": 1.0})
+            od = ScanMatchingOdometry(reg, keyframe_delta_trans=delta_trans, keyframe_delta_angle=0.15, keyframe_delta_time=delta_time)     # (:76-78)
+            for k, c in enumerate(st.scans):
+                T = od.matching(100.0 + 0.1 * k, c)
+                p = np.array([float(v) for v in odom[k][2:5]])
+                assert np.abs(p - T[:3, 3]).max() < tol, (method, k, p, T[:3, 3])
+                qw, qx, qy, qz = [float(v) for v in odom[k][5:9]]
+                R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                              [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                              [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+                assert np.abs(R - T[:3, :3]).max() < 10 * tol, (method, k)
+                if k == 0 or not subscribers:
+                    continue
+                s = status[k]
+                assert int(s[3]) == int(od.last_result.converged) == 1
+                fit = reg.getFitnessScore()
+                assert abs(float(s[5]) - fit) <= 1e-5 * max(fit, 1e-3) + 10 * tol, (method, k, s[5], fit)
+                aligned = synth.transform_cloud(c, np.asarray(od.last_result.matrix(), np.float64))
+                _idx, d2 = reg.nn_target(synth.xyz_of(aligned))
+                frac = float(np.mean(np.asarray(d2).reshape(-1) < 0.25))
+                assert abs(float(s[7]) - frac) < 2e-3, (method, k, s[7], frac)
+            if subscribers:
+                assert od.num_keyframes == 1
+            elif mirror_method == "FAST_GICP":
+                assert od.num_keyframes >= 2          # run A really switched keyframes (setInputTarget on the new one)
+            if hasattr(reg, "close"):
+                reg.close()
+
+
 def _check_regularization_param(exe, tmp_path, align_with):
     """reg_regularization_method reaches both GICP branches of the patched factory (registrations.cpp:27-56) and changes the result like the mirror's."""
     from hdl_graph_slam_amd import _lib as L
@@ -314,6 +366,12 @@ def test_next_row_hunks_and_robustness_on_the_emulated_kernels(tmp_path):
     import oracle as O
     _check_next_rows(exe, tmp_path)
     _check_prefilter_nodelet("simt", tmp_path)
+
+    def oracle_registration(pnh):
+        p = O.default_params(O.HGS_FAST_GICP if pnh["registration_method"] == "FAST_GICP" else O.HGS_NDT_OMP)
+        p.resolution = pnh["reg_resolution"]
+        return O.OracleRegistration(p)
+    _check_odometry_nodelet("simt", tmp_path, oracle_registration, 2e-4)
     _check_regularization_param(exe, tmp_path, None)
     wl, files = _write_loop_set(tmp_path)
     o = O.OracleRegistration(O.default_params(O.HGS_FAST_GICP))
@@ -335,6 +393,7 @@ def test_next_row_hunks_and_robustness_on_the_gpu(tmp_path):
     from hdl_graph_slam_amd.registrations import select_registration_method
     _check_next_rows(exe, tmp_path)
     _check_prefilter_nodelet("hip", tmp_path)
+    _check_odometry_nodelet("hip", tmp_path, select_registration_method, 2e-6)
 
     def mirror(method, regularization, tgt, src):
         reg = select_registration_method({"registration_method": method, "reg_regularization_method": regularization, "reg_resolution": 1.0})
