@@ -96,6 +96,10 @@ def roofline_of(method, prof, units, prof_steps, launch_config, pmc_ok=True, pro
     hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
            "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5)}
     out = {"bound": "hbm", "kernel": kname}
+    if dom == "covariance" and pmc_name and "plane" in pmc_name:
+        # round 6: the non-FROBENIUS covariance stage is two kernels; the HIP events bracket the pair
+        out["kernel_note"] = ("the covariance stage under PLANE = k_knn_cov<20, 2, 2> (search; fp64 neighbourhood covariances staged) + k_cov_regularize (3x3 eigen-decompositions): "
+                              "avg_launch_us and achieved are of the pair (k_cov_regularize alone: ~0.4 ms of it, profiles/r06_fast_gicp_plane_kernel_stats.md)")
     out.update(hbm)
     if method == "NDT_OMP" and valu is not None:
         out.update({"bound": "valu", "achieved": valu["ginst_per_s"], "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": valu["issue_frac"]})
