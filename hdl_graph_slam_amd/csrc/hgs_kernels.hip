@@ -2059,56 +2059,75 @@ void launch_pf_voxel_centroids(hipStream_t s, const float4* pts, const unsigned 
 // binary search in ukeys.  Same predicate as k_pf_radius_flags (keep iff more than min_neighbors points, the point itself included, lie strictly within
 // the radius; the same float distance), same output order; what it saves is building a resident cloud + search index just to throw both away, and the host
 // read-back of the voxel count that sizing them needs (hgs_engine.hip, prefilter_impl).  A centroid may round a hair outside its voxel: the box is taken
-// 1e-3 voxel widths larger.  One thread per centroid; threads beyond *count clear their flag.
+// 1e-3 voxel widths larger.  G lanes per centroid (below); the groups beyond *count clear their flag.
+// (Round 6 also measured k_pf_voxel_centroids reading its run four entries at a time: 28.8 vs 29.1 us — its time is the longest run's ordered float sum, a
+// near-sensor voxel with a few hundred returns, not the loads; and an L2 warm-up of small launches' trees — every block touching the whole tree once before its
+// walks — for k_knn_cov / k_gicp_linearize: k_knn_cov unchanged, config 2's linearize 0.35 -> 0.50 ms; both removed.  profiles/r06_ab6_prefilter_warm.log)
+template <int G>
 __global__ __launch_bounds__(kBlock) void k_pf_grid_radius_flags(const float4* __restrict__ cen, const int* __restrict__ count, const unsigned* __restrict__ ukeys,
                                                                  const unsigned* __restrict__ meta, float inv_leaf, float radius, float r2, int min_neighbors, int cap,
                                                                  unsigned* __restrict__ keep) {
-  const int j = blockIdx.x * kBlock + threadIdx.x;
-  if (j >= cap) return;
+  // G adjacent lanes per centroid, lane g on the z-layer lo[2] + g of the r-box (G >= the box's layers: launch_pf_grid_radius_flags): a layer starts with ONE
+  // bisection of the key table, its rows follow each other closely in it.  One thread per centroid walked all (2 ceil(r / leaf) + 2)^2 rows itself — a chain of
+  // ~120 dependent loads for a centroid without neighbours, and nearly every wave holds one: 52 us of a 0.36 ms prefilter.  The G partial counts are summed
+  // across the group (an integer count against a threshold: nothing about the predicate changes).
+  static_assert(G == 4 || G == 8 || G == 16, "a power of two that divides the wave");
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  const int j = t / G, g = t & (G - 1);
   const int m = *count;
-  if (j >= m) {
-    keep[j] = 0u;
-    return;
-  }
-  const int* im = reinterpret_cast<const int*>(meta);
-  const float4 p = cen[j];
-  const F3 q = {p.x, p.y, p.z};
-  const int nx = im[10], ny = im[10] > 0 ? im[11] / im[10] : 0;
-  int lo[3], hi[3];
-  const float c[3] = {p.x, p.y, p.z};
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    lo[a] = (int)floorf((c[a] - radius) * inv_leaf - 1.0e-3f) - im[6 + a];
-    hi[a] = (int)floorf((c[a] + radius) * inv_leaf + 1.0e-3f) - im[6 + a];
-  }
-  lo[0] = max(lo[0], 0), lo[1] = max(lo[1], 0), lo[2] = max(lo[2], 0);
-  hi[0] = min(hi[0], nx - 1), hi[1] = min(hi[1], ny - 1);  // (z: rows beyond the grid simply hold no key)
   int cnt = 0;
-  int a = 0;  // the rows are visited in ascending key order: every lower bound is searched from the previous one (gallop, then bisect)
-  for (int iz = lo[2]; iz <= hi[2] && cnt <= min_neighbors; iz++)
-    for (int iy = lo[1]; iy <= hi[1] && cnt <= min_neighbors; iy++) {
-      const long long row = (long long)iy * im[10] + (long long)iz * im[11];
-      const long long k0 = row + lo[0], k1 = row + hi[0];
-      if (k1 < 0 || k0 > 0xfffffffell) continue;
-      const unsigned key0 = (unsigned)max(k0, 0ll), key1 = (unsigned)min(k1, 0xfffffffell);
-      int b = a, step = a == 0 ? m : 1;  // (the first row: a plain bisection of the whole table)
-      while (b < m && ukeys[b] < key0) a = b + 1, b = min(b + step, m), step <<= 1;
-      while (a < b) {  // lower bound of key0 in [a, b)
-        const int mid = (a + b) >> 1;
-        if (ukeys[mid] < key0) a = mid + 1;
-        else b = mid;
-      }
-      for (; a < m && ukeys[a] <= key1 && cnt <= min_neighbors; a++) {
-        const float4 o = cen[a];
-        cnt += dist2f(q, o.x, o.y, o.z) < r2 ? 1 : 0;
-      }
+  if (j < m) {
+    const int* im = reinterpret_cast<const int*>(meta);
+    const float4 p = cen[j];
+    const F3 q = {p.x, p.y, p.z};
+    const int nx = im[10], ny = im[10] > 0 ? im[11] / im[10] : 0;
+    int lo[3], hi[3];
+    const float c[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = (int)floorf((c[a] - radius) * inv_leaf - 1.0e-3f) - im[6 + a];
+      hi[a] = (int)floorf((c[a] + radius) * inv_leaf + 1.0e-3f) - im[6 + a];
     }
-  keep[j] = cnt > min_neighbors ? 1u : 0u;
+    lo[0] = max(lo[0], 0), lo[1] = max(lo[1], 0), lo[2] = max(lo[2], 0);
+    hi[0] = min(hi[0], nx - 1), hi[1] = min(hi[1], ny - 1);  // (z: rows beyond the grid simply hold no key)
+    int a = 0;  // the rows of a layer are visited in ascending key order: every lower bound is searched from the previous one (gallop, then bisect)
+    // (a box of more than G layers — the host never launches one — would be walked by the group's last lane)
+    const int iz0 = lo[2] + g, iz1 = g == G - 1 ? hi[2] : min(iz0, hi[2]);
+    for (int iz = iz0; iz <= iz1 && cnt <= min_neighbors; iz++)
+      for (int iy = lo[1]; iy <= hi[1] && cnt <= min_neighbors; iy++) {
+        const long long row = (long long)iy * im[10] + (long long)iz * im[11];
+        const long long k0 = row + lo[0], k1 = row + hi[0];
+        if (k1 < 0 || k0 > 0xfffffffell) continue;
+        const unsigned key0 = (unsigned)max(k0, 0ll), key1 = (unsigned)min(k1, 0xfffffffell);
+        int b = a, step = a == 0 ? m : 1;  // (the first row: a plain bisection of the whole table)
+        while (b < m && ukeys[b] < key0) a = b + 1, b = min(b + step, m), step <<= 1;
+        while (a < b) {  // lower bound of key0 in [a, b)
+          const int mid = (a + b) >> 1;
+          if (ukeys[mid] < key0) a = mid + 1;
+          else b = mid;
+        }
+        for (; a < m && ukeys[a] <= key1 && cnt <= min_neighbors; a++) {
+          const float4 o = cen[a];
+          cnt += dist2f(q, o.x, o.y, o.z) < r2 ? 1 : 0;
+        }
+      }
+  }
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);  // (lane g == 0 ends with its group's total)
+  if (g == 0 && j < cap) keep[j] = (j < m && cnt > min_neighbors) ? 1u : 0u;
 }
 void launch_pf_grid_radius_flags(hipStream_t s, const float4* cen, const int* count, const unsigned* ukeys, const unsigned* meta, float inv_leaf, float radius, float r2,
                                  int min_neighbors, int cap, unsigned* keep) {
-  if (cap > 0)
-    hipLaunchKernelGGL(k_pf_grid_radius_flags, dim3((cap + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cen, count, ukeys, meta, inv_leaf, radius, r2, min_neighbors, cap, keep);
+  if (cap <= 0) return;
+  // layers of the r-box: floor((c + r) / leaf + 1e-3) - floor((c - r) / leaf - 1e-3) + 1 <= 2 r / leaf + 2 + 1 (the engine asks for r / leaf <= 4)
+  const int layers = (int)ceilf(2.f * radius * inv_leaf + 2.0e-3f) + 2;
+  const long long threads4 = (long long)cap * 4, threads8 = (long long)cap * 8, threads16 = (long long)cap * 16;
+  if (layers <= 4)
+    hipLaunchKernelGGL(k_pf_grid_radius_flags<4>, dim3((unsigned)((threads4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, cen, count, ukeys, meta, inv_leaf, radius, r2, min_neighbors, cap, keep);
+  else if (layers <= 8)
+    hipLaunchKernelGGL(k_pf_grid_radius_flags<8>, dim3((unsigned)((threads8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, cen, count, ukeys, meta, inv_leaf, radius, r2, min_neighbors, cap, keep);
+  else
+    hipLaunchKernelGGL(k_pf_grid_radius_flags<16>, dim3((unsigned)((threads16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, cen, count, ukeys, meta, inv_leaf, radius, r2, min_neighbors, cap, keep);
 }
 
 // ---- pcl::ApproximateVoxelGrid (apps/prefiltering_nodelet.cpp:59-63, scan_matching_odometry_nodelet.cpp:91-96) ------------------
