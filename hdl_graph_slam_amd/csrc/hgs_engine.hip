@@ -321,7 +321,8 @@ struct hgs_handle {
   int upload_trace = 0;
   int cov_split = 1;       // non-FROBENIUS regularisations: search kernel + k_cov_regularize (0: one kernel with the eigen-decomposition inline; HGS_COV_SPLIT, A/B runs)
   int resident_descs = 1;  // HGS_RESIDENT_DESCS=0: every stage uploads its descriptor array (A/B runs)
-  int knn_qpw_tiny = 0;   // queries per packet of k_knn_cov for launches below 32 k queries (0: 32 as for every small launch).  16 measured equal, 8 slower (profiles/r06_ab_resident_descs_qpw.log): off
+  int knn_qpw_tiny = -1;  // queries per packet of small k_knn_cov launches: -1 = by launch size (queries_per_wave), 0 = 32 as before round 6, 8 / 16 / 24 = below knn_tiny_below queries
+  int knn_tiny_below = 32768;
   int seed_grid = 1;    // targets of 1-NN searches get a seed grid (ensure_seed_grid); HGS_SEED_GRID=0 (A/B runs)
   int knn_replay = -1;  // k_knn_cov gather: -1 default (2), 0 tree walk, 1 leaf-log replay, 2 per-lane leaf lists; HGS_KNN_REPLAY (A/B runs, tests)
   int batch_lanes = 0;  // 0: open_lanes chooses (4; NDT_OMP above 32 problems 3; never more than the process's hardware-queue budget has room for); HGS_BATCH_LANES fixes it (A/B runs)
@@ -619,10 +620,19 @@ int upload_descs(hgs_handle* h, const std::vector<hgs_cloud*>& clouds, bool with
 // (one 120 k-point cloud is 1.8 waves per SIMD) and is bound by the dependent-load chain of a single walk; 32-query
 // packets walk fewer nodes and put more waves in flight (0.91 -> 0.66 ms for one 120 k-point cloud).  Large batches keep
 // 64 (least total work); the 1-NN kernels always do (no measurable gain from shorter packets there).
-// Round 6 tried `tiny`-query packets (16 / 8) for launches that cannot even give every SIMD one 32-query packet (an odometry source behind the KITTI prefilter:
-// 13.5 k points = 422 packets): 16 measures equal, 8 slower (profiles/r06_ab_resident_descs_qpw.log) — the option stays for A/B runs, default off.
-int queries_per_wave(size_t total_queries, int small, int tiny = 0) {
-  if (tiny > 0 && total_queries < (size_t)1024 * (size_t)small) return tiny;
+// Round 6, second visit to the question: a launch of a few packets per SIMD lasts as long as its SLOWEST packet, and those are the packets over sparse far
+// returns at ~4x the median's leaves (scripts/probes/knn_probe.py, profiles/r06_knn_probe_before.log).  Shorter packets split them — behind a full pre-fill
+// window (k_knn_cov<.., WINDOW>: the first attempt, 16 own points in front of unfilled lists, measured equal).  Same-box (profiles/r06_ab8_knn_short_packets.log):
+// the odometry source behind the KITTI prefilter (13.5 k points) hgs_align 0.390 -> 0.355 ms with 8-query packets (16: 0.361); one raw HDL-32E source (65 k)
+// 0.843 -> 0.787 ms with 16 (8: 0.808, 24: 0.795); the HDL-32E PAIR in one launch (131 k queries) loses with every short packet (covariance stage 0.234 -> 0.27-0.39 ms).
+// `tiny`: -1 = these tiers, 0 = none (32 as before), 8 / 16 / 24 = that packet below `tiny_below` queries (A/B runs, tests).
+int queries_per_wave(size_t total_queries, int small, int tiny = 0, size_t tiny_below = 0) {
+  if (tiny < 0) {
+    if (total_queries < (size_t)32768) return 8;
+    if (total_queries < (size_t)100000) return 16;
+  } else if (tiny > 0 && total_queries < tiny_below) {
+    return tiny;
+  }
   return total_queries >= (size_t)600000 ? 64 : small;
 }
 
@@ -698,11 +708,12 @@ int ensure_cov(hgs_handle* h, const std::vector<hgs_cloud*>& all, int k) {
   for (hgs_cloud* c : todo) max_n = std::max(max_n, (int)c->n_input);
   size_t total_q = 0;
   for (hgs_cloud* c : todo) total_q += c->n_input;
-  const int qpw = queries_per_wave(total_q, 32, h->knn_qpw_tiny);  // (32: >= k points in the pre-fill window)
+  int qpw = queries_per_wave(total_q, 32, h->knn_qpw_tiny, (size_t)h->knn_tiny_below);  // (32: >= k points in the pre-fill window; shorter packets borrow a window)
   // the leaf-log gather pays for batches of LiDAR keyframes, not for one or two (dense) clouds: see launch_knn_cov
   // pass 2 of k_knn_cov: per-lane leaf lists (mode 2; measured against the leaf-log replay and the second tree walk: 64 LiDAR clouds
   // 4.25 -> 4.0 ms, dense 1 M-point pair 1.46 -> 1.27 ms, one HDL-32E pair unchanged); HGS_KNN_REPLAY=0|1|2 forces a mode (tests, A/B)
   const int gather = h->knn_replay >= 0 ? h->knn_replay : 2;
+  if (qpw < 32 && (gather != 2 || k > 20)) qpw = 32;  // (the short-packet instantiation exists for the per-lane lists and k <= 20: launch_knn_cov)
   double* raw_stage = nullptr;
   if (h->prm.regularization_method != 0 && h->cov_split) {  // PLANE / MIN_EIG / ...: the eigen-decompositions in a kernel of their own (k_cov_regularize)
     HGS_HIP(h, h->cov_raw.reserve(todo.size() * (size_t)std::max(max_n, 1) * 6 * sizeof(double)));
@@ -1328,7 +1339,8 @@ int hgs_debug_set_option(hgs_handle* h, const char* key, int value) try {
   else if (k == "ndt_sort") h->ndt_sort = std::max(-1, std::min(1, value));
   else if (k == "cov_split") h->cov_split = value != 0 ? 1 : 0;
   else if (k == "resident_descs") h->resident_descs = value != 0 ? 1 : 0;
-  else if (k == "knn_qpw_tiny") h->knn_qpw_tiny = std::max(0, std::min(32, value & ~7));
+  else if (k == "knn_qpw_tiny") h->knn_qpw_tiny = value < 0 ? -1 : std::max(0, std::min(32, value & ~7));
+  else if (k == "knn_tiny_below") h->knn_tiny_below = std::max(0, value);
   else if (k == "seed_grid") h->seed_grid = value != 0 ? 1 : 0;
   else if (k == "knn_replay") h->knn_replay = std::max(-1, std::min(2, value));                           // -1: the engine chooses
   else if (k == "ndt_resident") h->ndt_resident_blocks = std::max(0, value);

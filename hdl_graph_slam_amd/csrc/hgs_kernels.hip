@@ -479,7 +479,7 @@ void launch_build_tree(hipStream_t s, const CloudDesc* descs, int ncloud, int ma
 // REG: 0 = FROBENIUS inline (the mode hdl_graph_slam runs by SURVEY A.2); 1 = any hgs_regularization inline (3x3 eigen-decomposition per point: the
 // compiler then needs > 96 VGPRs for the whole kernel); 2 = the neighbourhood covariance staged in fp64 (`raw`, 48 bytes per point) for
 // k_cov_regularize — the search keeps FROBENIUS's register budget and occupancy, the eigen-decompositions run in a streaming kernel of their own.
-template <int KMAX, int REG, int GATHER>
+template <int KMAX, int REG, int GATHER, bool WINDOW = false>
 __global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const CloudDesc* descs, int k, int qpw, int reg_method, double* __restrict__ raw, int raw_stride) {
   constexpr bool REG_GENERAL = REG == 1;
   constexpr bool REPLAY = GATHER == 1, LISTS = GATHER == 2;
@@ -502,24 +502,47 @@ __global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const Clou
   float* slot = walk_slots[threadIdx.x >> 6];  // the quad walk's parking area; its first 128 bytes stage the replayed records
   LeafLog log = {leaf_log[REPLAY ? threadIdx.x >> 6 : 0], REPLAY ? kKnnLeafLog : 0, 0};
   const int i0 = i - lane;
+  // the pre-fill window [win0, win0 + win_n): whole leaves that contain the packet's own points; at least 32 points (>= k for every k hdl_graph_slam uses)
+  // unless the cloud has fewer, at most 64 (39 when it is not the packet itself)
+  // WINDOW = false (packets of 32 or 64 queries): the window is the packet itself, as in rounds 2-5 — the general form below costs the 64-candidate batch
+  // 3.7 % of its covariance stage (3.53 -> 3.66 ms) and buys a 32- / 64-query packet nothing: its last packet is no longer the slowest wave, but the packets
+  // over sparse far returns are, at 4x the median's leaves (profiles/r06_ab7_knn_window.log).  WINDOW = true: launches with 16- / 8-query packets.
+  int win0 = i0, win_n = min(qpw, n - i0), win_leaves = qpw >> 3, order_lane = qpw >> 1;
+  F3 wp = q;
+  if (WINDOW) {
+    win0 = i0 & ~31, win_n = min(max(qpw, 32), n - win0);
+    if (win_n < 32 && win0 > 0) win0 = max(0, (n - 32) & ~7), win_n = n - win0;
+    if (i0 >= n) win0 = 0, win_n = 0;  // (a wave of idle lanes behind the cloud's end)
+    win_leaves = (win_n + kLeaf - 1) / kLeaf;
+    order_lane = max(0, min(qpw, n - i0)) >> 1;  // the packet's middle QUERY decides which child is nearest (an idle lane wants none)
+    const float4 wpp = lane < win_n ? d.pts[win0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    wp = F3{wpp.x, wpp.y, wpp.z};
+  }
+  const bool walk = WINDOW ? n > win_n : n > qpw;  // otherwise the window was the whole cloud
   float r2;
   int ties, list_cnt = 0;
+  HGS_PROBE_TIME(0);
   {
     KnnRadiusLane<KMAX, GATHER != 0, LISTS> L;
     L.init(live, active);
     L.list = &lane_lists[0][LISTS ? threadIdx.x : 0], L.stride = kBlock, L.cnt = 0, L.cap = kKnnLaneList;
-    // The wave's own 64 points (8 whole leaves of the Hilbert order) are every lane's first candidates: all-pairs
-    // through v_readlane, no memory traffic — the walk then starts with every list full and a bound within ~1.2x of
+    // The wave's window — its own 64 points (8 whole leaves of the Hilbert order) — holds every lane's first candidates: all-pairs
+    // through v_readlane — the walk then starts with every list full and a bound within ~1.2x of
     // the final radius instead of +inf, which is what keeps it from wandering (3x fewer insertions and leaves).
-    const int own = min(qpw, n - i0);
-    for (int jj = 0; jj < own; jj++) {
-      const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), jj)), py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), jj)),
-                  pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), jj));
+    // (WINDOW, above: a packet of fewer than 32 points — every one of a launch with 16- / 8-query packets, the last one of a cloud — takes the window of >= k
+    // points around it.  A launch of less than one packet per SIMD lasts as long as its slowest wave, and those are the packets over sparse far returns at
+    // ~4x the median's leaves (scripts/probes/knn_probe.py): shorter packets split them, but only behind a full window — with 16 own points the lists start
+    // unfilled and the walk wanders, which is why round 6's first attempt at 16-query packets measured equal.)
+    for (int jj = 0; jj < win_n; jj++) {
+      const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wp.x), jj)), py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wp.y), jj)),
+                  pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wp.z), jj));
       const float dd = dist2f(q, px, py, pz);
       if (__ballot(dd < L.worst()) != 0ull) L.insert_wave(dd < L.worst() ? dd : FLT_MAX);
     }
-    if (n > qpw)  // otherwise the own window was the whole cloud
-      wave_walk_quad(tv, L, q, slot, qpw >> 1, (unsigned)(tv.P + (i0 >> 3)), (unsigned)(qpw >> 3), REPLAY ? &log : nullptr);
+    HGS_PROBE_TIME(1);
+    if (walk)
+      wave_walk_quad(tv, L, q, slot, order_lane, (unsigned)(tv.P + (win0 >> 3)), (unsigned)win_leaves, REPLAY ? &log : nullptr);
+    HGS_PROBE_TIME(2);
     r2 = L.worst();
     list_cnt = L.cnt;
     int n_lt = 0;
@@ -534,14 +557,14 @@ __global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const Clou
   if (__ballot(active && ties > 1) == 0ull) {
     KnnGatherLane<1> L;
     L.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
-    if (LISTS && n > qpw && __ballot(active && list_cnt > kKnnLaneList) == 0ull) {
+    if (LISTS && walk && __ballot(active && list_cnt > kKnnLaneList) == 0ull) {
       // Every lane over ITS leaves, entry r of all lanes at once, each lane gathering its own 128-byte leaf record: first the wave's own
       // leaves whose box lies within the lane's radius (their eight boxes are two adjacent group records: one fetch, two box
       // evaluations — 3.9 of the 8 on average), then the leaves on its list.  ~11.5 rounds per wave instead of 8 lock-step visits + ~9
       // list rounds, and every lane's arithmetic is on a leaf that matters to it.
       const hgs_f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
-      const unsigned leaf0 = (unsigned)(i0 >> 3);
-      const int n_own = max(0, min(qpw >> 3, tv.P - (int)leaf0));
+      const unsigned leaf0 = (unsigned)(win0 >> 3);  // ("own" leaves = the window's: the walk skipped exactly those; <= 5 of them from any leaf on, or 8 from a multiple of 8)
+      const int n_own = max(0, min(win_leaves, tv.P - (int)leaf0));
       unsigned own_mask = 0;
       if (tv.P >= 8) {  // the own leaves are two aligned sibling groups of four
         const float v = reinterpret_cast<const float*>(tv.nodes + 8 * (size_t)(((unsigned)tv.P + leaf0) >> 2))[lane];
@@ -578,15 +601,15 @@ __global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const Clou
           L.visit_leaf(lo, hi, qx, qy, qz, (int)leaf * kLeaf);
         }
       }
-    } else if (REPLAY && n > qpw && log.count <= log.cap) {
+    } else if (REPLAY && walk && log.count <= log.cap) {
       // No second tree walk: every leaf with a point within r2 of some lane (box_d2 <= r2 <= the bound pass 1 had when it met the
       // leaf) is either one of the wave's own 8 leaves or in pass 1's log.  The records are fetched by index, so the next one is
       // in flight while the current one is summed — no dependent chain, no box tests.
       // (the wave's own leaves that exist: a tail wave of a tiny cloud would otherwise read leaf records past the array)
-      const int n_own = max(0, min(qpw >> 3, tv.P - (i0 >> 3))), total = n_own + log.count;
+      const int n_own = max(0, min(win_leaves, tv.P - (win0 >> 3))), total = n_own + log.count;
       const hgs_f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
       const int l32 = lane & 31;
-      unsigned leaf = n_own > 0 ? (unsigned)(i0 >> 3) : (total > 0 ? log.ids[0] - (unsigned)tv.P : 0u);  // leaf index (node id - P)
+      unsigned leaf = n_own > 0 ? (unsigned)(win0 >> 3) : (total > 0 ? log.ids[0] - (unsigned)tv.P : 0u);  // leaf index (node id - P)
       float v = reinterpret_cast<const float*>(tv.lpts + 8 * (size_t)leaf)[l32];
       for (int j = 0; j < total; j++) {
         __builtin_amdgcn_wave_barrier();  // the previous record's reads are issued before the slot is overwritten
@@ -596,13 +619,13 @@ __global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const Clou
         const hgs_f16v lo = r[0], hi = r[1];
         const unsigned this_leaf = leaf;
         if (j + 1 < total) {
-          leaf = j + 1 < n_own ? (unsigned)(i0 >> 3) + (unsigned)(j + 1) : log.ids[j + 1 - n_own] - (unsigned)tv.P;
+          leaf = j + 1 < n_own ? (unsigned)(win0 >> 3) + (unsigned)(j + 1) : log.ids[j + 1 - n_own] - (unsigned)tv.P;
           v = reinterpret_cast<const float*>(tv.lpts + 8 * (size_t)leaf)[l32];
         }
         L.visit_leaf(lo, hi, qx, qy, qz, (int)this_leaf * kLeaf);
       }
     } else {
-      wave_walk_quad(tv, L, q, slot, qpw >> 1);
+      wave_walk_quad(tv, L, q, slot, order_lane);
     }
     L.finish(d.pts);
     s1[0] = L.s1[0], s1[1] = L.s1[1], s1[2] = L.s1[2], found = L.found;
@@ -610,17 +633,18 @@ __global__ __launch_bounds__(kBlock) HGS_KNN_OCCUPANCY void k_knn_cov(const Clou
   } else {
     KnnGatherLane<4> L;
     L.init(active ? r2 : -1.f, ties, q.x, q.y, q.z);
-    wave_walk_quad(tv, L, q, slot, qpw >> 1);
+    wave_walk_quad(tv, L, q, slot, order_lane);
     L.finish(d.pts);
     for (int taken = 4; __ballot(active && ties > taken) != 0ull; taken += 4) {  // more than 4 at the k-th distance
       const bool more = active && ties > taken;
       L.rearm_ties(more ? r2 : -1.f, more ? ties - taken : 0);
-      wave_walk_quad(tv, L, q, slot, qpw >> 1);
+      wave_walk_quad(tv, L, q, slot, order_lane);
       L.finish(d.pts);
     }
     s1[0] = L.s1[0], s1[1] = L.s1[1], s1[2] = L.s1[2], found = L.found;
     s2 = Sym3{L.s2[0], L.s2[1], L.s2[2], L.s2[3], L.s2[4], L.s2[5]};
   }
+  HGS_PROBE_TIME(3);
   if (!active) return;
   if (REG == 2) {  // staged: k_cov_regularize finishes the point
     const Sym3 c = gicp_neighbour_cov(s1, s2, found, k, 0.0);
@@ -643,10 +667,24 @@ __global__ __launch_bounds__(kBlock) void k_cov_regularize(const CloudDesc* desc
   d.cov[2 * i] = make_float4((float)c.xx, (float)c.xy, (float)c.xz, (float)c.yy);
   d.cov[2 * i + 1] = make_float4((float)c.yz, (float)c.zz, 0.f, 0.f);
 }
+#ifdef HGS_KNN_PROBE
+extern "C" int hgs_debug_read_knn_probe(void* out, size_t bytes) {  // (measurement builds only) copies the probe out and clears it
+  if (bytes > sizeof(unsigned long long) * (1 << 16) * 8) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_probe), bytes) != hipSuccess) return -3;
+  void* dev = nullptr;
+  if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_knn_probe)) != hipSuccess || hipMemset(dev, 0, sizeof(unsigned long long) * (1 << 16) * 8) != hipSuccess) return -4;
+  return 0;
+}
+#endif
 template <int REG, int REPLAY>
 static void launch_knn_cov_t(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n, int k, int qpw, int reg_method, double* raw, int raw_stride) {
   const int tile_pts = (kBlock / 64) * qpw;
   const dim3 grid(HGS_GRID_X((max_n + tile_pts - 1) / tile_pts), ncloud), block(kBlock);
+  if (qpw < 32) {  // short packets (hgs_engine.hip asks for them with the per-lane lists only, k <= 20: the window is sized for that)
+    if (REPLAY == 2 && k <= 20) hipLaunchKernelGGL((k_knn_cov<20, REG, 2, true>), grid, block, 0, s, descs, k, qpw, reg_method, raw, raw_stride);
+    return;
+  }
   if (k <= 8) hipLaunchKernelGGL((k_knn_cov<8, REG, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method, raw, raw_stride);
   else if (k <= 16) hipLaunchKernelGGL((k_knn_cov<16, REG, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method, raw, raw_stride);
   else if (k <= 20) hipLaunchKernelGGL((k_knn_cov<20, REG, REPLAY>), grid, block, 0, s, descs, k, qpw, reg_method, raw, raw_stride);

@@ -284,6 +284,16 @@ __device__ __forceinline__ void wave_nn1(const BvhView& t, float* slots, const F
 // FLT_MAX is not found by an unbounded search (the exclusive bound is clamped to FLT_MAX so that empty boxes, whose distance
 // is +inf, are never wanted).
 typedef float hgs_f8v __attribute__((ext_vector_type(8)));
+// (measurement builds only, -DHGS_KNN_PROBE: scripts/probes/knn_probe.py — per-wave phase clocks and step counts of k_knn_cov; the product build compiles none of it)
+#ifdef HGS_KNN_PROBE
+__device__ unsigned long long g_knn_probe[(1 << 16) * 8];
+__device__ __forceinline__ unsigned knn_probe_wave() { return (((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 0xffffu; }
+#define HGS_PROBE_COUNT(kind) do { if ((__lane_id() & 63u) == 0u) g_knn_probe[knn_probe_wave() * 8 + 5 + (kind)] += 1ull; } while (0)
+#define HGS_PROBE_TIME(slot) do { if ((__lane_id() & 63u) == 0u) g_knn_probe[knn_probe_wave() * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define HGS_PROBE_COUNT(kind) ((void)0)
+#define HGS_PROBE_TIME(slot) ((void)0)
+#endif
 constexpr int kParkLevels = 4;                     // leaf quad + three group levels with a slot of their own
 constexpr int kParkSlots = kParkLevels + 1;        // + the slot all higher levels share
 constexpr int kParkFloats = kParkSlots * 128;      // wave-private LDS floats (2560 bytes)
@@ -445,6 +455,7 @@ __device__ __forceinline__ void wave_walk_quad(const BvhView& t, Lane& lane, con
       if (log->count < log->cap && (__lane_id() & 63u) == 0u) log->ids[log->count] = ldnode;
       log->count++;
     }
+    HGS_PROBE_COUNT(1);
     const hgs_f16v xy = *reinterpret_cast<const hgs_f16v*>(rec);
     const hgs_f16v zw = *reinterpret_cast<const hgs_f16v*>(rec + 16);
     lane.visit_leaf(xy, zw, qx, qy, qz, ((int)ldnode - t.P) * kLeaf);
@@ -472,6 +483,7 @@ __device__ __forceinline__ void wave_walk_quad(const BvhView& t, Lane& lane, con
   const auto slot_of = [&](int depth) { const int s = (k - depth) >> 1; return park + 128 * (s < kParkLevels ? s : kParkLevels); };
   fetch_quad(t.nodes, slot_of(bd));
   for (;;) {
+    HGS_PROBE_COUNT(0);
     {
       const float* rec = slot_of(bd) + 32 * (node & 3u);
       const hgs_f16v lo = *reinterpret_cast<const hgs_f16v*>(rec);
@@ -572,8 +584,8 @@ struct KnnRadiusLane {
     }
 #pragma unroll
     for (int l = 0; l < 4; l++) {
-      if (__ballot(dd[l].x < worst()) != 0ull) insert_wave(dd[l].x < worst() ? dd[l].x : FLT_MAX);
-      if (__ballot(dd[l].y < worst()) != 0ull) insert_wave(dd[l].y < worst() ? dd[l].y : FLT_MAX);
+      if (__ballot(dd[l].x < worst()) != 0ull) { HGS_PROBE_COUNT(2); insert_wave(dd[l].x < worst() ? dd[l].x : FLT_MAX); }
+      if (__ballot(dd[l].y < worst()) != 0ull) { HGS_PROBE_COUNT(2); insert_wave(dd[l].y < worst() ? dd[l].y : FLT_MAX); }
     }
   }
 };

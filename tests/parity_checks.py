@@ -118,6 +118,31 @@ def check_cov_split_equals_inline(make_engine):
             os.environ["HGS_ENGINE_OPTIONS"] = old
 
 
+def check_covariances_with_short_packets(make_engine):
+    """k_knn_cov's pre-fill window: clouds whose LAST packet holds 1 .. 31 points (it borrows the leaves in front of it so that its lists start full), clouds
+    smaller than a window, and launches with 16- / 8-query packets (engine option knn_qpw_tiny: every packet then borrows), under all three gather passes."""
+    import os
+    scene = synth.make_scene(4)
+    scan = synth.scan(scene, "VLP-16", synth.pose_matrix([0, 0, 0], [0, 0, 0]), 17)
+    rng = np.random.default_rng(11)
+    old = os.environ.get("HGS_ENGINE_OPTIONS")
+    try:
+        for tiny, replay, sizes in ((0, 2, (21, 31, 33, 39, 40, 63, 65, 97, 1029, 2051)), (16, 2, (33, 47, 1029)), (8, 2, (41, 1029)), (0, 1, (33, 1029)), (16, 1, (47,)),
+                                    (0, 0, (33, 1029)), (8, 0, (41,))):
+            os.environ["HGS_ENGINE_OPTIONS"] = f"knn_qpw_tiny={tiny},knn_replay={replay}"
+            for n in sizes:
+                for cloud in (scan[:n], synth.to_xyzi(rng.uniform(-3, 3, (n, 3)).astype(np.float32))):
+                    e = make_engine(O.default_params(O.HGS_FAST_GICP))
+                    e.setInputTarget(cloud)
+                    check_covariances(e, cloud, 20)
+                    e.close()
+    finally:
+        if old is None:
+            os.environ.pop("HGS_ENGINE_OPTIONS", None)
+        else:
+            os.environ["HGS_ENGINE_OPTIONS"] = old
+
+
 def check_covariances_with_outliers(make_engine):
     for k in (20, 48):
         p = O.default_params(O.HGS_FAST_GICP)

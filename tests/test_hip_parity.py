@@ -78,6 +78,10 @@ def test_split_regularisation_kernel_equals_the_inline_one():
     PC.check_cov_split_equals_inline(_hip)
 
 
+def test_covariances_of_short_last_packets_and_short_packet_launches():
+    PC.check_covariances_with_short_packets(_hip)
+
+
 def test_covariances_when_the_leaf_log_overflows():
     """k_knn_cov with lanes whose k-NN ball covers hundreds of leaves: the gather pass falls back from the logged leaves to the tree."""
     PC.check_covariances_with_outliers(_hip)

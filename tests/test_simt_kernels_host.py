@@ -93,6 +93,10 @@ def test_split_regularisation_kernel_equals_the_inline_one():
     PC.check_cov_split_equals_inline(_engine)
 
 
+def test_covariances_of_short_last_packets_and_short_packet_launches():
+    PC.check_covariances_with_short_packets(_engine)
+
+
 def test_covariances_when_the_leaf_log_overflows():
     PC.check_covariances_with_outliers(_engine)
 
