@@ -86,6 +86,7 @@ struct Progress {
   int pad;
 };
 
+constexpr int kFusedRoundMaxProblems = 4;  // launches of at most this many problems may run the LM round in two launches (control steps replicated per block)
 constexpr int kBlock = 256;
 constexpr int kKnnLaneList = 16;          // leaves a lane of k_knn_cov remembers as its own candidates' (more: the wave falls back to the replay / walk)
 constexpr int kKnnLeafLog = 128;           // leaves pass 1 of k_knn_cov remembers per wave for pass 2 (more: pass 2 walks the tree)
@@ -109,6 +110,11 @@ void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
                        int tile_points /* points per block of the linearize kernel that filled `partials` */);
 void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B);
+// two launches per LM round (hgs_kernels.hip, "two launches per LM round"): the control steps replicated in every block, states ping-pong between two buffers
+void launch_gicp_linearize_round2(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states_in, GicpState* states_out, GicpConsts c, double* partials,
+                                  const double* partials_err, int max_blocks, int B, int qpw, Progress prog);
+void launch_gicp_error_round2(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states_in, GicpState* states_out, GicpConsts c, const double* partials,
+                              double* partials_err, int max_blocks, int B, int lin_tile_points);
 void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B, Progress prog);
 void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out, int B);
 

@@ -319,6 +319,8 @@ struct hgs_handle {
   // launches fill the device on their own and two chains are enough to cover each other's solves and tails.
   int prefilter_fast = 1;  // hgs_prefilter: distance filter inside the voxel grid's kernels, RadiusOutlierRemoval on the voxel grid (0: the separate passes + search tree; A/B, tests)
   int upload_trace = 0;
+  int fused_rounds = 1;    // launches of <= kFusedRoundMaxProblems GICP problems of at most fused_rounds_below points each: the LM round in two launches (control steps replicated per block; 0: four launches per round)
+  int fused_rounds_below = 262144;
   int cov_split = 1;       // non-FROBENIUS regularisations: search kernel + k_cov_regularize (0: one kernel with the eigen-decomposition inline; HGS_COV_SPLIT, A/B runs)
   int resident_descs = 1;  // HGS_RESIDENT_DESCS=0: every stage uploads its descriptor array (A/B runs)
   int knn_qpw_tiny = -1;  // queries per packet of small k_knn_cov launches: -1 = by launch size (queries_per_wave), 0 = 32 as before round 6, 8 / 16 / 24 = below knn_tiny_below queries
@@ -1114,11 +1116,16 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     const bool voxel = method == HGS_FAST_VGICP;
     const GicpConsts c = gicp_consts(h->prm);
     const VgicpConsts vc = vgicp_consts(h->prm);
-    HGS_HIP(h, h->states.reserve((size_t)B * sizeof(GicpState)));
+    // A launch of a few problems (a single registration: the odometry step, config 2) is a chain of ~4 us kernels in which the two per-problem control launches
+    // of an LM round cost as much as its two point kernels: such launches run the round in TWO launches, the control steps replicated in every block of
+    // k_gicp_linearize<true> / k_gicp_error<true> (hgs_kernels.hip).  The states then alternate between two buffers; a whole round leaves them in the first.
+    const bool round2 = !voxel && h->fused_rounds && B <= kFusedRoundMaxProblems && max_n <= h->fused_rounds_below;
+    HGS_HIP(h, h->states.reserve((size_t)B * sizeof(GicpState) * (round2 ? 2 : 1)));
     GicpState* st = h->states.as<GicpState>();
+    GicpState* st_other = st + B;
     const TargetView tv = target_view(tgt);
     const NdtTargetView vtv = voxel ? vgicp_target_view(tgt) : NdtTargetView{};
-    const long max_rounds = (long)std::max(1, c.max_iterations) * std::max(1, c.lm_max_iterations) + 2;
+    const long max_rounds = (long)std::max(1, c.max_iterations) * std::max(1, c.lm_max_iterations) + 2 + (round2 ? 1 : 0);  // (round2: a round's accept / reject runs in the next round's first kernel)
     std::vector<BatchLane> lanes;
     HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
     auto finish_lane = [&](BatchLane& L) {
@@ -1129,6 +1136,15 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       const CloudDesc* dd = d_descs + L.b0;
       GicpState* ls = st + L.b0;
+      if (round2) {
+        {
+          StageTimer tm(h, HGS_STAGE_LINEARIZE);
+          launch_gicp_linearize_round2(L.stream, dd, tv, ls, st_other + L.b0, c, L.partials, L.partials_err, max_blocks, L.B, qpw, L.prog);
+        }
+        StageTimer tm(h, HGS_STAGE_ERROR);
+        launch_gicp_error_round2(L.stream, dd, tv, st_other + L.b0, ls, c, L.partials, L.partials_err, max_blocks, L.B, nn_tile);
+        return;
+      }
       {
         StageTimer tm(h, HGS_STAGE_LINEARIZE);
         if (voxel) launch_vgicp_linearize(L.stream, dd, vtv, ls, vc, L.partials, max_blocks, L.B);
@@ -1338,6 +1354,8 @@ int hgs_debug_set_option(hgs_handle* h, const char* key, int value) try {
   else if (k == "lane_start") h->lane_start = value != 0 ? 1 : 0;
   else if (k == "ndt_sort") h->ndt_sort = std::max(-1, std::min(1, value));
   else if (k == "cov_split") h->cov_split = value != 0 ? 1 : 0;
+  else if (k == "fused_rounds") h->fused_rounds = value != 0 ? 1 : 0;
+  else if (k == "fused_rounds_below") h->fused_rounds_below = std::max(0, value);
   else if (k == "resident_descs") h->resident_descs = value != 0 ? 1 : 0;
   else if (k == "knn_qpw_tiny") h->knn_qpw_tiny = value < 0 ? -1 : std::max(0, std::min(32, value & ~7));
   else if (k == "knn_tiny_below") h->knn_tiny_below = std::max(0, value);

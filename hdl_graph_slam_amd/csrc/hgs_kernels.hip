@@ -846,19 +846,62 @@ __device__ __forceinline__ void packet_nn1(const BvhView& tv, float* park, const
   }
 }
 
-// (Round 6 measured "fused tails" — the LM control steps run by the last block of a problem in the tail of k_gicp_linearize / k_gicp_error, two launches
-// per round instead of four — and dropped them: every block has to make its tile partial visible device-wide before it takes its ticket, and on a chip whose
-// L2 is per XCD that release is an L2 write-back per BLOCK: config 2 (254 tiles) 0.886 -> 1.139 ms, the 53-tile odometry source unchanged.  A kernel
-// boundary does that write-back once.  profiles/r06_ab_fused_tails_seed2.log)
+// ---- two launches per LM round for single registrations (round 6) ---------------------------------------------------------------------------------
+// A single registration (the odometry step, config 2) is a chain of ~4 us kernels: the two per-problem control launches of an LM round (k_gicp_solve,
+// k_gicp_decide) cost as much as its two point kernels.  Handing the control step to ONE block inside the point kernel ("fused tails": the last block
+// of a problem, found by a ticket) was built twice and loses twice: with a fence per block (L2 write-back + invalidate on a chip with one L2 per XCD)
+// config 2 went 0.886 -> 1.139 ms (profiles/r06_ab_fused_tails_seed2.log); fence-free (device-scope stores / loads of the partials, relaxed ticket —
+// bitwise identical, profiles/r06_ab10_fused_tails_fence_free.{log,patch}) 0.888 -> 0.905 ms: store -> ticket -> coherent loads is a chain of three
+// memory round trips, which is what a kernel boundary costs.  What works without ANY hand-over inside a kernel is to REPLICATE the control step: every
+// block of k_gicp_linearize<true> first runs the accept / reject step of the previous round on its own copy of the state (the same code on the same
+// partials: every block arrives at the same bits), every block of k_gicp_error<true> the solve of the linearisation just made; block 0 of a problem
+// writes the state out — into the OTHER of two state buffers, so that a block starting late never reads a state that has already been advanced.
+// Launches of <= kFusedRoundMaxProblems problems below the engine's size limit only: a 5 us serial step repeated by 250 blocks is latency nobody
+// waits for, repeated by 30 000 it is throughput.
+__device__ __forceinline__ void gicp_state_load(GicpState& st, const GicpState* src) {
+  static_assert(sizeof(GicpState) % sizeof(double) == 0 && sizeof(GicpState) / sizeof(double) <= kBlock, "state copied one double per thread");
+  if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(&st)[threadIdx.x] = reinterpret_cast<const double*>(src)[threadIdx.x];
+}
+__device__ __forceinline__ void gicp_state_store(GicpState* dst, const GicpState& st) {
+  if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(dst)[threadIdx.x] = reinterpret_cast<const double*>(&st)[threadIdx.x];
+}
+
 // update_correspondences + linearize fused: per source point 1-NN in the target tree, Mahalanobis matrix,
 // 6x6 normal-equation terms; wave shuffle reduction, one LDS row per wave, the last wave of the block adds the rows.
 // Algorithmic bytes per source point: 16 (a_i) + 24 (C_A) + 4 (corr) + 16 (b_j) + 24 (C_B) = 84.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINEARIZE_WAVES))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
-                                                           double* __restrict__ partials, int max_blocks, int qpw) {
+// ROUND2 (k_gicp_linearize<true>): states = the buffer the previous kernel wrote, states_out = the other one; partials_err = the trial errors of the
+// previous k_gicp_error<true>; the accept / reject step (gicp_decide_wave's arithmetic, in its order) runs first, in every block.
+template <bool ROUND2>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ROUND2 ? 4 : HGS_LINEARIZE_WAVES))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
+                                                           double* __restrict__ partials, int max_blocks, int qpw, GicpState* states_out,
+                                                           const double* __restrict__ partials_err, Progress prog) {
   const int b = blockIdx.y;
-  if (states[b].phase != GICP_LINEARIZE) return;
+  __shared__ GicpState st2;                         // ROUND2: this block's copy of the problem's state
+  __shared__ double ws2[kGicpControlWorkspace];
+  if constexpr (!ROUND2) {
+    if (states[b].phase != GICP_LINEARIZE) return;
+  }
   const CloudDesc d = descs[b];
   const int n = d.meta->nvalid;
+  if constexpr (ROUND2) {
+    const int phase_in = states[b].phase;  // (block-uniform)
+    gicp_state_load(st2, states + b);
+    double s = 0;
+    if (phase_in == GICP_TRY && threadIdx.x < 64) {
+      const int ntiles_err = (n + kBlock - 1) / kBlock;
+      const double* pe = partials_err + (size_t)b * max_blocks;
+      for (int t = threadIdx.x; t < ntiles_err; t += 64) s += pe[t];
+      s = wave_sum(s);
+    }
+    __syncthreads();
+    if (phase_in == GICP_TRY && threadIdx.x == 0) gicp_after_error(st2, s, c, ws2);
+    __syncthreads();
+    if (blockIdx.x == 0) {
+      gicp_state_store(states_out + b, st2);
+      if (threadIdx.x == 0) progress_tick(prog, phase_in == GICP_TRY && st2.phase == GICP_DONE);  // (k_gicp_decide's tick: once per problem and round)
+    }
+    if (st2.phase != GICP_LINEARIZE) return;
+  }
   const int tile_pts = (kBlock / 64) * qpw * kNW;
   const int ntiles = (n + tile_pts - 1) / tile_pts;
   const int tile = xcd_tile(blockIdx.x, ntiles);
@@ -871,7 +914,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINE
   // the wave's index lives in an SGPR and the lane id is recomputed after the search: nothing about the thread's identity is
   // kept in (or spilled from) a VGPR across the walk
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const Pose T = states[b].x0;
+  const Pose T = ROUND2 ? st2.x0 : states[b].x0;
   float Tf[12];
   pose_to_float(T, Tf);
   static_assert(kNW == 1, "one packet of 64 consecutive source points per wave");
@@ -920,7 +963,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HGS_LINE
 }
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
                            int max_blocks, int B, int qpw) {
-  hipLaunchKernelGGL(k_gicp_linearize, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw);
+  hipLaunchKernelGGL(k_gicp_linearize<false>, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw, (GicpState*)nullptr,
+                     (const double*)nullptr, Progress{});
+}
+void launch_gicp_linearize_round2(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states_in, GicpState* states_out, GicpConsts c, double* partials,
+                                  const double* partials_err, int max_blocks, int B, int qpw, Progress prog) {
+  hipLaunchKernelGGL(k_gicp_linearize<true>, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states_in, c, partials, max_blocks, qpw, states_out, partials_err, prog);
 }
 
 // The LM control step behind a linearisation, run by a whole 256-thread block: fixed-order tile reduction, then ONE lane factorises and steps.  The
@@ -952,12 +1000,34 @@ void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states,
 }
 
 // compute_error(xi): same correspondences, Mahalanobis matrices of the linearisation pose x0, residuals at xi.
+// ROUND2 (k_gicp_error<true>): the LM solve of the linearisation the previous k_gicp_linearize<true> made (gicp_solve_block's arithmetic, in its order)
+// runs first, in every block; `partials` / lin_tile_points: that kernel's tile partials and tiling.
+template <bool ROUND2>
 __global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, TargetView tgt, const GicpState* states, double* __restrict__ partials_err,
-                                                       int max_blocks) {
+                                                       int max_blocks, GicpConsts c, GicpState* states_out, const double* __restrict__ partials, int lin_tile_points) {
   const int b = blockIdx.y;
-  if (states[b].phase != GICP_TRY) return;
+  __shared__ GicpState st2;
+  __shared__ double ws2[kGicpControlWorkspace];
+  __shared__ double acc2[kAcc];
+  __shared__ double scratch2[kSolveBlock];
+  if constexpr (!ROUND2) {
+    if (states[b].phase != GICP_TRY) return;
+  }
   const CloudDesc d = descs[b];
   const int n = d.meta->nvalid;
+  if constexpr (ROUND2) {
+    static_assert(kSolveBlock == kBlock, "reduce_tiles runs on the point kernel's block");
+    const int phase_in = states[b].phase;  // (block-uniform)
+    gicp_state_load(st2, states + b);
+    if (phase_in == GICP_LINEARIZE) {
+      const int ntiles_lin = (n + lin_tile_points - 1) / lin_tile_points;
+      reduce_tiles<kAcc>(partials + (size_t)b * max_blocks * kAcc, ntiles_lin, acc2, scratch2);  // (ends with a barrier: the state copy is complete)
+      if (threadIdx.x == 0) gicp_after_linearize(st2, acc2, c, ws2);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) gicp_state_store(states_out + b, st2);
+    if (st2.phase != GICP_TRY) return;
+  }
   const int ntiles = (n + kBlock - 1) / kBlock;
   if ((int)blockIdx.x >= ntiles) return;
   const int tile = (int)blockIdx.x;
@@ -967,8 +1037,8 @@ __global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, T
   if (i < n) {
     const int j = d.corr[i];
     if (j >= 0) {
-      const Pose T0 = states[b].x0;
-      const Pose Ti = states[b].xi;
+      const Pose T0 = ROUND2 ? st2.x0 : states[b].x0;
+      const Pose Ti = ROUND2 ? st2.xi : states[b].xi;
       const double R[9] = {T0.m[0], T0.m[1], T0.m[2], T0.m[4], T0.m[5], T0.m[6], T0.m[8], T0.m[9], T0.m[10]};
       const Sym3 M = gicp_mahalanobis(R, load_cov(d.cov, i), load_cov(tgt.cov, j));
       const float4 a = d.pts[i], bp = tgt.pts[j];
@@ -978,7 +1048,11 @@ __global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, T
   block_reduce_store<1>(&err, partials_err + (size_t)b * max_blocks + tile, lds);
 }
 void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B) {
-  hipLaunchKernelGGL(k_gicp_error, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks);
+  hipLaunchKernelGGL(k_gicp_error<false>, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks, GicpConsts{}, (GicpState*)nullptr, (const double*)nullptr, 0);
+}
+void launch_gicp_error_round2(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states_in, GicpState* states_out, GicpConsts c, const double* partials,
+                              double* partials_err, int max_blocks, int B, int lin_tile_points) {
+  hipLaunchKernelGGL(k_gicp_error<true>, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states_in, partials_err, max_blocks, c, states_out, partials, lin_tile_points);
 }
 
 // The LM accept / reject step behind compute_error, run by ONE wave (the first 64 threads of the calling block; the others only pass the barriers):

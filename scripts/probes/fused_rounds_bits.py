@@ -1,0 +1,36 @@
+"""Fused LM tails (engine option fused_rounds=1) against the four-launch round on the same engine and the same pairs: final pose, iteration count and LM tries must be
+bitwise the same (the control steps run the same code on the same partials in the same order), every repetition — a partial read before it arrived would show here."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hdl_graph_slam_amd import synth  # noqa: E402
+from hdl_graph_slam_amd.registrations import select_registration_method  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+bad = 0
+total = 0
+for sensor, seed, ds in (("HDL-32E", 1, None), ("VLP-16", 2, 0.2), ("HDL-64E", 3, 0.25), ("VLP-16", 4, None)):
+    tgt, src, T = synth.make_pair(sensor, seed, downsample=ds)
+    for reg_method in ("FROBENIUS", "PLANE"):
+        reg = select_registration_method({"registration_method": "FAST_GICP", "reg_regularization_method": reg_method}, device_id=0)
+        reg.setInputTarget(tgt)
+        reg.setInputSource(src)
+        reg.set_option("fused_rounds", 0)
+        ref = reg.align(np.eye(4))
+        ref_bits = (ref.matrix().tobytes(), ref.iterations, ref.converged)
+        fit_ref = reg.getFitnessScore()
+        for rep in range(reps):
+            reg.set_option("fused_rounds", 1)
+            reg.setInputSource(src)  # cold: the correspondences of the previous align are gone
+            r = reg.align(np.eye(4))
+            total += 1
+            if (r.matrix().tobytes(), r.iterations, r.converged) != ref_bits or reg.getFitnessScore() != fit_ref:
+                bad += 1
+                print("MISMATCH", sensor, seed, reg_method, rep, r.iterations, ref.iterations, np.abs(r.matrix() - ref.matrix()).max())
+        print(sensor, seed, reg_method, "points", len(src), "iterations", ref.iterations, "converged", ref.converged)
+        reg.close()
+print("fused_rounds_bits:", total - bad, "of", total, "identical")
+sys.exit(1 if bad else 0)

@@ -118,6 +118,62 @@ def check_cov_split_equals_inline(make_engine):
             os.environ["HGS_ENGINE_OPTIONS"] = old
 
 
+def check_two_launch_rounds_equal_four_launch_rounds(make_engine, reps=3):
+    """Launches of <= 4 GICP problems run an LM round in TWO launches, the control steps replicated in every block of k_gicp_linearize<true> /
+    k_gicp_error<true> and the states alternating between two buffers (engine option fused_rounds, the default), against the four-launch round
+    (fused_rounds=0) on the same engine: the same code on the same partials in the same order — poses, iteration counts, LM tries, errors and fitness
+    scores are identical bits.  Covers an accepted-at-once loop, the LM rejection path (several error / decide rounds per linearisation), an empty source,
+    batches of 1 / 3 / 4 / 5 candidates (5: above the limit, i.e. the four-launch round under the option) and the size limit."""
+    tgt, src, T = synth.make_pair("VLP-16", 1, downsample=0.3)
+    tgt2, src2, T2 = synth.make_pair("HDL-32E", 4, downsample=0.4)
+    p_lm = O.default_params(O.HGS_FAST_GICP)
+    p_lm.max_correspondence_distance = 1.0
+    p_lm.transformation_epsilon, p_lm.rotation_epsilon = 1e-5, 1e-6
+    p_lm.lm_init_lambda_factor = 1e-12
+    hard = T @ synth.pose_matrix([0.8, 0.5, 0.1], [0.01, 0.01, 0.08])
+    for params, guess in ((O.default_params(O.HGS_FAST_GICP), np.eye(4)), (p_lm, hard)):
+        e = make_engine(params)
+        e.setInputTarget(tgt)
+        runs = {}
+        for fused in (0, 1, 1, 0) + (1,) * reps:
+            e.set_option("fused_rounds", fused)
+            e.setInputSource(src)  # (cold: no correspondences left over from the run before)
+            r = e.align(guess)
+            fit = e.getFitnessScore()
+            runs.setdefault(fused, []).append((bytes(r.final_transformation), r.converged, r.iterations, r.lm_tries, r.error, fit))
+        assert all(x == runs[0][0] for x in runs[0] + runs[1]), (runs[0][0][1:], [x[1:] for x in runs[1]])
+        assert runs[0][0][2] >= 1
+        # an empty source: block 0 runs the control steps on zero partials
+        empty = src[:0]
+        out = []
+        for fused in (0, 1):
+            e.set_option("fused_rounds", fused)
+            e.setInputSource(empty)
+            r = e.align(guess)
+            out.append((bytes(r.final_transformation), r.converged, r.iterations, r.lm_tries))
+        assert out[0] == out[1]
+        # the size limit: a source above it takes the four-launch round under the option
+        e.set_option("fused_rounds", 1)
+        e.set_option("fused_rounds_below", len(src) - 1)
+        e.setInputSource(src)
+        r = e.align(guess)
+        assert (bytes(r.final_transformation), r.converged, r.iterations, r.lm_tries, r.error, e.getFitnessScore()) == runs[0][0]
+        e.set_option("fused_rounds_below", 262144)
+        # batches: one lane, several lanes, above the limit
+        clouds = [e.upload(c) for c in (src, src2, src[::2], src2[::3], src[5::3])]
+        guesses = [guess, T2, np.eye(4), T2, guess]
+        for n in (1, 3, 4, 5):
+            recs = []
+            for fused in (0, 1, 1):
+                e.set_option("fused_rounds", fused)
+                rec, best = e.loop_match_batch(clouds[:n], [np.asarray(g, np.float32) for g in guesses[:n]])
+                recs.append((rec.tobytes(), best))
+            assert recs[0] == recs[1] == recs[2], n
+        for c in clouds:
+            c.close()
+        e.close()
+
+
 def check_covariances_with_short_packets(make_engine):
     """k_knn_cov's pre-fill window: clouds whose LAST packet holds 1 .. 31 points (it borrows the leaves in front of it so that its lists start full), clouds
     smaller than a window, and launches with 16- / 8-query packets (engine option knn_qpw_tiny: every packet then borrows), under all three gather passes."""

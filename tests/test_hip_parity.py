@@ -82,6 +82,11 @@ def test_covariances_of_short_last_packets_and_short_packet_launches():
     PC.check_covariances_with_short_packets(_hip)
 
 
+@pytest.mark.gpu
+def test_two_launch_lm_rounds_equal_the_four_launch_rounds():
+    PC.check_two_launch_rounds_equal_four_launch_rounds(_hip, reps=20)
+
+
 def test_covariances_when_the_leaf_log_overflows():
     """k_knn_cov with lanes whose k-NN ball covers hundreds of leaves: the gather pass falls back from the logged leaves to the tree."""
     PC.check_covariances_with_outliers(_hip)

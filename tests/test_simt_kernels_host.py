@@ -97,6 +97,10 @@ def test_covariances_of_short_last_packets_and_short_packet_launches():
     PC.check_covariances_with_short_packets(_engine)
 
 
+def test_two_launch_lm_rounds_equal_the_four_launch_rounds():
+    PC.check_two_launch_rounds_equal_four_launch_rounds(_engine, reps=1)
+
+
 def test_covariances_when_the_leaf_log_overflows():
     PC.check_covariances_with_outliers(_engine)
 
