@@ -307,7 +307,8 @@ struct hgs_handle {
   hipStream_t lane_stream[7] = {};  // kMaxLanes - 1
   hipEvent_t lane_event[8] = {};
   int lane_start = 1;                // 1: the host synchronises before it releases the lanes of a batch (open_lanes); HGS_LANE_START=0: not (A/B runs)
-  int nn_qpw = 0;  // 0: chosen per launch (nn_queries_per_wave)
+  int nn_qpw = 0;  // queries per packet of k_gicp_linearize in the two-launch LM rounds: 0 = by launch size (run_batch), 16 / 32 / 64
+  int nn_qpw16_below = 64, nn_qpw32_below = 0;  // ... 16 up to this many 256-point tiles in the launch, 32 up to that many
   // levels of the Hilbert curve the index sort compares (HGS_HILBERT_LEVELS, A/B runs; 16 = all 48 bits, rounds 1-3).  64 x 119 k batch, index stage / step:
   // 16 -> 0.915 / 11.99 ms, 13 -> 0.83 / 11.93, 11 -> 0.75 / 11.91, 10 -> 0.75 / 12.1, 9 -> 0.75 / 12.7 (the walks slow down once a cell of the finest compared
   // level holds many points): 13 = 1/8192 of the cloud's extent (2.4 cm on a 200 m scan), one radix pass less for a batch and two for a pair
@@ -1101,9 +1102,19 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   size_t total_q = 0;
   for (hgs_cloud* c : sources) total_q += c->n_input;
   (void)total_q;
-  const int qpw = h->nn_qpw > 0 ? h->nn_qpw : 64;  // round 2 measured: 16- or 32-query packets do not shorten a single registration's linearize (97 -> 90 us) and cost the batch
+  const int qpw = 64;  // queries per packet of the 1-NN kernels; shorter packets cost a batch ~13 % more work (round 2) ...
   const int nn_tile = (kBlock / 64) * qpw * kNW;                 // points per block of k_gicp_linearize / k_fitness (their own tiling formula)
-  const int max_blocks = std::max(1, (max_n + nn_tile - 1) / nn_tile);  // >= the tile count of every kernel of the loop
+  // ... but a launch of a FEW blocks lasts as long as one packet walk, and a shorter packet walks fewer nodes: the two-launch LM rounds of a small single
+  // registration run k_gicp_linearize<true> with 16- / 32-query packets, whose last wave per block redoes the 64-point wave rows so that no bit of the
+  // result depends on the packet size (hgs_kernels.hip).  Same-box (profiles/r06_ab12_nn_qpw.log, r06_ab13): the 13.5 k-point odometry source hgs_align
+  // 0.347 -> 0.31 ms with 16; the 65 k-point HDL-32E source is best with 64.  nn_qpw (option): 0 = by launch size, 16 / 32 / 64 = that packet.
+  const bool gicp_round2 = method == HGS_FAST_GICP && h->fused_rounds && B <= kFusedRoundMaxProblems && max_n <= h->fused_rounds_below;
+  const long tiles64 = (long)B * ((max_n + nn_tile - 1) / nn_tile);
+  const int lin_qpw = !gicp_round2 ? 64 : h->nn_qpw > 0 ? h->nn_qpw : tiles64 <= (long)h->nn_qpw16_below ? 16 : tiles64 <= (long)h->nn_qpw32_below ? 32 : 64;
+  const int lin_tile = (kBlock / 64) * lin_qpw * kNW;
+  const int lin_blocks = std::max(1, (max_n + lin_tile - 1) / lin_tile);
+  const int max_blocks = std::max(1, lin_qpw < 64 ? (max_n + 63) / 64 : (max_n + nn_tile - 1) / nn_tile);  // >= the tile (row) count of every kernel of the loop
+  const int err_blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
   const CloudDesc* d_descs = nullptr;
   HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
   HGS_HIP(h, h->guesses.reserve((size_t)B * 16 * sizeof(float)));
@@ -1119,7 +1130,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     // A launch of a few problems (a single registration: the odometry step, config 2) is a chain of ~4 us kernels in which the two per-problem control launches
     // of an LM round cost as much as its two point kernels: such launches run the round in TWO launches, the control steps replicated in every block of
     // k_gicp_linearize<true> / k_gicp_error<true> (hgs_kernels.hip).  The states then alternate between two buffers; a whole round leaves them in the first.
-    const bool round2 = !voxel && h->fused_rounds && B <= kFusedRoundMaxProblems && max_n <= h->fused_rounds_below;
+    const bool round2 = gicp_round2;
     HGS_HIP(h, h->states.reserve((size_t)B * sizeof(GicpState) * (round2 ? 2 : 1)));
     GicpState* st = h->states.as<GicpState>();
     GicpState* st_other = st + B;
@@ -1139,10 +1150,10 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       if (round2) {
         {
           StageTimer tm(h, HGS_STAGE_LINEARIZE);
-          launch_gicp_linearize_round2(L.stream, dd, tv, ls, st_other + L.b0, c, L.partials, L.partials_err, max_blocks, L.B, qpw, L.prog);
+          launch_gicp_linearize_round2(L.stream, dd, tv, ls, st_other + L.b0, c, L.partials, L.partials_err, max_blocks, lin_blocks, L.B, lin_qpw, L.prog);
         }
         StageTimer tm(h, HGS_STAGE_ERROR);
-        launch_gicp_error_round2(L.stream, dd, tv, st_other + L.b0, ls, c, L.partials, L.partials_err, max_blocks, L.B, nn_tile);
+        launch_gicp_error_round2(L.stream, dd, tv, st_other + L.b0, ls, c, L.partials, L.partials_err, max_blocks, err_blocks, L.B, lin_tile);
         return;
       }
       {
@@ -1264,7 +1275,7 @@ int run_fitness(hgs_handle* h, const std::vector<hgs_cloud*>& sources, double ma
   if (!use_corr_seeds) HGS_TRY(ensure_seed_grid(h, h->target));
   int max_n = 0;
   for (hgs_cloud* c : sources) max_n = std::max(max_n, (int)c->n_input);
-  const int qpw = h->nn_qpw > 0 ? h->nn_qpw : 64;
+  const int qpw = 64;
   const int nn_tile = (kBlock / 64) * qpw * kNW;
   const int max_blocks = std::max(1, (max_n + nn_tile - 1) / nn_tile);
   const CloudDesc* d_descs = nullptr;
@@ -1365,6 +1376,8 @@ int hgs_debug_set_option(hgs_handle* h, const char* key, int value) try {
   else if (k == "ndt_chunk") h->ndt_chunk = std::max(0, value);
   else if (k == "hilbert_levels") h->hilbert_levels = std::max(4, std::min(16, value));
   else if (k == "nn_qpw") h->nn_qpw = value == 16 ? 16 : (value == 32 ? 32 : (value == 64 ? 64 : 0));
+  else if (k == "nn_qpw16_below") h->nn_qpw16_below = std::max(0, value);
+  else if (k == "nn_qpw32_below") h->nn_qpw32_below = std::max(0, value);
   else if (k == "upload_trace") h->upload_trace = value != 0 ? 1 : 0;
   else if (k == "prefilter_fast") h->prefilter_fast = value != 0 ? 1 : 0;
   else {

@@ -200,12 +200,23 @@ __device__ __forceinline__ void wave_sums28_to(const double (&even)[14], const d
 // fixed order -> bitwise reproducible.
 constexpr int kSolveBlock = 256;     // GICP / VGICP solve
 constexpr int kNdtSolveBlock = 512;  // NDT: 43 columns leave only 5 rows at 256 threads (1024 was measured slower)
+// nchunks > 0 (k_gicp_linearize's short-packet launches): p holds one row per 64-point CHUNK and the partial of tile t is (c[4t] + c[4t+1]) + (c[4t+2] + c[4t+3]),
+// rows past the last chunk counting as zeros — what last_wave_stores makes of the four wave rows of a 256-point block, bit for bit.
 template <int N, int THREADS = kSolveBlock>
-__device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int ntiles, double* out /* LDS [N] */, double* scratch /* LDS [THREADS] */) {
+__device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int ntiles, double* out /* LDS [N] */, double* scratch /* LDS [THREADS] */, int nchunks = 0) {
   constexpr int ROWS = THREADS / N;
   const int t = threadIdx.x;
   if (t < ROWS * N) {
     const int col = t % N, row = t / N;
+    const auto partial = [&](int tile) -> double {
+      if (nchunks == 0) return p[(size_t)tile * N + col];
+      const int c = 4 * tile;
+      const double r0 = p[(size_t)c * N + col];
+      const double r1 = c + 1 < nchunks ? p[(size_t)(c + 1) * N + col] : 0.0;
+      const double r2 = c + 2 < nchunks ? p[(size_t)(c + 2) * N + col] : 0.0;
+      const double r3 = c + 3 < nchunks ? p[(size_t)(c + 3) * N + col] : 0.0;
+      return (r0 + r1) + (r2 + r3);
+    };
     // four independent partial sums keep four loads in flight per thread (one dependent chain was latency bound)
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     int tile = row;
@@ -213,11 +224,11 @@ __device__ __forceinline__ void reduce_tiles(const double* __restrict__ p, int n
 #pragma unroll 2
 #endif
     for (; tile + 3 * ROWS < ntiles; tile += 4 * ROWS) {
-      const double a = p[(size_t)tile * N + col], b = p[(size_t)(tile + ROWS) * N + col];
-      const double c = p[(size_t)(tile + 2 * ROWS) * N + col], d = p[(size_t)(tile + 3 * ROWS) * N + col];
+      const double a = partial(tile), b = partial(tile + ROWS);
+      const double c = partial(tile + 2 * ROWS), d = partial(tile + 3 * ROWS);
       s0 += a, s1 += b, s2 += c, s3 += d;
     }
-    for (; tile < ntiles; tile += ROWS) s0 += p[(size_t)tile * N + col];
+    for (; tile < ntiles; tile += ROWS) s0 += partial(tile);
     scratch[row * N + col] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
@@ -866,12 +877,34 @@ __device__ __forceinline__ void gicp_state_store(GicpState* dst, const GicpState
   if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(dst)[threadIdx.x] = reinterpret_cast<const double*>(&st)[threadIdx.x];
 }
 
+// The 28 sums of one 64-point wave row: the lane's terms, then the transposing swap-adds.
+__device__ __forceinline__ void gicp_wave_row(const GicpPointResidual& r, const Sym3& M, double* row, int lane) {
+  double even[14], odd[14];
+  {
+    double t[kAcc];
+    gicp_point_terms_by_slot(r, M, t);
+#pragma unroll
+    for (int j = 0; j < 14; j++) even[j] = t[2 * j];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    double t[kAcc];
+    gicp_point_terms_by_slot(r, M, t);
+#pragma unroll
+    for (int j = 0; j < 14; j++) odd[j] = t[2 * j + 1];
+  }
+  wave_sums28_to(even, odd, row, lane);
+}
+
 // update_correspondences + linearize fused: per source point 1-NN in the target tree, Mahalanobis matrix,
 // 6x6 normal-equation terms; wave shuffle reduction, one LDS row per wave, the last wave of the block adds the rows.
 // Algorithmic bytes per source point: 16 (a_i) + 24 (C_A) + 4 (corr) + 16 (b_j) + 24 (C_B) = 84.
 // ROUND2 (k_gicp_linearize<true>): states = the buffer the previous kernel wrote, states_out = the other one; partials_err = the trial errors of the
 // previous k_gicp_error<true>; the accept / reject step (gicp_decide_wave's arithmetic, in its order) runs first, in every block.
-template <bool ROUND2>
+// SHORT (with ROUND2 only): the short-packet form, below.  Its own instantiation and not a branch: with both forms of the per-point arithmetic in one function
+// the compiler shared subexpressions between them and contracted the 64-query form's multiplies and adds differently from k_gicp_linearize<false>'s
+// (measured: the last bits of the pose moved; profiles/r06_ab13_short_packets.log).
+template <bool ROUND2, bool SHORT = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ROUND2 ? 4 : HGS_LINEARIZE_WAVES))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
                                                            double* __restrict__ partials, int max_blocks, int qpw, GicpState* states_out,
                                                            const double* __restrict__ partials_err, Progress prog) {
@@ -931,6 +964,42 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ROUND2 ?
   int jj = active ? j : -1;
   if (jj >= 0 && !((double)d2 < c.max_corr2)) jj = -1;
   if (active) __builtin_nontemporal_store(jj, d.corr + idx);
+  if constexpr (SHORT) {
+    static_assert(ROUND2, "the short-packet form belongs to the two-launch rounds");
+    // Short packets (qpw 16 / 32: a single small registration, where a launch lasts as long as ONE packet walk and a shorter packet walks fewer nodes) must
+    // not change a bit of the result: the waves of the block only search; the LAST one to finish takes the correspondences of the block's 64-point chunks
+    // from LDS and runs the linearisation of each chunk with all 64 lanes — the wave row the 64-query kernel computes for the same points, same code — and
+    // writes one row per chunk; the solve adds the four chunk rows of a 256-point tile in last_wave_stores' order (reduce_tiles).
+    {
+      __shared__ int chunk_corr[kBlock];
+      int lane;
+      HGS_LANE_ID(lane);
+      if (lane < qpw) chunk_corr[wave * qpw + lane] = jj;
+      unsigned ticket = 0;
+      if (lane == 0) ticket = __hip_atomic_fetch_add(&arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ticket = (unsigned)__builtin_amdgcn_readlane((int)ticket, 0);
+      if (ticket != kBlock / 64 - 1) return;
+      const int chunks = tile_pts / 64;  // 1 (qpw 16) or 2 (qpw 32)
+      for (int ch = 0; ch < chunks; ch++) {
+        const int i2 = tile * tile_pts + ch * 64 + lane;
+        if (tile * tile_pts + ch * 64 >= n) break;
+        const int j2 = i2 < n ? chunk_corr[ch * 64 + lane] : -1;
+        Sym3 M2 = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        GicpPointResidual r2 = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (j2 >= 0) {
+          const float4 a2 = load_stream(d.pts + i2);
+          M2 = gicp_mahalanobis(R, load_cov_stream(d.cov, i2), load_cov(tgt.cov, j2));
+          const float4 bp = tgt.pts[j2];
+          r2 = gicp_point_residual(T, M2, a2.x, a2.y, a2.z, bp.x, bp.y, bp.z);
+        }
+        gicp_wave_row(r2, M2, lds, lane);
+        __builtin_amdgcn_wave_barrier();  // (the row is written by lanes 15, 31, 47, 63 and read by lanes 0..27 of the same wave: LDS runs a wave's accesses in order)
+        if (lane < kAcc) partials[((size_t)b * max_blocks + (size_t)tile * chunks + ch) * kAcc + lane] = lds[lane];
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  } else {
   // a lane without a correspondence carries M = 0, T a = 0: every term below is then an exact zero
   Sym3 M = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   GicpPointResidual r = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -944,22 +1013,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ROUND2 ?
   int lane;
   HGS_LANE_ID(lane);
   double* row = lds + wave * kAcc;
-  double even[14], odd[14];
-  {
-    double t[kAcc];
-    gicp_point_terms_by_slot(r, M, t);
-#pragma unroll
-    for (int j = 0; j < 14; j++) even[j] = t[2 * j];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    double t[kAcc];
-    gicp_point_terms_by_slot(r, M, t);
-#pragma unroll
-    for (int j = 0; j < 14; j++) odd[j] = t[2 * j + 1];
-  }
-  wave_sums28_to(even, odd, row, lane);
+  gicp_wave_row(r, M, row, lane);
   last_wave_stores<kAcc>(lds, &arrivals, partials + ((size_t)b * max_blocks + tile) * kAcc, lane);
+  }
 }
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
                            int max_blocks, int B, int qpw) {
@@ -967,21 +1023,24 @@ void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt
                      (const double*)nullptr, Progress{});
 }
 void launch_gicp_linearize_round2(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states_in, GicpState* states_out, GicpConsts c, double* partials,
-                                  const double* partials_err, int max_blocks, int B, int qpw, Progress prog) {
-  hipLaunchKernelGGL(k_gicp_linearize<true>, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states_in, c, partials, max_blocks, qpw, states_out, partials_err, prog);
+                                  const double* partials_err, int max_blocks, int lin_blocks, int B, int qpw, Progress prog) {
+  if (qpw < 64)
+    hipLaunchKernelGGL((k_gicp_linearize<true, true>), dim3(HGS_GRID_X(lin_blocks), B), dim3(kBlock), 0, s, descs, tgt, states_in, c, partials, max_blocks, qpw, states_out, partials_err, prog);
+  else
+    hipLaunchKernelGGL((k_gicp_linearize<true, false>), dim3(HGS_GRID_X(lin_blocks), B), dim3(kBlock), 0, s, descs, tgt, states_in, c, partials, max_blocks, qpw, states_out, partials_err, prog);
 }
 
 // The LM control step behind a linearisation, run by a whole 256-thread block: fixed-order tile reduction, then ONE lane factorises and steps.  The
 // control step is a chain of dependent loads and stores on the problem's state and on the factorisation's pivoted arrays: both live in LDS for its
 // duration (state copied in and out by the block; round 3 ran it on HBM + 592 bytes of scratch).  
-__device__ __forceinline__ void gicp_solve_block(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials) {
+__device__ __forceinline__ void gicp_solve_block(int ntiles, GicpState* state, const GicpConsts& c, const double* __restrict__ problem_partials, int nchunks = 0) {
   __shared__ double acc[kAcc];
   __shared__ double scratch[kSolveBlock];
   __shared__ GicpState st;
   __shared__ double ws[kGicpControlWorkspace];
   static_assert(sizeof(GicpState) % sizeof(double) == 0 && sizeof(GicpState) / sizeof(double) <= kSolveBlock, "state copied one double per thread");
   if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(&st)[threadIdx.x] = reinterpret_cast<const double*>(state)[threadIdx.x];
-  reduce_tiles<kAcc>(problem_partials, ntiles, acc, scratch);  // (ends with a barrier: the state copy is complete)
+  reduce_tiles<kAcc>(problem_partials, ntiles, acc, scratch, nchunks);  // (ends with a barrier: the state copy is complete)
   if (threadIdx.x == 0) gicp_after_linearize(st, acc, c, ws);
   __syncthreads();
   if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(state)[threadIdx.x] = reinterpret_cast<const double*>(&st)[threadIdx.x];
@@ -991,8 +1050,11 @@ __global__ __launch_bounds__(kSolveBlock) __attribute__((amdgpu_waves_per_eu(HGS
   const int b = blockIdx.x;
   if (states[b].phase != GICP_LINEARIZE) return;
   if (HGS_CONTROL_PRIO) __builtin_amdgcn_s_setprio(HGS_CONTROL_PRIO);
-  const int ntiles = (descs[b].meta->nvalid + tile_points - 1) / tile_points;  // tiles of the linearize kernel that filled `partials`
-  gicp_solve_block(ntiles, states + b, c, partials + (size_t)b * max_blocks * kAcc);
+  // tiles of the linearize kernel that filled `partials`; its short-packet launches (tile_points < kBlock) leave one row per 64-point chunk (reduce_tiles)
+  const int n = descs[b].meta->nvalid;
+  const bool chunked = tile_points < kBlock;
+  const int ntiles = chunked ? (n + kBlock - 1) / kBlock : (n + tile_points - 1) / tile_points;
+  gicp_solve_block(ntiles, states + b, c, partials + (size_t)b * max_blocks * kAcc, chunked ? (n + 63) / 64 : 0);
 }
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,
                        int tile_points) {
@@ -1020,8 +1082,9 @@ __global__ __launch_bounds__(kBlock) void k_gicp_error(const CloudDesc* descs, T
     const int phase_in = states[b].phase;  // (block-uniform)
     gicp_state_load(st2, states + b);
     if (phase_in == GICP_LINEARIZE) {
-      const int ntiles_lin = (n + lin_tile_points - 1) / lin_tile_points;
-      reduce_tiles<kAcc>(partials + (size_t)b * max_blocks * kAcc, ntiles_lin, acc2, scratch2);  // (ends with a barrier: the state copy is complete)
+      const bool chunked = lin_tile_points < kBlock;  // (short-packet launches: one row per 64-point chunk, k_gicp_solve)
+      const int ntiles_lin = chunked ? (n + kBlock - 1) / kBlock : (n + lin_tile_points - 1) / lin_tile_points;
+      reduce_tiles<kAcc>(partials + (size_t)b * max_blocks * kAcc, ntiles_lin, acc2, scratch2, chunked ? (n + 63) / 64 : 0);  // (ends with a barrier: the state copy is complete)
       if (threadIdx.x == 0) gicp_after_linearize(st2, acc2, c, ws2);
     }
     __syncthreads();
@@ -1051,8 +1114,8 @@ void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, co
   hipLaunchKernelGGL(k_gicp_error<false>, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states, partials_err, max_blocks, GicpConsts{}, (GicpState*)nullptr, (const double*)nullptr, 0);
 }
 void launch_gicp_error_round2(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states_in, GicpState* states_out, GicpConsts c, const double* partials,
-                              double* partials_err, int max_blocks, int B, int lin_tile_points) {
-  hipLaunchKernelGGL(k_gicp_error<true>, dim3(max_blocks, B), dim3(kBlock), 0, s, descs, tgt, states_in, partials_err, max_blocks, c, states_out, partials, lin_tile_points);
+                              double* partials_err, int max_blocks, int err_blocks, int B, int lin_tile_points) {
+  hipLaunchKernelGGL(k_gicp_error<true>, dim3(err_blocks, B), dim3(kBlock), 0, s, descs, tgt, states_in, partials_err, max_blocks, c, states_out, partials, lin_tile_points);
 }
 
 // The LM accept / reject step behind compute_error, run by ONE wave (the first 64 threads of the calling block; the others only pass the barriers):

@@ -24,6 +24,7 @@ for sensor, seed, ds in (("HDL-32E", 1, None), ("VLP-16", 2, 0.2), ("HDL-64E", 3
         fit_ref = reg.getFitnessScore()
         for rep in range(reps):
             reg.set_option("fused_rounds", 1)
+            reg.set_option("nn_qpw", (0, 16, 32, 64)[rep % 4])  # (short packets: the last wave of a block redoes the 64-point wave rows)
             reg.setInputSource(src)  # cold: the correspondences of the previous align are gone
             r = reg.align(np.eye(4))
             total += 1

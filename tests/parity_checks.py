@@ -159,6 +159,19 @@ def check_two_launch_rounds_equal_four_launch_rounds(make_engine, reps=3):
         r = e.align(guess)
         assert (bytes(r.final_transformation), r.converged, r.iterations, r.lm_tries, r.error, e.getFitnessScore()) == runs[0][0]
         e.set_option("fused_rounds_below", 262144)
+        # packet sizes of k_gicp_linearize<true>: 16- / 32-query packets search only, the block's last wave redoes the 64-point wave rows (not a bit may move)
+        for q in (16, 32, 64, 0):
+            e.set_option("nn_qpw", q)
+            e.setInputSource(src)
+            r = e.align(guess)
+            assert (bytes(r.final_transformation), r.converged, r.iterations, r.lm_tries, r.error, e.getFitnessScore()) == runs[0][0], q
+            e.setInputSource(src[: len(src) - 77])  # (a last chunk of 51 points behind a different tile count)
+            ra = e.align(guess)
+            e.set_option("fused_rounds", 0)
+            e.setInputSource(src[: len(src) - 77])
+            rb = e.align(guess)
+            e.set_option("fused_rounds", 1)
+            assert (bytes(ra.final_transformation), ra.iterations, ra.lm_tries, ra.error) == (bytes(rb.final_transformation), rb.iterations, rb.lm_tries, rb.error), q
         # batches: one lane, several lanes, above the limit
         clouds = [e.upload(c) for c in (src, src2, src[::2], src2[::3], src[5::3])]
         guesses = [guess, T2, np.eye(4), T2, guess]
