@@ -308,7 +308,7 @@ struct hgs_handle {
   hipEvent_t lane_event[8] = {};
   int lane_start = 1;                // 1: the host synchronises before it releases the lanes of a batch (open_lanes); HGS_LANE_START=0: not (A/B runs)
   int nn_qpw = 0;  // queries per packet of k_gicp_linearize in the two-launch LM rounds: 0 = by launch size (run_batch), 16 / 32 / 64
-  int nn_qpw16_below = 64, nn_qpw32_below = 0;  // ... 16 up to this many 256-point tiles in the launch, 32 up to that many
+  int nn_qpw16_below = 96, nn_qpw32_below = 0;  // ... 16 up to this many 256-point tiles in the launch, 32 up to that many
   // levels of the Hilbert curve the index sort compares (HGS_HILBERT_LEVELS, A/B runs; 16 = all 48 bits, rounds 1-3).  64 x 119 k batch, index stage / step:
   // 16 -> 0.915 / 11.99 ms, 13 -> 0.83 / 11.93, 11 -> 0.75 / 11.91, 10 -> 0.75 / 12.1, 9 -> 0.75 / 12.7 (the walks slow down once a cell of the finest compared
   // level holds many points): 13 = 1/8192 of the cloud's extent (2.4 cm on a 200 m scan), one radix pass less for a batch and two for a pair
@@ -1107,7 +1107,8 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   // ... but a launch of a FEW blocks lasts as long as one packet walk, and a shorter packet walks fewer nodes: the two-launch LM rounds of a small single
   // registration run k_gicp_linearize<true> with 16- / 32-query packets, whose last wave per block redoes the 64-point wave rows so that no bit of the
   // result depends on the packet size (hgs_kernels.hip).  Same-box (profiles/r06_ab12_nn_qpw.log, r06_ab13): the 13.5 k-point odometry source hgs_align
-  // 0.347 -> 0.31 ms with 16; the 65 k-point HDL-32E source is best with 64.  nn_qpw (option): 0 = by launch size, 16 / 32 / 64 = that packet.
+  // 0.344 -> 0.315 ms with 16; by size (profiles/r06_nn_qpw_sizes.log): 7 k points -6 %, 11 k -4 %, 16 k -3 %, 22 k -1 %, 64 k +2 % (32 never wins).
+  // nn_qpw (option): 0 = by launch size, 16 / 32 / 64 = that packet.
   const bool gicp_round2 = method == HGS_FAST_GICP && h->fused_rounds && B <= kFusedRoundMaxProblems && max_n <= h->fused_rounds_below;
   const long tiles64 = (long)B * ((max_n + nn_tile - 1) / nn_tile);
   const int lin_qpw = !gicp_round2 ? 64 : h->nn_qpw > 0 ? h->nn_qpw : tiles64 <= (long)h->nn_qpw16_below ? 16 : tiles64 <= (long)h->nn_qpw32_below ? 32 : 64;
