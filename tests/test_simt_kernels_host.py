@@ -98,7 +98,7 @@ def test_covariances_of_short_last_packets_and_short_packet_launches():
 
 
 def test_two_launch_lm_rounds_equal_the_four_launch_rounds():
-    PC.check_two_launch_rounds_equal_four_launch_rounds(_engine, reps=1)
+    PC.check_two_launch_rounds_equal_four_launch_rounds(_engine, reps=1, light=True)
 
 
 def test_covariances_when_the_leaf_log_overflows():
