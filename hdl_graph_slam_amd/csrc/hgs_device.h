@@ -112,7 +112,8 @@ void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states,
 void launch_gicp_error(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, double* partials_err, int max_blocks, int B);
 // two launches per LM round (hgs_kernels.hip, "two launches per LM round"): the control steps replicated in every block, states ping-pong between two buffers
 void launch_gicp_linearize_round2(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states_in, GicpState* states_out, GicpConsts c, double* partials,
-                                  const double* partials_err, int max_blocks /* row stride of the partials */, int lin_blocks /* grid */, int B, int qpw, Progress prog);
+                                  const double* partials_err, int max_blocks /* row stride of the partials */, int lin_blocks /* grid */, int B, int qpw, Progress prog,
+                                  DevResult* results, DevResult* early_out /* host-mapped, or null */);
 void launch_gicp_error_round2(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states_in, GicpState* states_out, GicpConsts c, const double* partials,
                               double* partials_err, int max_blocks, int err_blocks /* grid */, int B, int lin_tile_points);
 void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials_err, int max_blocks, int B, Progress prog);

@@ -320,6 +320,10 @@ struct hgs_handle {
   // launches fill the device on their own and two chains are enough to cover each other's solves and tails.
   int prefilter_fast = 1;  // hgs_prefilter: distance filter inside the voxel grid's kernels, RadiusOutlierRemoval on the voxel grid (0: the separate passes + search tree; A/B, tests)
   int upload_trace = 0;
+  int early_result = 1;    // a single registration in two-launch rounds hands its result over in host-mapped memory (run_batch; 0: result kernel + copy + synchronisation)
+  PinnedBuffer h_early;                // the host-mapped record
+  hipEvent_t early_event = nullptr;    // behind the rounds that were still queued when hgs_align returned early
+  bool early_pending = false, early_valid = false;
   int fused_rounds = 1;    // launches of <= kFusedRoundMaxProblems GICP problems of at most fused_rounds_below points each: the LM round in two launches (control steps replicated per block; 0: four launches per round)
   int fused_rounds_below = 262144;
   int cov_split = 1;       // non-FROBENIUS regularisations: search kernel + k_cov_regularize (0: one kernel with the eigen-decomposition inline; HGS_COV_SPLIT, A/B runs)
@@ -941,6 +945,10 @@ constexpr int kMaxLanes = 8;  // HGS_BATCH_LANES up to 8 (A/B runs); the default
 
 // Progress mirror of one lane of a batch: device counters + two ints of host-mapped pinned memory the kernels write into.
 int make_progress(hgs_handle* h, int lane, int B, Progress* out) {
+  if (h->early_pending) {  // the rounds that were queued behind an early result (they tick the mirror) have to be through before the mirror is reset
+    HGS_HIP(h, hipEventSynchronize(h->early_event));
+    h->early_pending = false;
+  }
   HGS_HIP(h, h->done.reserve(64));
   HGS_HIP(h, h->h_flags.reserve(64));
   volatile int* hf = h->h_flags.as<volatile int>() + 2 * lane;
@@ -1081,6 +1089,7 @@ void lane_fitness(hgs_handle* h, BatchLane& L, const CloudDesc* d_descs, double 
 // the problem's lane as soon as the lane has converged, i.e. under the remaining iterations of the other lanes.
 int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float* guesses_host, const double* fit_max_range = nullptr) {
   const int B = (int)sources.size();
+  h->early_valid = false;
   hgs_cloud* tgt = h->target;
   const int method = h->prm.method;
   std::vector<hgs_cloud*> all(sources);
@@ -1132,6 +1141,14 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     // of an LM round cost as much as its two point kernels: such launches run the round in TWO launches, the control steps replicated in every block of
     // k_gicp_linearize<true> / k_gicp_error<true> (hgs_kernels.hip).  The states then alternate between two buffers; a whole round leaves them in the first.
     const bool round2 = gicp_round2;
+    // One registration without a fitness pass behind it (hgs_align: the odometry step): the kernel that finds it finished writes the result record into
+    // host-mapped memory in front of the mirror's `done` flag; the poll below returns with it — no result kernel, no copy, no synchronisation.
+    const bool early = round2 && B == 1 && !fit_max_range && h->early_result && !h->profiling;
+    DevResult* early_out = nullptr;
+    if (early) {
+      HGS_HIP(h, h->h_early.reserve(sizeof(DevResult)));
+      early_out = h->h_early.as<DevResult>();
+    }
     HGS_HIP(h, h->states.reserve((size_t)B * sizeof(GicpState) * (round2 ? 2 : 1)));
     GicpState* st = h->states.as<GicpState>();
     GicpState* st_other = st + B;
@@ -1141,6 +1158,10 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     std::vector<BatchLane> lanes;
     HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
     auto finish_lane = [&](BatchLane& L) {
+      if (early && *L.prog.host_done) {  // (not when the lane ran out of rounds: then the result kernel + copy below fetch whatever state it is in)
+        h->early_valid = true;
+        return;
+      }
       launch_gicp_results(L.stream, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
       if (fit_max_range) lane_fitness(h, L, d_descs, *fit_max_range, max_blocks, qpw, nn_tile);
     };
@@ -1151,7 +1172,8 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       if (round2) {
         {
           StageTimer tm(h, HGS_STAGE_LINEARIZE);
-          launch_gicp_linearize_round2(L.stream, dd, tv, ls, st_other + L.b0, c, L.partials, L.partials_err, max_blocks, lin_blocks, L.B, lin_qpw, L.prog);
+          launch_gicp_linearize_round2(L.stream, dd, tv, ls, st_other + L.b0, c, L.partials, L.partials_err, max_blocks, lin_blocks, L.B, lin_qpw, L.prog,
+                                       h->results.as<DevResult>() + L.b0, early_out);
         }
         StageTimer tm(h, HGS_STAGE_ERROR);
         launch_gicp_error_round2(L.stream, dd, tv, st_other + L.b0, ls, c, L.partials, L.partials_err, max_blocks, err_blocks, L.B, lin_tile);
@@ -1177,6 +1199,11 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       }
     }, finish_lane);
     HGS_TRY(close_lanes(h, lanes));
+    if (h->early_valid) {  // rounds may still be queued (the host runs ahead): the next batch's mirror reset waits for them (make_progress)
+      if (!h->early_event) HGS_HIP(h, hipEventCreateWithFlags(&h->early_event, hipEventDisableTiming));
+      HGS_HIP(h, hipEventRecord(h->early_event, h->stream));
+      h->early_pending = true;
+    }
   } else {
     const NdtConsts c = ndt_consts(h->prm);
     HGS_HIP(h, h->states.reserve((size_t)B * sizeof(NdtState)));
@@ -1367,6 +1394,7 @@ int hgs_debug_set_option(hgs_handle* h, const char* key, int value) try {
   else if (k == "ndt_sort") h->ndt_sort = std::max(-1, std::min(1, value));
   else if (k == "cov_split") h->cov_split = value != 0 ? 1 : 0;
   else if (k == "fused_rounds") h->fused_rounds = value != 0 ? 1 : 0;
+  else if (k == "early_result") h->early_result = value != 0 ? 1 : 0;
   else if (k == "fused_rounds_below") h->fused_rounds_below = std::max(0, value);
   else if (k == "resident_descs") h->resident_descs = value != 0 ? 1 : 0;
   else if (k == "knn_qpw_tiny") h->knn_qpw_tiny = value < 0 ? -1 : std::max(0, std::min(32, value & ~7));
@@ -1476,6 +1504,7 @@ int hgs_destroy(hgs_handle* h) try {
   for (hipEvent_t ev : h->lane_event)
     if (ev) (void)hipEventDestroy(ev);
   if (h->comm_event) (void)hipEventDestroy(h->comm_event);
+  if (h->early_event) (void)hipEventDestroy(h->early_event);
   for (hipStream_t ls : h->lane_stream)
     if (ls) (void)hipStreamDestroy(ls), streams_in_use(h->device).fetch_sub(1, std::memory_order_relaxed);
   for (auto& blk : h->block_pool) (void)hipFree(blk.first);
@@ -1489,6 +1518,7 @@ int hgs_destroy(hgs_handle* h) try {
   h->h_small.release();
   h->h_comm.release();
   h->h_flags.release();
+  h->h_early.release();
   h->h_xform.release();
   for (auto& ev : h->prof_events) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
   for (auto& ev : h->prof_free) (void)hipEventDestroy(ev.a), (void)hipEventDestroy(ev.b);
@@ -1644,7 +1674,9 @@ int hgs_align(hgs_handle* h, const float guess[16], hgs_result* out) try {
   std::vector<hgs_cloud*> src{h->source};
   HGS_TRY(run_batch(h, src, guess));
   std::vector<DevResult> r;
-  HGS_TRY(fetch_results(h, 1, r));
+  if (h->early_valid) r.assign(1, *h->h_early.as<DevResult>());  // (written in front of the `done` flag the poll has seen: k_gicp_linearize<true>)
+  else HGS_TRY(fetch_results(h, 1, r));
+  h->early_valid = false;
   to_public(r[0], 0, false, out);
   std::memcpy(h->final_T, out->final_transformation, sizeof(h->final_T));
   return HGS_OK;

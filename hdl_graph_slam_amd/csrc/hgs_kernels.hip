@@ -109,10 +109,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 // End-of-round bookkeeping, called by ONE thread of each of the B per-problem blocks of the last kernel of a round:
 // counts finished problems and completed rounds in HBM and mirrors both into host-mapped pinned memory, so that the
 // host can keep the queue filled and stop enqueueing rounds without ever synchronising the stream.
-__device__ __forceinline__ void progress_tick(Progress p, bool finished_now) {
+// release_done: the caller has stored results into host-mapped memory that the host reads as soon as it sees host_done (k_gicp_linearize<true>'s early result).
+__device__ __forceinline__ void progress_tick(Progress p, bool finished_now, bool release_done = false) {
   // the mirror lives in host-mapped memory: system-scope atomic stores reach it without a __threadfence_system(), whose cache
   // write-back + invalidate would hit every block of a kernel that is still computing (k_ndt_pass ticks from inside)
-  if (finished_now && atomicAdd(&p.dev[0], 1) + 1 == p.B) __hip_atomic_store(const_cast<int*>(p.host_done), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (finished_now && atomicAdd(&p.dev[0], 1) + 1 == p.B) {
+    if (release_done) __hip_atomic_store(const_cast<int*>(p.host_done), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(const_cast<int*>(p.host_done), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int t = atomicAdd(&p.dev[1], 1) + 1;
   if (t % p.B == 0) __hip_atomic_store(const_cast<int*>(p.host_rounds), t / p.B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -869,6 +873,24 @@ __device__ __forceinline__ void packet_nn1(const BvhView& tv, float* park, const
 // writes the state out — into the OTHER of two state buffers, so that a block starting late never reads a state that has already been advanced.
 // Launches of <= kFusedRoundMaxProblems problems below the engine's size limit only: a 5 us serial step repeated by 250 blocks is latency nobody
 // waits for, repeated by 30 000 it is throughput.
+__device__ __forceinline__ DevResult gicp_result_of(const GicpState& st) {
+  DevResult r;
+  pose_to_colmajor_f(st.x0, r.T);
+  r.converged = st.converged, r.iterations = st.iterations, r.lm_tries = st.lm_tries_total, r.pad = 0;
+  r.error = st.y0;
+  r.fit_sum = 0, r.fit_count = 0, r.pad2 = 0;
+  return r;
+}
+// A finished single registration hands its result to the host the moment it exists: the record goes into host-mapped memory with system-scope stores in
+// front of the progress mirror's `done` flag (released), and hgs_align returns from its poll — no result kernel, no device-to-host copy, no stream
+// synchronisation, and the no-op rounds the host had queued ahead drain behind its back (engine: run_batch, `early`).
+__device__ __forceinline__ void gicp_early_result(DevResult* mapped, const DevResult& r) {
+  static_assert(sizeof(DevResult) % 8 == 0, "stored as 64-bit words");
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&r);
+  unsigned long long* o = reinterpret_cast<unsigned long long*>(mapped);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(DevResult) / 8); k++) __hip_atomic_store(o + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void gicp_state_load(GicpState& st, const GicpState* src) {
   static_assert(sizeof(GicpState) % sizeof(double) == 0 && sizeof(GicpState) / sizeof(double) <= kBlock, "state copied one double per thread");
   if (threadIdx.x < sizeof(GicpState) / sizeof(double)) reinterpret_cast<double*>(&st)[threadIdx.x] = reinterpret_cast<const double*>(src)[threadIdx.x];
@@ -907,7 +929,7 @@ __device__ __forceinline__ void gicp_wave_row(const GicpPointResidual& r, const 
 template <bool ROUND2, bool SHORT = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ROUND2 ? 4 : HGS_LINEARIZE_WAVES))) void k_gicp_linearize(const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c,
                                                            double* __restrict__ partials, int max_blocks, int qpw, GicpState* states_out,
-                                                           const double* __restrict__ partials_err, Progress prog) {
+                                                           const double* __restrict__ partials_err, Progress prog, DevResult* results, DevResult* early_out) {
   const int b = blockIdx.y;
   __shared__ GicpState st2;                         // ROUND2: this block's copy of the problem's state
   __shared__ double ws2[kGicpControlWorkspace];
@@ -931,7 +953,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ROUND2 ?
     __syncthreads();
     if (blockIdx.x == 0) {
       gicp_state_store(states_out + b, st2);
-      if (threadIdx.x == 0) progress_tick(prog, phase_in == GICP_TRY && st2.phase == GICP_DONE);  // (k_gicp_decide's tick: once per problem and round)
+      if (threadIdx.x == 0) {
+        const bool finished_now = phase_in == GICP_TRY && st2.phase == GICP_DONE;
+        if (finished_now && early_out) {  // (single registrations: the result record in HBM for whoever reads it on the device, and in host-mapped memory)
+          const DevResult r = gicp_result_of(st2);
+          results[b] = r;
+          gicp_early_result(early_out + b, r);
+        }
+        progress_tick(prog, finished_now, early_out != nullptr);  // (k_gicp_decide's tick: once per problem and round)
+      }
     }
     if (st2.phase != GICP_LINEARIZE) return;
   }
@@ -1020,14 +1050,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ROUND2 ?
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials,
                            int max_blocks, int B, int qpw) {
   hipLaunchKernelGGL(k_gicp_linearize<false>, dim3(HGS_GRID_X(max_blocks), B), dim3(kBlock), 0, s, descs, tgt, states, c, partials, max_blocks, qpw, (GicpState*)nullptr,
-                     (const double*)nullptr, Progress{});
+                     (const double*)nullptr, Progress{}, (DevResult*)nullptr, (DevResult*)nullptr);
 }
 void launch_gicp_linearize_round2(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states_in, GicpState* states_out, GicpConsts c, double* partials,
-                                  const double* partials_err, int max_blocks, int lin_blocks, int B, int qpw, Progress prog) {
+                                  const double* partials_err, int max_blocks, int lin_blocks, int B, int qpw, Progress prog, DevResult* results, DevResult* early_out) {
   if (qpw < 64)
-    hipLaunchKernelGGL((k_gicp_linearize<true, true>), dim3(HGS_GRID_X(lin_blocks), B), dim3(kBlock), 0, s, descs, tgt, states_in, c, partials, max_blocks, qpw, states_out, partials_err, prog);
+    hipLaunchKernelGGL((k_gicp_linearize<true, true>), dim3(HGS_GRID_X(lin_blocks), B), dim3(kBlock), 0, s, descs, tgt, states_in, c, partials, max_blocks, qpw, states_out, partials_err, prog, results, early_out);
   else
-    hipLaunchKernelGGL((k_gicp_linearize<true, false>), dim3(HGS_GRID_X(lin_blocks), B), dim3(kBlock), 0, s, descs, tgt, states_in, c, partials, max_blocks, qpw, states_out, partials_err, prog);
+    hipLaunchKernelGGL((k_gicp_linearize<true, false>), dim3(HGS_GRID_X(lin_blocks), B), dim3(kBlock), 0, s, descs, tgt, states_in, c, partials, max_blocks, qpw, states_out, partials_err, prog, results, early_out);
 }
 
 // The LM control step behind a linearisation, run by a whole 256-thread block: fixed-order tile reduction, then ONE lane factorises and steps.  The
@@ -1160,13 +1190,7 @@ void launch_gicp_decide(hipStream_t s, const CloudDesc* descs, GicpState* states
 __global__ void k_gicp_results(const GicpState* states, DevResult* out, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const GicpState& st = states[b];
-  DevResult r;
-  pose_to_colmajor_f(st.x0, r.T);
-  r.converged = st.converged, r.iterations = st.iterations, r.lm_tries = st.lm_tries_total, r.pad = 0;
-  r.error = st.y0;
-  r.fit_sum = 0, r.fit_count = 0, r.pad2 = 0;
-  out[b] = r;
+  out[b] = gicp_result_of(states[b]);
 }
 void launch_gicp_results(hipStream_t s, const GicpState* states, DevResult* out, int B) {
   hipLaunchKernelGGL(k_gicp_results, dim3((B + 63) / 64), dim3(64), 0, s, states, out, B);

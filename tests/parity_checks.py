@@ -132,12 +132,27 @@ def check_two_launch_rounds_equal_four_launch_rounds(make_engine, reps=3, light=
     p_lm.transformation_epsilon, p_lm.rotation_epsilon = 1e-5, 1e-6
     p_lm.lm_init_lambda_factor = 1e-12
     hard = T @ synth.pose_matrix([0.8, 0.5, 0.1], [0.01, 0.01, 0.08])
+    # a registration that runs out of iterations: the result record handed over in host-mapped memory (engine option early_result) says converged = 0
+    p_cut = O.default_params(O.HGS_FAST_GICP)
+    p_cut.max_iterations = 2
+    e = make_engine(p_cut)
+    e.setInputTarget(tgt)
+    cut = []
+    for fused, early in ((0, 1), (1, 1), (1, 0), (1, 1)):
+        e.set_option("fused_rounds", fused)
+        e.set_option("early_result", early)
+        e.setInputSource(src)
+        r = e.align(hard)
+        cut.append((bytes(r.final_transformation), r.converged, r.iterations, r.lm_tries, r.error))
+    assert all(x == cut[0] for x in cut) and not cut[0][1] and cut[0][2] == 2, [x[1:] for x in cut]
+    e.close()
     for params, guess in ((O.default_params(O.HGS_FAST_GICP), np.eye(4)), (p_lm, hard)):
         e = make_engine(params)
         e.setInputTarget(tgt)
         runs = {}
-        for fused in (0, 1, 1, 0) + (1,) * reps:
+        for k, fused in enumerate((0, 1, 1, 0) + (1,) * reps):
             e.set_option("fused_rounds", fused)
+            e.set_option("early_result", int(k % 3 != 2))  # (every third run fetches the record with the result kernel + copy)
             e.setInputSource(src)  # (cold: no correspondences left over from the run before)
             r = e.align(guess)
             fit = e.getFitnessScore()
