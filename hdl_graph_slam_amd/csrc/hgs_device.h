@@ -105,6 +105,10 @@ void launch_knn_cov(hipStream_t s, const CloudDesc* descs, int ncloud, int max_n
                     double* raw_stage = nullptr /* ncloud * max_n * 6 doubles: non-FROBENIUS regularisations run as search + k_cov_regularize */);
 
 void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog);
+struct Guess16 {
+  float m[16];  // column-major
+};
+void launch_gicp_init1(hipStream_t s, GicpState* states, const float* guess_host /* [16] */, Progress prog);
 void launch_gicp_linearize(hipStream_t s, const CloudDesc* descs, TargetView tgt, const GicpState* states, GicpConsts c, double* partials, int max_blocks, int B,
                            int qpw);
 void launch_gicp_solve(hipStream_t s, const CloudDesc* descs, GicpState* states, GicpConsts c, const double* partials, int max_blocks, int B,

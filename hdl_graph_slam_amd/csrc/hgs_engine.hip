@@ -1127,8 +1127,9 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   const int err_blocks = std::max(1, (max_n + kBlock - 1) / kBlock);
   const CloudDesc* d_descs = nullptr;
   HGS_TRY(upload_descs(h, sources, false, &d_descs, nullptr));
+  const bool guess_in_args = B == 1 && method == HGS_FAST_GICP;  // (a single GICP registration: the guess rides in k_gicp_init1's arguments)
   HGS_HIP(h, h->guesses.reserve((size_t)B * 16 * sizeof(float)));
-  HGS_HIP(h, h->up.upload(h->guesses.p, guesses_host, (size_t)B * 16 * sizeof(float), h->stream));  // (the caller's array is pageable: through a pinned slot)
+  if (!guess_in_args) HGS_HIP(h, h->up.upload(h->guesses.p, guesses_host, (size_t)B * 16 * sizeof(float), h->stream));  // (the caller's array is pageable: through a pinned slot)
   HGS_HIP(h, h->done.reserve(64));
   HGS_HIP(h, h->results.reserve((size_t)B * sizeof(DevResult)));
   HGS_HIP(h, h->partials.reserve((size_t)B * max_blocks * kAccNdt * sizeof(double)));
@@ -1165,7 +1166,9 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
       launch_gicp_results(L.stream, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
       if (fit_max_range) lane_fitness(h, L, d_descs, *fit_max_range, max_blocks, qpw, nn_tile);
     };
-    for (BatchLane& L : lanes) launch_gicp_init(L.stream, st + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, L.B, L.prog);
+    if (guess_in_args) launch_gicp_init1(lanes[0].stream, st, guesses_host, lanes[0].prog);
+    else
+      for (BatchLane& L : lanes) launch_gicp_init(L.stream, st + L.b0, h->guesses.as<float>() + (size_t)L.b0 * 16, L.B, L.prog);
     drive_lanes(lanes, max_rounds, [&](BatchLane& L) {
       const CloudDesc* dd = d_descs + L.b0;
       GicpState* ls = st + L.b0;

@@ -738,6 +738,17 @@ __global__ void k_gicp_init(GicpState* states, const float* guesses, int B, Prog
 void launch_gicp_init(hipStream_t s, GicpState* states, const float* guesses, int B, Progress prog) {
   hipLaunchKernelGGL(k_gicp_init, dim3((B + 63) / 64), dim3(64), 0, s, states, guesses, B, prog);
 }
+// a single registration: the guess travels in the kernel's arguments (no upload in front of the launch)
+__global__ void k_gicp_init1(GicpState* states, Guess16 guess, Progress prog) {
+  if (threadIdx.x != 0) return;
+  prog.dev[0] = 0, prog.dev[1] = 0;
+  gicp_state_init(states[0], guess.m);
+}
+void launch_gicp_init1(hipStream_t s, GicpState* states, const float* guess_host, Progress prog) {
+  Guess16 g;
+  for (int i = 0; i < 16; i++) g.m[i] = guess_host[i];
+  hipLaunchKernelGGL(k_gicp_init1, dim3(1), dim3(64), 0, s, states, g, prog);
+}
 
 __device__ __forceinline__ Sym3 load_cov(const float4* cov, int i) {
   const float4 a = cov[2 * i], b = cov[2 * i + 1];
