@@ -326,6 +326,10 @@ struct hgs_handle {
   bool early_pending = false, early_valid = false;
   int fused_rounds = 1;    // launches of <= kFusedRoundMaxProblems GICP problems of at most fused_rounds_below points each: the LM round in two launches (control steps replicated per block; 0: four launches per round)
   int fused_rounds_below = 262144;
+  // ... or batches of more problems of at most that many 256-point tiles in total: the loop-closure batch of a KITTI run (candidate keyframes are prefiltered
+  // sweeps of 11-14 k points) — 6 / 12 / 24 candidates x 11 k points 0.62 -> 0.57 / 0.73 -> 0.68 / 0.88 -> 0.83 ms per detection, 48 candidates (2160 tiles)
+  // 1.07 -> 1.12 (scripts/probes/small_batch_probe.py, profiles/r06_small_batch.log)
+  int fused_rounds_max_problems = kFusedRoundMaxProblems, fused_rounds_max_blocks = 1536;
   int cov_split = 1;       // non-FROBENIUS regularisations: search kernel + k_cov_regularize (0: one kernel with the eigen-decomposition inline; HGS_COV_SPLIT, A/B runs)
   int resident_descs = 1;  // HGS_RESIDENT_DESCS=0: every stage uploads its descriptor array (A/B runs)
   int knn_qpw_tiny = -1;  // queries per packet of small k_knn_cov launches: -1 = by launch size (queries_per_wave), 0 = 32 as before round 6, 8 / 16 / 24 = below knn_tiny_below queries
@@ -1118,7 +1122,8 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
   // result depends on the packet size (hgs_kernels.hip).  Same-box (profiles/r06_ab12_nn_qpw.log, r06_ab13): the 13.5 k-point odometry source hgs_align
   // 0.344 -> 0.315 ms with 16; by size (profiles/r06_nn_qpw_sizes.log): 7 k points -6 %, 11 k -4 %, 16 k -3 %, 22 k -1 %, 64 k +2 % (32 never wins).
   // nn_qpw (option): 0 = by launch size, 16 / 32 / 64 = that packet.
-  const bool gicp_round2 = method == HGS_FAST_GICP && h->fused_rounds && B <= kFusedRoundMaxProblems && max_n <= h->fused_rounds_below;
+  const bool gicp_round2 = method == HGS_FAST_GICP && h->fused_rounds && max_n <= h->fused_rounds_below &&
+                           (B <= h->fused_rounds_max_problems || (long)B * ((max_n + kBlock - 1) / kBlock) <= (long)h->fused_rounds_max_blocks);
   const long tiles64 = (long)B * ((max_n + nn_tile - 1) / nn_tile);
   const int lin_qpw = !gicp_round2 ? 64 : h->nn_qpw > 0 ? h->nn_qpw : tiles64 <= (long)h->nn_qpw16_below ? 16 : tiles64 <= (long)h->nn_qpw32_below ? 32 : 64;
   const int lin_tile = (kBlock / 64) * lin_qpw * kNW;
@@ -1398,6 +1403,8 @@ int hgs_debug_set_option(hgs_handle* h, const char* key, int value) try {
   else if (k == "cov_split") h->cov_split = value != 0 ? 1 : 0;
   else if (k == "fused_rounds") h->fused_rounds = value != 0 ? 1 : 0;
   else if (k == "early_result") h->early_result = value != 0 ? 1 : 0;
+  else if (k == "fused_rounds_max_problems") h->fused_rounds_max_problems = std::max(0, value);
+  else if (k == "fused_rounds_max_blocks") h->fused_rounds_max_blocks = std::max(0, value);
   else if (k == "fused_rounds_below") h->fused_rounds_below = std::max(0, value);
   else if (k == "resident_descs") h->resident_descs = value != 0 ? 1 : 0;
   else if (k == "knn_qpw_tiny") h->knn_qpw_tiny = value < 0 ? -1 : std::max(0, std::min(32, value & ~7));

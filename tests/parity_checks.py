@@ -123,7 +123,7 @@ def check_two_launch_rounds_equal_four_launch_rounds(make_engine, reps=3, light=
     k_gicp_error<true> and the states alternating between two buffers (engine option fused_rounds, the default), against the four-launch round
     (fused_rounds=0) on the same engine: the same code on the same partials in the same order — poses, iteration counts, LM tries, errors and fitness
     scores are identical bits.  Covers an accepted-at-once loop, the LM rejection path (several error / decide rounds per linearisation), an empty source,
-    batches of 1 / 3 / 4 / 5 candidates (5: above the limit, i.e. the four-launch round under the option), the size limit and the packet sizes of the
+    batches of 1 / 3 / 4 / 5 candidates (5: a batch that qualifies by its total tile count — engine option fused_rounds_max_blocks), the size limit and the packet sizes of the
     linearize kernel.  light: smaller clouds and fewer combinations (the host emulation of the kernels runs this check at ~1e-4 of the device's speed)."""
     tgt, src, T = synth.make_pair("VLP-16", 1, downsample=0.8 if light else 0.3)
     tgt2, src2, T2 = synth.make_pair("HDL-32E", 4, downsample=1.0 if light else 0.4)
@@ -193,11 +193,13 @@ def check_two_launch_rounds_equal_four_launch_rounds(make_engine, reps=3, light=
         guesses = [guess, T2, np.eye(4), T2, guess]
         for n in (3, 5) if light else (1, 3, 4, 5):
             recs = []
-            for fused in (0, 1) if light else (0, 1, 1):
+            for fused, max_blocks in ((0, 1536), (1, 1536), (1, 0)) if light else ((0, 1536), (1, 1536), (1, 1536), (1, 0)):  # (0: batches above 4 problems in four launches)
                 e.set_option("fused_rounds", fused)
+                e.set_option("fused_rounds_max_blocks", max_blocks)
                 rec, best = e.loop_match_batch(clouds[:n], [np.asarray(g, np.float32) for g in guesses[:n]])
                 recs.append((rec.tobytes(), best))
             assert all(x == recs[0] for x in recs[1:]), n
+        e.set_option("fused_rounds_max_blocks", 1536)
         for c in clouds:
             c.close()
         e.close()
