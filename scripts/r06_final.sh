@@ -7,7 +7,7 @@ cd "$ROOT"
 mkdir -p gpurun_out
 [ -d .scan_cache ] && export HGS_SCAN_CACHE="$ROOT/.scan_cache"
 if [ -z "${SKIP_TESTS:-}" ]; then
-  timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -6 | tee gpurun_out/r06_gputest_final.log
+  timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -12 | grep -E "passed|failed|error" | tee gpurun_out/r06_gputest_final.log
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a gpurun_out/r06_gputest_final.log
 fi
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06_bench_driver_cmd.log 2>gpurun_out/r06_bench_driver_cmd.err; echo "bench exit $?"
