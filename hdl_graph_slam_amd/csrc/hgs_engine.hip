@@ -327,9 +327,10 @@ struct hgs_handle {
   int fused_rounds = 1;    // launches of <= kFusedRoundMaxProblems GICP problems of at most fused_rounds_below points each: the LM round in two launches (control steps replicated per block; 0: four launches per round)
   int fused_rounds_below = 262144;
   // ... or batches of more problems of at most that many 256-point tiles in total: the loop-closure batch of a KITTI run (candidate keyframes are prefiltered
-  // sweeps of 11-14 k points) — 6 / 12 / 24 candidates x 11 k points 0.62 -> 0.57 / 0.73 -> 0.68 / 0.88 -> 0.83 ms per detection, 48 candidates (2160 tiles)
-  // 1.07 -> 1.12 (scripts/probes/small_batch_probe.py, profiles/r06_small_batch.log)
-  int fused_rounds_max_problems = kFusedRoundMaxProblems, fused_rounds_max_blocks = 1536;
+  // sweeps of 11-14 k points).  Under four lanes: 6 / 12 / 24 candidates x 11 k points 0.62 -> 0.57 / 0.73 -> 0.68 / 0.88 -> 0.83 ms per detection, 48
+  // candidates (2160 tiles) 1.07 -> 1.12.  Such batches run on ONE lane now (open_lanes), where the two-launch round is worth less: 6 / 12 candidates
+  // 0.521 -> 0.514 / 0.633 -> 0.628 ms, 24 candidates (1080 tiles) 0.794 -> 0.819 — hence 640 (scripts/probes/small_batch_probe.py, profiles/r06_small_batch.log)
+  int fused_rounds_max_problems = kFusedRoundMaxProblems, fused_rounds_max_blocks = 640;
   int cov_split = 1;       // non-FROBENIUS regularisations: search kernel + k_cov_regularize (0: one kernel with the eigen-decomposition inline; HGS_COV_SPLIT, A/B runs)
   int resident_descs = 1;  // HGS_RESIDENT_DESCS=0: every stage uploads its descriptor array (A/B runs)
   int knn_qpw_tiny = -1;  // queries per packet of small k_knn_cov launches: -1 = by launch size (queries_per_wave), 0 = 32 as before round 6, 8 / 16 / 24 = below knn_tiny_below queries
@@ -977,10 +978,16 @@ struct BatchLane {
 // Splits B problems into lanes (contiguous ranges) and makes the extra streams wait for what the main stream has enqueued
 // so far (indices, covariances, descriptors, guesses).  Profiling keeps one lane: the stage timers bracket launches on the
 // main stream and are meant to time kernels that have the device to themselves.
-int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t partial_err_bytes_per_problem, std::vector<BatchLane>& lanes) {
+int open_lanes(hgs_handle* h, int B, size_t partial_bytes_per_problem, size_t partial_err_bytes_per_problem, std::vector<BatchLane>& lanes, int tiles_per_problem) {
   // round 3, 64 x 119 k FAST_GICP batch: 1 / 2 / 3 / 4 lanes = 5615 / 5755 / 5787 / 5811 registrations/s (round 2's kernels preferred 2 above 32 problems)
   // NDT (one launch per iteration, work queue inside): 2 / 3 / 4 lanes = 1679 / 1724 / 1652 on the 64-candidate batch (round 2: 1403 / 1384 / 1326)
-  const int wanted = h->batch_lanes > 0 ? h->batch_lanes : (h->prm.method == HGS_NDT_OMP && B > 32 ? 3 : 4);
+  // round 6, batches of SMALL problems (candidate keyframes of a KITTI run: prefiltered sweeps of 11-14 k points; scripts/probes/small_batch_lanes_probe.py,
+  // profiles/r06_small_batch_lanes.log): GICP's short kernels gain nothing from concurrent chains and pay for the extra streams — one lane: 6 / 12 / 24 / 48
+  // candidates x 11 k points 0.558 -> 0.505 / 0.683 -> 0.624 / 0.810 -> 0.782 / 1.092 -> 1.019 ms per detection (96 candidates: equal; 65 k-point problems:
+  // four lanes from 8 candidates on) — while NDT_OMP's passes want all four lanes also above 32 problems (48 x 11 k: 7.9 -> 6.8 ms).
+  const bool small_problems = tiles_per_problem > 0 && tiles_per_problem <= 96;
+  const int by_size = h->prm.method == HGS_NDT_OMP ? (B > 32 && !small_problems ? 3 : 4) : (small_problems && (long)B * tiles_per_problem <= 3072 ? 1 : 4);
+  const int wanted = h->batch_lanes > 0 ? h->batch_lanes : by_size;
   int n = h->profiling ? 1 : std::max(1, std::min(std::min(wanted, kMaxLanes), B));  // (h_flags / done hold 2 ints per lane: 64 bytes = 8 lanes)
   // the process's hardware-queue budget (above): lane streams this engine already owns are free, new ones only while there is room.
   // HGS_BATCH_LANES (A/B runs) overrides the budget.
@@ -1162,7 +1169,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     const NdtTargetView vtv = voxel ? vgicp_target_view(tgt) : NdtTargetView{};
     const long max_rounds = (long)std::max(1, c.max_iterations) * std::max(1, c.lm_max_iterations) + 2 + (round2 ? 1 : 0);  // (round2: a round's accept / reject runs in the next round's first kernel)
     std::vector<BatchLane> lanes;
-    HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
+    HGS_TRY(open_lanes(h, B, (size_t)max_blocks * kAccNdt * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes, err_blocks));
     auto finish_lane = [&](BatchLane& L) {
       if (early && *L.prog.host_done) {  // (not when the lane ran out of rounds: then the result kernel + copy below fetch whatever state it is in)
         h->early_valid = true;
@@ -1231,7 +1238,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
     // one derivative pass per iteration as ndt_omp runs; up to 1 + 10 with the More-Thuente search
     const long max_rounds = ((long)c.max_iterations + 4) * (c.line_search ? 11 : 1);
     std::vector<BatchLane> lanes;
-    HGS_TRY(open_lanes(h, B, (size_t)max_blocks * 2 * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes));
+    HGS_TRY(open_lanes(h, B, (size_t)max_blocks * 2 * sizeof(double), (size_t)max_blocks * 2 * sizeof(double), lanes, err_blocks));
     auto finish_lane = [&](BatchLane& L) {
       launch_ndt_results(L.stream, d_descs + L.b0, st + L.b0, h->results.as<DevResult>() + L.b0, L.B);
       if (fit_max_range) lane_fitness(h, L, d_descs, *fit_max_range, max_blocks, qpw, nn_tile);

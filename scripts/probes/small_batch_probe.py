@@ -17,7 +17,7 @@ rng = np.random.default_rng(5)
 for reg_method in ("FROBENIUS", "PLANE"):
     reg = select_registration_method({"registration_method": "FAST_GICP", "reg_regularization_method": reg_method}, device_id=0)
     reg.setInputTarget(tgt)
-    for B in (6, 12, 24, 48):
+    for B in (6, 12, 24, 48, 64):
         clouds = [reg.upload(src[rng.permutation(len(src))[: len(src) - 37 * k]]) for k in range(B)]
         guesses = [np.asarray(synth.pose_matrix(rng.normal(0, 0.15, 3), rng.normal(0, 0.01, 3)), np.float32) for _ in range(B)]
         ref = None

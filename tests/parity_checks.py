@@ -193,13 +193,13 @@ def check_two_launch_rounds_equal_four_launch_rounds(make_engine, reps=3, light=
         guesses = [guess, T2, np.eye(4), T2, guess]
         for n in (3, 5) if light else (1, 3, 4, 5):
             recs = []
-            for fused, max_blocks in ((0, 1536), (1, 1536), (1, 0)) if light else ((0, 1536), (1, 1536), (1, 1536), (1, 0)):  # (0: batches above 4 problems in four launches)
+            for fused, max_blocks in ((0, 100000), (1, 100000), (1, 0)) if light else ((0, 100000), (1, 100000), (1, 100000), (1, 0)):  # (0: batches above 4 problems in four launches)
                 e.set_option("fused_rounds", fused)
                 e.set_option("fused_rounds_max_blocks", max_blocks)
                 rec, best = e.loop_match_batch(clouds[:n], [np.asarray(g, np.float32) for g in guesses[:n]])
                 recs.append((rec.tobytes(), best))
             assert all(x == recs[0] for x in recs[1:]), n
-        e.set_option("fused_rounds_max_blocks", 1536)
+        e.set_option("fused_rounds_max_blocks", 640)
         for c in clouds:
             c.close()
         e.close()
