@@ -324,7 +324,7 @@ struct hgs_handle {
   PinnedBuffer h_early;                // the host-mapped record
   hipEvent_t early_event = nullptr;    // behind the rounds that were still queued when hgs_align returned early
   bool early_pending = false, early_valid = false;
-  int fused_rounds = 1;    // launches of <= kFusedRoundMaxProblems GICP problems of at most fused_rounds_below points each: the LM round in two launches (control steps replicated per block; 0: four launches per round)
+  int fused_rounds = 1;    // launches of a few GICP problems (below) of at most fused_rounds_below points each: the LM round in two launches (control steps replicated per block; 0: four launches per round)
   int fused_rounds_below = 262144;
   // ... or batches of more problems of at most that many 256-point tiles in total: the loop-closure batch of a KITTI run (candidate keyframes are prefiltered
   // sweeps of 11-14 k points).  Under four lanes: 6 / 12 / 24 candidates x 11 k points 0.62 -> 0.57 / 0.73 -> 0.68 / 0.88 -> 0.83 ms per detection, 48

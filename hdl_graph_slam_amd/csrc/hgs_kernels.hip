@@ -882,8 +882,8 @@ __device__ __forceinline__ void packet_nn1(const BvhView& tv, float* park, const
 // block of k_gicp_linearize<true> first runs the accept / reject step of the previous round on its own copy of the state (the same code on the same
 // partials: every block arrives at the same bits), every block of k_gicp_error<true> the solve of the linearisation just made; block 0 of a problem
 // writes the state out — into the OTHER of two state buffers, so that a block starting late never reads a state that has already been advanced.
-// Launches of <= kFusedRoundMaxProblems problems below the engine's size limit only: a 5 us serial step repeated by 250 blocks is latency nobody
-// waits for, repeated by 30 000 it is throughput.
+// Launches of <= kFusedRoundMaxProblems problems below the engine's size limit, and batches of small problems up to a few hundred tiles in total
+// (run_batch: fused_rounds_max_blocks), only: a 5 us serial step repeated by 250 blocks is latency nobody waits for, repeated by 30 000 it is throughput.
 __device__ __forceinline__ DevResult gicp_result_of(const GicpState& st) {
   DevResult r;
   pose_to_colmajor_f(st.x0, r.T);
