@@ -320,6 +320,7 @@ struct hgs_handle {
   // launches fill the device on their own and two chains are enough to cover each other's solves and tails.
   int prefilter_fast = 1;  // hgs_prefilter: distance filter inside the voxel grid's kernels, RadiusOutlierRemoval on the voxel grid (0: the separate passes + search tree; A/B, tests)
   int upload_trace = 0;
+  int early_run_ahead = 2;  // rounds the host keeps queued in front of a single registration that hands its result over early (the surplus drains behind the caller's back; 3 / 4 measured: no gain for the odometry source, config 2 0.837 -> 0.844 / 0.852 ms back to back: profiles/r06_ab16_early_run_ahead.log)
   int early_result = 1;    // a single registration in two-launch rounds hands its result over in host-mapped memory (run_batch; 0: result kernel + copy + synchronisation)
   PinnedBuffer h_early;                // the host-mapped record
   hipEvent_t early_event = nullptr;    // behind the rounds that were still queued when hgs_align returned early
@@ -1049,7 +1050,7 @@ int close_lanes(hgs_handle* h, std::vector<BatchLane>& lanes) {
 // failed) the loop keeps enqueueing up to max_rounds: the caller then sees the error from hipGetLastError.
 constexpr long kRunAhead = 2;  // one round executing, one queued behind it (a round is >= 100 us, enqueueing one ~20 us)
 template <typename F, typename G>
-void drive_lanes(std::vector<BatchLane>& lanes, long max_rounds, F&& enqueue_round, G&& on_finished) {
+void drive_lanes(std::vector<BatchLane>& lanes, long max_rounds, F&& enqueue_round, G&& on_finished, long run_ahead = kRunAhead) {
   long spins = 0;
   for (;;) {
     bool all_finished = true, enqueued = false;
@@ -1061,7 +1062,7 @@ void drive_lanes(std::vector<BatchLane>& lanes, long max_rounds, F&& enqueue_rou
         continue;
       }
       all_finished = false;
-      if (L.round - (long)*L.prog.host_rounds < kRunAhead) {
+      if (L.round - (long)*L.prog.host_rounds < run_ahead) {
         enqueue_round(L);
         L.round++;
         enqueued = true;
@@ -1075,7 +1076,7 @@ void drive_lanes(std::vector<BatchLane>& lanes, long max_rounds, F&& enqueue_rou
     if ((++spins & 0x3ff) == 0) {
       for (BatchLane& L : lanes)
         if (!L.finished && !*L.prog.host_done && hipStreamQuery(L.stream) == hipSuccess && !*L.prog.host_done &&
-            L.round - (long)*L.prog.host_rounds >= kRunAhead) {
+            L.round - (long)*L.prog.host_rounds >= run_ahead) {
           enqueue_round(L);  // drained without the mirror advancing: do not spin forever, max_rounds bounds the loop
           L.round++;
         }
@@ -1212,7 +1213,7 @@ int run_batch(hgs_handle* h, const std::vector<hgs_cloud*>& sources, const float
         StageTimer tm(h, HGS_STAGE_SOLVE);
         launch_gicp_decide(L.stream, dd, ls, c, L.partials_err, max_blocks, L.B, L.prog);
       }
-    }, finish_lane);
+    }, finish_lane, early ? (long)h->early_run_ahead : kRunAhead);
     HGS_TRY(close_lanes(h, lanes));
     if (h->early_valid) {  // rounds may still be queued (the host runs ahead): the next batch's mirror reset waits for them (make_progress)
       if (!h->early_event) HGS_HIP(h, hipEventCreateWithFlags(&h->early_event, hipEventDisableTiming));
@@ -1410,6 +1411,7 @@ int hgs_debug_set_option(hgs_handle* h, const char* key, int value) try {
   else if (k == "cov_split") h->cov_split = value != 0 ? 1 : 0;
   else if (k == "fused_rounds") h->fused_rounds = value != 0 ? 1 : 0;
   else if (k == "early_result") h->early_result = value != 0 ? 1 : 0;
+  else if (k == "early_run_ahead") h->early_run_ahead = std::max(1, std::min(8, value));
   else if (k == "fused_rounds_max_problems") h->fused_rounds_max_problems = std::max(0, value);
   else if (k == "fused_rounds_max_blocks") h->fused_rounds_max_blocks = std::max(0, value);
   else if (k == "fused_rounds_below") h->fused_rounds_below = std::max(0, value);

@@ -292,7 +292,7 @@ int hgs_debug_ndt_derivatives(hgs_handle* h, const double p6[6], double* score, 
 int hgs_debug_merge_shard_records(const hgs_result* gathered, const int32_t* counts, int32_t world, size_t per, size_t n_total,
                                   hgs_result* all_out, int32_t* duplicate_id);
 /* A measurement / test knob of one engine: "batch_lanes", "lane_start", "ndt_sort", "cov_split", "resident_descs", "knn_qpw_tiny",
- * "seed_grid", "knn_replay", "ndt_resident", "ndt_chunk", "hilbert_levels", "nn_qpw", "nn_qpw16_below", "nn_qpw32_below", "fused_rounds", "fused_rounds_below", "fused_rounds_max_problems", "fused_rounds_max_blocks", "early_result",
+ * "seed_grid", "knn_replay", "ndt_resident", "ndt_chunk", "hilbert_levels", "nn_qpw", "nn_qpw16_below", "nn_qpw32_below", "fused_rounds", "fused_rounds_below", "fused_rounds_max_problems", "fused_rounds_max_blocks", "early_result", "early_run_ahead",
  * "knn_tiny_below", "upload_trace", "prefilter_fast".  Results never depend on them (the tests
  * that force a code path check exactly that); A/B runs and those tests are the only callers — the library reads no tuning variable from the environment. */
 int hgs_debug_set_option(hgs_handle* h, const char* key, int32_t value);
