@@ -792,7 +792,8 @@ __device__ __forceinline__ void last_wave_stores(const double* lds /* [4 * N] */
 // bound).  2.6 MB per 119 k-point target, built once per target index (~10 us), shared by all candidates of a batch.  Measured (round 6,
 // profiles/r06_ab_seed_grid.log): NDT batch k_fitness 1.52 -> 1.13 ms.  NOT used by k_gicp_linearize: the first linearisation of a registration is
 // slow because its true nearest-neighbour distances are large (the guess is off by decimetres), not because it lacks a bound — with grid seeds
-// the stage measured 6.40 instead of 6.33 ms.
+// the stage measured 6.40 instead of 6.33 ms.  Refining the grid's point inside its own leaf (the nearest of the eight points that share it: a tighter bound for
+// eight distances) does not pay either: NDT batch k_fitness 1.12 -> 1.14 ms (profiles/r06_ab17_seed_refine.log).
 #ifndef HGS_SEED_INV0
 #define HGS_SEED_INV0 4.0f  // finest cell: 0.25 m
 #endif
